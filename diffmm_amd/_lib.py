@@ -1,0 +1,114 @@
+"""ctypes binding of libdiffmm_hip.so (include/diffmm_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this module raises.
+Build the library with `python __graft_entry__.py` (or `make -C diffmm_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffmm_hip.so")
+
+SPMM_MAX_BATCH = 4
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+
+
+class SpmmProblem(C.Structure):
+    _fields_ = [("tasks", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("x_lo", C.c_void_p), ("x_hi", C.c_void_p),
+                ("y", C.c_void_p), ("c1", C.c_void_p), ("c2", C.c_void_p), ("y_pert", C.c_void_p), ("noise", C.c_void_p),
+                ("y_mean", C.c_void_p), ("m1", C.c_void_p), ("m2", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("n_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
+                ("noise_degree", C.c_float)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("sam", C.c_int64), ("sak", C.c_int64), ("B", C.c_void_p), ("sbk", C.c_int64), ("sbn", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("alpha", C.c_float), ("e1", C.c_float), ("e2", C.c_float),
+                ("act", C.c_int32), ("split_k", C.c_int32), ("precision", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class GatherDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("grad", C.c_void_p)]
+
+
+class InfoNCETerm(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("temp", C.c_float), ("weight", C.c_float)]
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_U64 = C.c_uint64
+
+_SIGS = {
+    "dmm_version": (C.c_int, []),
+    "dmm_last_error_string": (C.c_char_p, []),
+    "dmm_spmm_tasks_per_block": (C.c_int, [_I]),
+    "dmm_spmm_csr_f32": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
+    "dmm_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
+    "dmm_rownorm_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "dmm_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    "dmm_gcn_mix_fwd": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _L, _P]),
+    "dmm_gcn_mix_partials": (C.c_int64, [_L]),
+    "dmm_gcn_mix_bwd": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _I, _F, _P, _L, _P]),
+    "dmm_gather_normalize": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P]),
+    "dmm_infonce_fwd": (C.c_int, [_P, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P]),
+    "dmm_infonce_bwd": (C.c_int, [_P, _P, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P]),
+    "dmm_scatter_normalize_bwd": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
+    "dmm_bpr_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "dmm_segment_sum": (C.c_int, [_P, _I, _L, _F, _P, _P]),
+    "dmm_sumsq_scratch": (C.c_int64, [_L]),
+    "dmm_sumsq": (C.c_int, [_P, _L, _F, _P, _P, _P]),
+    "dmm_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P]),
+    "dmm_qsample_temb": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),
+    "dmm_temb_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
+    "dmm_mul_sigmoid_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
+    "dmm_gate_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _P]),
+    "dmm_tanh_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
+    "dmm_add_inplace": (C.c_int, [_P, _P, _F, _L, _P]),
+    "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),
+    "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P]),
+    "dmm_topk_rows": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def exported_symbols():
+    return sorted(_SIGS.keys())
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` -- diffmm_amd has no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().dmm_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"libdiffmm_hip {what} failed with code {code}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("diffmm_amd kernels take device tensors only (there is no CPU path)")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

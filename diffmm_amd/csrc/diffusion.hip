@@ -1,0 +1,243 @@
+// Diffusion-path kernels that are not GEMMs: q_sample + time embedding (operand builder of Denoise layer 1),
+// the diffusion loss with its direct gradients, and the per-user top-k of the rebuild.
+// Reference: GaussianDiffusion.forward_cal_xt (Model.py:324-341), Denoise.forward time embedding (Model.py:196-202),
+// training_losses (Model.py:407-425), Coach.trainEpoch rebuild loop (Main.py:224-230).
+#include "common.h"
+
+namespace dmm {
+
+constexpr int MAX_TE = 32;
+
+__device__ __forceinline__ void time_features(int t, int te, float* e /*[te]*/) {
+  const int half = te / 2;
+  for (int k = 0; k < half; ++k) {
+    const float f = expf((-9.210340371976184f * (float)k) / (float)half);
+    const float ang = (float)t * f;
+    e[k] = cosf(ang);
+    e[half + k] = sinf(ang);
+  }
+  if (te & 1) e[te - 1] = 0.f;
+}
+
+// one workgroup per batch row
+__global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restrict__ x0, long long ldx0, const float* __restrict__ noise,
+                                                            const int32_t* __restrict__ t, const float* __restrict__ sqrt_ac,
+                                                            const float* __restrict__ sqrt_1mac, const float* __restrict__ w_emb,
+                                                            const float* __restrict__ b_emb, int te, float* __restrict__ xcat, long long ldx,
+                                                            int I, int draw_noise, unsigned long long seed, unsigned long long offset,
+                                                            float* __restrict__ eps_out) {
+  const int b = blockIdx.x;
+  const int tb = t[b];
+  float* __restrict__ row = xcat + (long long)b * ldx;
+  if (x0) {
+    const bool has_eps = noise != nullptr || draw_noise;
+    const float a = has_eps ? sqrt_ac[tb] : 1.0f, c = has_eps ? sqrt_1mac[tb] : 0.0f;
+    const float* __restrict__ xr = x0 + (long long)b * ldx0;
+    if (noise || !draw_noise) {
+      for (int j = threadIdx.x; j < I; j += 256) {
+        const float e = noise ? noise[(long long)b * I + j] : 0.f;
+        row[j] = a * xr[j] + c * e;
+        if (eps_out) eps_out[(long long)b * I + j] = e;
+      }
+    } else {
+      // 4 normals per Philox call: thread handles columns 4q .. 4q+3
+      for (int q = threadIdx.x; q * 4 < I; q += 256) {
+        const uint4 r = philox4(seed, offset + (unsigned long long)b * ((I + 3) / 4) + q, 0xd1ffu);
+        const float2 n0 = box_muller(r.x, r.y), n1 = box_muller(r.z, r.w);
+        const float e[4] = {n0.x, n0.y, n1.x, n1.y};
+        for (int u = 0; u < 4; ++u) {
+          const int j = 4 * q + u;
+          if (j < I) {
+            row[j] = a * xr[j] + c * e[u];
+            if (eps_out) eps_out[(long long)b * I + j] = e[u];
+          }
+        }
+      }
+    }
+  }
+  // time embedding -> columns I .. I+te, zero padding up to ldx
+  __shared__ float e[MAX_TE];
+  if (threadIdx.x == 0) time_features(tb, te, e);
+  __syncthreads();
+  for (int c = threadIdx.x; I + c < ldx; c += 256) {
+    float v = 0.f;
+    if (c < te) {
+      v = b_emb[c];
+      for (int k = 0; k < te; ++k) v = fmaf(w_emb[c * te + k], e[k], v);
+    }
+    row[I + c] = v;
+  }
+}
+
+// d w_emb[c][k] = sum_b dtemb[b][c] * e_b[k],  d b_emb[c] = sum_b dtemb[b][c]   (single workgroup; te <= 32)
+__global__ __launch_bounds__(1024) void temb_bwd_kernel(const int32_t* __restrict__ t, const float* __restrict__ dxcat, long long ldx, int I,
+                                                         int te, int B, float* __restrict__ dw, float* __restrict__ db) {
+  const int c = threadIdx.x / te, k = threadIdx.x % te;
+  if (c >= te) return;
+  double aw = 0.0, ab = 0.0;
+  const int half = te / 2;
+  const bool is_pad = (te & 1) && k == te - 1;
+  const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
+  for (int b = 0; b < B; ++b) {
+    const float ang = (float)t[b] * f;
+    const float ek = is_pad ? 0.f : (k < half ? cosf(ang) : sinf(ang));
+    const float g = dxcat[(long long)b * ldx + I + c];
+    aw += (double)g * (double)ek;
+    ab += (double)g;
+  }
+  dw[c * te + k] += (float)aw;
+  if (k == 0) db[c] += (float)ab;
+}
+
+// diffusion loss: one workgroup per batch row
+__global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict__ out, const float* __restrict__ x0, long long ld,
+                                                         const double* __restrict__ w, const float* __restrict__ um,
+                                                         const float* __restrict__ ui, int I, int d, float sim_weight, double reg_term,
+                                                         double gscale, double* __restrict__ loss, float* __restrict__ dout,
+                                                         float* __restrict__ dum) {
+  __shared__ double smd[4];
+  __shared__ float smf[4];
+  const int b = blockIdx.x;
+  const float* __restrict__ o = out + (long long)b * ld;
+  const float* __restrict__ x = x0 + (long long)b * ld;
+  const double wb = w[b];
+  const float gcoef = (float)(gscale * wb * 2.0 / (double)I);
+  double a = 0.0;
+  for (int j = threadIdx.x; j < I; j += 256) {
+    const float df = o[j] - x[j];
+    a += (double)(df * df);
+    if (dout) dout[(long long)b * ld + j] = gcoef * df;
+  }
+  const double sse = block_sum_256d(a, smd);
+  // cosine similarity of the two d-vectors
+  float dot = 0.f, nu = 0.f, ni = 0.f;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float p = um[(long long)b * d + c], q = ui[(long long)b * d + c];
+    dot += p * q; nu += p * p; ni += q * q;
+  }
+  dot = block_sum_256(dot, smf);
+  nu = sqrtf(block_sum_256(nu, smf));
+  ni = sqrtf(block_sum_256(ni, smf));
+  const float cu = fmaxf(nu, 1e-8f), ci = fmaxf(ni, 1e-8f);
+  const float cosv = dot / (cu * ci);
+  if (threadIdx.x == 0) loss[b] = wb * (sse / (double)I) + (double)sim_weight * (1.0 - (double)cosv) + reg_term;
+  if (dum) {
+    const float gs = (float)gscale * sim_weight;
+    for (int c = threadIdx.x; c < d; c += 256) {
+      const float p = um[(long long)b * d + c], q = ui[(long long)b * d + c];
+      // d(1 - cos)/d um = -( q / (cu ci) - cos * p / cu^2 )   (the second term vanishes in the clamped branch)
+      const float dcos = q / (cu * ci) - (nu > 1e-8f ? cosv * p / (cu * cu) : 0.f);
+      dum[(long long)b * d + c] = -gs * dcos;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-row top-k (k = the user's train degree): bitwise threshold search on order-preserving keys,
+// then an ordered compaction.  Deterministic; ties at the threshold go to the smaller column id.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int block_sum_int(int v, int* sm4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm4[0] + sm4[1] + sm4[2] + sm4[3];
+}
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long long ldx, const int32_t* __restrict__ row_ids,
+                                                         const int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_idx, int cols) {
+  __shared__ int sm4[4];
+  __shared__ int wave_off[5];
+  const int u = row_ids[blockIdx.x];
+  const int beg = out_ptr[u];
+  int k = out_ptr[u + 1] - beg;
+  if (k <= 0) return;  // uniform per block
+  if (k > cols) k = cols;
+  const float* __restrict__ r = x + (long long)blockIdx.x * ldx;
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = T | (1u << bit);
+    int c = 0;
+    for (int j = threadIdx.x; j < cols; j += 256) c += fkey(r[j]) >= cand;
+    if (block_sum_int(c, sm4) >= k) T = cand;
+  }
+  int c = 0;
+  for (int j = threadIdx.x; j < cols; j += 256) c += fkey(r[j]) > T;
+  const int n_gt = block_sum_int(c, sm4);
+  int need_ties = k - n_gt;  // >= 1 by construction
+  int written = 0;           // uniform running output position
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j0 = 0; j0 < cols; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    const uint32_t key = j < cols ? fkey(r[j]) : 0u;
+    const bool gt = j < cols && key > T, tie = j < cols && key == T;
+    // ordered ranks of this thread among the chunk's gt / tie elements
+    const unsigned long long mg = __ballot(gt), mt = __ballot(tie);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    __syncthreads();
+    if (lane == 0) { sm4[wave] = __popcll(mg); wave_off[wave] = __popcll(mt); }
+    __syncthreads();
+    int gbase = 0, tbase = 0, gtot = 0, ttot = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      if (w2 < wave) { gbase += sm4[w2]; tbase += wave_off[w2]; }
+      gtot += sm4[w2]; ttot += wave_off[w2];
+    }
+    const int tie_rank = tbase + __popcll(mt & below);
+    const int ties_taken_chunk = min(ttot, need_ties);
+    const bool take_tie = tie && tie_rank < need_ties;
+    // output order inside the chunk: ascending column => merge gt and taken ties by column id
+    // rank of this element = (# gt before it) + (# taken ties before it)
+    if (gt || take_tie) {
+      const int gt_before = gbase + __popcll(mg & below);
+      // taken ties before this column: ties with rank < need_ties and smaller column
+      const int ties_before = min(tbase + __popcll(mt & below), need_ties);
+      out_idx[beg + written + gt_before + ties_before] = j;
+    }
+    written += gtot + ties_taken_chunk;
+    need_ties -= ties_taken_chunk;
+  }
+}
+
+}  // namespace dmm
+using namespace dmm;
+
+extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const int32_t* t, const float* sqrt_ac,
+                                const float* sqrt_1mac, const float* w_emb, const float* b_emb, int te, float* xcat, int64_t ldx, int B, int I,
+                                int draw_noise, uint64_t seed, uint64_t offset, float* eps_out, void* stream) {
+  DMM_CHECK_ARG(t && w_emb && b_emb && xcat && B > 0 && I > 0, "dmm_qsample_temb: null operand");
+  DMM_CHECK_ARG(te >= 2 && te <= MAX_TE && ldx >= I + te, "dmm_qsample_temb: te=%d must be 2..%d and ldx >= I+te", te, MAX_TE);
+  DMM_CHECK_ARG(!(noise || draw_noise) || (sqrt_ac && sqrt_1mac), "dmm_qsample_temb: schedule tables missing");
+  hipLaunchKernelGGL(qsample_temb_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)ldx0, noise, t, sqrt_ac, sqrt_1mac, w_emb,
+                     b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out);
+  DMM_LAUNCH_CHECK("dmm_qsample_temb");
+  return 0;
+}
+
+extern "C" int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, int I, int te, int B, float* dw_emb, float* db_emb, void* stream) {
+  DMM_CHECK_ARG(t && dxcat && dw_emb && db_emb && te >= 2 && te <= MAX_TE && B > 0, "dmm_temb_bwd: bad arguments");
+  hipLaunchKernelGGL(temb_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t, dxcat, (long long)ldx, I, te, B, dw_emb, db_emb);
+  DMM_LAUNCH_CHECK("dmm_temb_bwd");
+  return 0;
+}
+
+extern "C" int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w, const float* um, const float* ui, int B, int I, int d,
+                             float sim_weight, double reg_term, double gscale, double* loss, float* dout, float* dum, void* stream) {
+  DMM_CHECK_ARG(out && x0 && w && um && ui && loss && B > 0 && I > 0 && d > 0, "dmm_diff_loss: bad arguments");
+  hipLaunchKernelGGL(diff_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, x0, (long long)ld, w, um, ui, I, d, sim_weight, reg_term,
+                     gscale, loss, dout, dum);
+  DMM_LAUNCH_CHECK("dmm_diff_loss");
+  return 0;
+}
+
+extern "C" int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids, const int32_t* out_ptr, int32_t* out_idx, int rows, int cols,
+                             void* stream) {
+  DMM_CHECK_ARG(x && row_ids && out_ptr && out_idx && rows > 0 && cols > 0, "dmm_topk_rows: bad arguments");
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, row_ids, out_ptr, out_idx, cols);
+  DMM_LAUNCH_CHECK("dmm_topk_rows");
+  return 0;
+}

@@ -1,0 +1,378 @@
+// Memory-bound pieces of the joint step: row normalisation, modal mixing, reductions, fused Adam.
+// All are HBM/L2-bandwidth kernels: 16-byte accesses per lane, grid-stride, <= 2048 workgroups.
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace dmm {
+static std::mutex g_err_mu;
+static char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+static inline unsigned grid_for(int64_t work_items, int per_block) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+}  // namespace dmm
+
+extern "C" int dmm_version(void) { return DMM_VERSION; }
+extern "C" const char* dmm_last_error_string(void) { return dmm::g_err; }
+
+namespace dmm {
+
+// ---------------------------------------------------------------------------------------------
+// row normalise: one group of LANES = D/4 lanes per row (same shape as the SpMM groups)
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           float* __restrict__ norm, int rows) {
+  constexpr int LANES = D / 4, G = 256 / LANES;
+  const int l = threadIdx.x % LANES;
+  for (int r = blockIdx.x * G + threadIdx.x / LANES; r < rows; r += gridDim.x * G) {  // group-uniform trip count
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * D + 4 * l);
+    float ss = group_sum<LANES>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    const float nrm = sqrtf(ss);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    *reinterpret_cast<float4*>(y + (size_t)r * D + 4 * l) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    if (l == 0 && norm) norm[r] = nrm;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ norm, float* __restrict__ dx, int rows) {
+  constexpr int LANES = D / 4, G = 256 / LANES;
+  const int l = threadIdx.x % LANES;
+  for (int r = blockIdx.x * G + threadIdx.x / LANES; r < rows; r += gridDim.x * G) {
+    const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * D + 4 * l);
+    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * D + 4 * l);
+    const float nrm = norm[r];
+    float4 o;
+    if (nrm < 1e-12f) {  // clamped branch of F.normalize: y = x / eps
+      o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+    } else {
+      const float dot = group_sum<LANES>(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
+      const float inv = 1.0f / nrm;
+      o = make_float4((g.x - v.x * dot) * inv, (g.y - v.y * dot) * inv, (g.z - v.z * dot) * inv, (g.w - v.w * dot) * inv);
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)r * D + 4 * l) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// modal mixing
+// ---------------------------------------------------------------------------------------------
+struct MixPtrs {
+  const float* z[3];
+  float* dz[3];
+};
+
+__device__ __forceinline__ void softmax3(const float* logits, int M, float (&w)[3]) {
+  float mx = logits[0];
+  for (int m = 1; m < M; ++m) mx = fmaxf(mx, logits[m]);
+  float s = 0.f;
+  for (int m = 0; m < 3; ++m) {
+    w[m] = m < M ? expf(logits[m] - mx) : 0.f;
+    s += w[m];
+  }
+  for (int m = 0; m < 3; ++m) w[m] /= s;
+}
+
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ bx, MixPtrs P, const float* __restrict__ logits,
+                                                       int M, float maw, float* __restrict__ mx, int64_t n4) {
+  float w[3];
+  softmax3(logits, M, w);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 b = reinterpret_cast<const float4*>(bx)[i];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < M; ++m) {  // same association as the reference: w_m * (bx + maw * z_m), summed over m
+      const float4 z = reinterpret_cast<const float4*>(P.z[m])[i];
+      o.x += w[m] * (b.x + maw * z.x);
+      o.y += w[m] * (b.y + maw * z.y);
+      o.z += w[m] * (b.z + maw * z.z);
+      o.w += w[m] * (b.w + maw * z.w);
+    }
+    reinterpret_cast<float4*>(mx)[i] = o;
+  }
+}
+
+// dbx = sw*dmx + extra ; dz_m += maw*w_m*dmx ; partial[blk][m] = sum dmx * (bx + maw z_m)
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dmx, const float* __restrict__ bx, MixPtrs P,
+                                                       const float* __restrict__ extra, float* __restrict__ dbx,
+                                                       const float* __restrict__ logits, int M, float maw,
+                                                       float* __restrict__ partials, int64_t n4) {
+  __shared__ float sm4[4];
+  float w[3];
+  softmax3(logits, M, w);
+  const float sw = w[0] + w[1] + w[2];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 g = reinterpret_cast<const float4*>(dmx)[i];
+    const float4 b = reinterpret_cast<const float4*>(bx)[i];
+    float4 o = make_float4(sw * g.x, sw * g.y, sw * g.z, sw * g.w);
+    if (extra) {
+      const float4 e = reinterpret_cast<const float4*>(extra)[i];
+      o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+    }
+    reinterpret_cast<float4*>(dbx)[i] = o;
+    for (int m = 0; m < M; ++m) {
+      const float4 z = reinterpret_cast<const float4*>(P.z[m])[i];
+      acc[m] += g.x * (b.x + maw * z.x) + g.y * (b.y + maw * z.y) + g.z * (b.z + maw * z.z) + g.w * (b.w + maw * z.w);
+      float4 d = reinterpret_cast<float4*>(P.dz[m])[i];
+      const float c = maw * w[m];
+      d.x += c * g.x; d.y += c * g.y; d.z += c * g.z; d.w += c * g.w;
+      reinterpret_cast<float4*>(P.dz[m])[i] = d;
+    }
+  }
+  for (int m = 0; m < 3; ++m) {
+    const float s = block_sum_256(acc[m], sm4);
+    if (threadIdx.x == 0) partials[blockIdx.x * 3 + m] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void mix_bwd_final_kernel(const float* __restrict__ partials, int nblk,
+                                                             const float* __restrict__ logits, int M, float* __restrict__ dlogits) {
+  __shared__ double sm4[4];
+  double g[3];
+  for (int m = 0; m < 3; ++m) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += (double)partials[i * 3 + m];
+    g[m] = block_sum_256d(a, sm4);
+  }
+  if (threadIdx.x == 0) {
+    float w[3];
+    softmax3(logits, M, w);
+    double dotwg = 0.0;
+    for (int m = 0; m < M; ++m) dotwg += (double)w[m] * g[m];
+    for (int m = 0; m < M; ++m) dlogits[m] = (float)((double)w[m] * (g[m] - dotwg));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ in, int64_t len, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ double sm4[4];
+  const float* p = in + (size_t)blockIdx.x * len;
+  double a = 0.0;
+  for (int64_t i = threadIdx.x; i < len; i += 256) a += (double)p[i];
+  a = block_sum_256d(a, sm4);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)(a * (double)scale);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float sm4[4];
+  float a = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = x[(n4 << 2) + threadIdx.x];
+    a += v * v;
+  }
+  a = block_sum_256(a, sm4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam
+// ---------------------------------------------------------------------------------------------
+struct AdamExtra {
+  const float* g[4];
+  int64_t n[4];
+  int cnt;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, AdamExtra ex, float l2c, float step_size,
+                                                    float b1, float b2, float inv_sqrt_c2, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float pv = p[i];
+    float gr = g[i];
+    for (int k = 0; k < ex.cnt; ++k)
+      if (i < ex.n[k]) gr += ex.g[k][i];
+    gr = fmaf(l2c, pv, gr);
+    const float mm = b1 * m[i] + (1.0f - b1) * gr;
+    const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = pv - step_size * mm / (sqrtf(vv) * inv_sqrt_c2 + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small elementwise ops of the diffusion path
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] * b[i];
+}
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ proj,
+                                                        const float* __restrict__ gate, float* __restrict__ dproj,
+                                                        float* __restrict__ dpre, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = dout[i], s = gate[i];
+    dproj[i] = d * s;
+    dpre[i] = d * proj[i] * s * (1.0f - s);
+  }
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                        float* __restrict__ dpre, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float t = h[i];
+    dpre[i] = dh[i] * (1.0f - t * t);
+  }
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = fmaf(alpha, x[i], y[i]);
+}
+// column sums: block (64 columns) x all rows; 4 waves split the rows, combine through LDS
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, float* __restrict__ out) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  double a = 0.0;
+  if (c < cols)
+    for (int r = w; r < rows; r += 4) a += (double)x[(size_t)r * ldx + c];
+  sm[w][threadIdx.x & 63] = (float)a;
+  __syncthreads();
+  if (w == 0 && c < cols) out[c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+template <int D>
+static int rownorm_launch(bool fwd, const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out, int rows, hipStream_t s) {
+  constexpr int G = 1024 / D;
+  const unsigned grid = grid_for(rows, G);
+  if (fwd)
+    hipLaunchKernelGGL(rownorm_fwd_kernel<D>, dim3(grid), dim3(256), 0, s, a, out, nrm_out, rows);
+  else
+    hipLaunchKernelGGL(rownorm_bwd_kernel<D>, dim3(grid), dim3(256), 0, s, a, b, nrm_in, out, rows);
+  DMM_LAUNCH_CHECK("dmm_rownorm");
+  return 0;
+}
+static int rownorm_dispatch(bool fwd, const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out, int rows, int D, hipStream_t s) {
+  switch (D) {
+    case 8: return rownorm_launch<8>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+    case 16: return rownorm_launch<16>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+    case 32: return rownorm_launch<32>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+    case 64: return rownorm_launch<64>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+    case 128: return rownorm_launch<128>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+    case 256: return rownorm_launch<256>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+  }
+  set_error("dmm_rownorm: D=%d unsupported (8,16,32,64,128,256)", D);
+  return DMM_ERR_INVALID_ARG;
+}
+}  // namespace dmm
+
+using namespace dmm;
+
+extern "C" int dmm_rownorm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream) {
+  DMM_CHECK_ARG(x && y && rows >= 0, "dmm_rownorm_fwd: null operand");
+  if (rows == 0) return 0;
+  return rownorm_dispatch(true, x, nullptr, nullptr, y, norm, rows, D, (hipStream_t)stream);
+}
+extern "C" int dmm_rownorm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream) {
+  DMM_CHECK_ARG(dy && y && norm && dx && rows >= 0, "dmm_rownorm_bwd: null operand");
+  if (rows == 0) return 0;
+  return rownorm_dispatch(false, dy, y, norm, dx, nullptr, rows, D, (hipStream_t)stream);
+}
+
+extern "C" int dmm_gcn_mix_fwd(const float* bx, const float* const* z, const float* w_logits, int M, float maw, float* mx,
+                               int64_t n, void* stream) {
+  DMM_CHECK_ARG(bx && z && w_logits && mx && (M == 2 || M == 3) && n % 4 == 0, "dmm_gcn_mix_fwd: bad arguments (M=%d n=%lld)", M, (long long)n);
+  MixPtrs P = {};
+  for (int m = 0; m < M; ++m) P.z[m] = z[m];
+  hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, bx, P, w_logits, M, maw, mx, n / 4);
+  DMM_LAUNCH_CHECK("dmm_gcn_mix_fwd");
+  return 0;
+}
+extern "C" int64_t dmm_gcn_mix_partials(int64_t n) { return (int64_t)grid_for(n / 4, 256) * 3; }
+extern "C" int dmm_gcn_mix_bwd(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
+                               float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
+                               void* stream) {
+  DMM_CHECK_ARG(dmx && bx && z && dz && dbx && w_logits && dw_logits && partials && (M == 2 || M == 3) && n % 4 == 0,
+                "dmm_gcn_mix_bwd: bad arguments");
+  MixPtrs P = {};
+  for (int m = 0; m < M; ++m) {
+    P.z[m] = z[m];
+    P.dz[m] = dz[m];
+  }
+  const unsigned grid = grid_for(n / 4, 256);
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, w_logits, M, maw, partials, n / 4);
+  hipLaunchKernelGGL(mix_bwd_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)grid, w_logits, M, dw_logits);
+  DMM_LAUNCH_CHECK("dmm_gcn_mix_bwd");
+  return 0;
+}
+
+extern "C" int dmm_segment_sum(const float* in, int n_seg, int64_t len, float scale, float* out, void* stream) {
+  DMM_CHECK_ARG(in && out && n_seg > 0 && len >= 0, "dmm_segment_sum: bad arguments");
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, in, len, scale, out);
+  DMM_LAUNCH_CHECK("dmm_segment_sum");
+  return 0;
+}
+extern "C" int64_t dmm_sumsq_scratch(int64_t n) { return grid_for(n / 4 + 1, 1024); }
+extern "C" int dmm_sumsq(const float* x, int64_t n, float scale, float* scratch, float* out, void* stream) {
+  DMM_CHECK_ARG(x && scratch && out && n > 0, "dmm_sumsq: bad arguments");
+  DMM_CHECK_ARG(((uintptr_t)x & 15) == 0, "dmm_sumsq: x must be 16-byte aligned");
+  const unsigned grid = grid_for(n / 4 + 1, 1024);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, (int64_t)grid, scale, out);
+  DMM_LAUNCH_CHECK("dmm_sumsq");
+  return 0;
+}
+
+extern "C" int dmm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
+                             int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  DMM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && n_extra >= 0 && n_extra <= 4, "dmm_adam_step: bad arguments");
+  AdamExtra ex = {};
+  ex.cnt = n_extra;
+  for (int k = 0; k < n_extra; ++k) {
+    ex.g[k] = extra[k];
+    ex.n[k] = extra_n[k];
+  }
+  const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ex, l2_coef,
+                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps);
+  DMM_LAUNCH_CHECK("dmm_adam_step");
+  return 0;
+}
+
+extern "C" int dmm_mul_sigmoid_fwd(const float* proj, const float* gate, float* out, int64_t n, void* stream) {
+  DMM_CHECK_ARG(proj && gate && out && n > 0, "dmm_mul_sigmoid_fwd: bad arguments");
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, proj, gate, out, n);
+  DMM_LAUNCH_CHECK("dmm_mul_sigmoid_fwd");
+  return 0;
+}
+extern "C" int dmm_gate_bwd(const float* dout, const float* proj, const float* gate, float* dproj, float* dgate_pre, int64_t n, void* stream) {
+  DMM_CHECK_ARG(dout && proj && gate && dproj && dgate_pre && n > 0, "dmm_gate_bwd: bad arguments");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, dout, proj, gate, dproj, dgate_pre, n);
+  DMM_LAUNCH_CHECK("dmm_gate_bwd");
+  return 0;
+}
+extern "C" int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* stream) {
+  DMM_CHECK_ARG(dh && h && dpre && n > 0, "dmm_tanh_bwd: bad arguments");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, dh, h, dpre, n);
+  DMM_LAUNCH_CHECK("dmm_tanh_bwd");
+  return 0;
+}
+extern "C" int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n, void* stream) {
+  DMM_CHECK_ARG(y && x && n > 0, "dmm_add_inplace: bad arguments");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
+  DMM_LAUNCH_CHECK("dmm_add_inplace");
+  return 0;
+}
+extern "C" int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, void* stream) {
+  DMM_CHECK_ARG(x && out && rows > 0 && cols > 0, "dmm_colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out);
+  DMM_LAUNCH_CHECK("dmm_colsum");
+  return 0;
+}

@@ -1,0 +1,185 @@
+// CSR SpMM  Y = alpha * A X (+ beta C1 + gamma C2)  with fused epilogues, batched over up to 4 problems.
+//
+// Replaces the reference's torch.sparse.mm call sites (Model.py:90,93,105,111,114,123,130; Main.py:319)
+// and their autograd backward (A symmetric => dX = A dY, the same kernel).
+//
+// Work decomposition (MI355X: 256 CUs x 4 SIMDs, wave = 64):
+//   * one "group" of LANES = D/4 consecutive lanes owns one TASK = (row, [nz_begin, nz_end)); every lane
+//     keeps a float4 of the output row, so one group reads a full X row as one coalesced D*4-byte segment;
+//   * rows longer than the planner's task length are split into k <= G consecutive tasks of the SAME
+//     workgroup (G = 1024 / D groups per 256-thread workgroup); the partial rows are combined through LDS in
+//     task order, so results are bitwise reproducible -- no atomics.  This is what balances the TikTok
+//     degree law (1 % of the rows hold 70 % of the non-zeros) across waves;
+//   * the host planner (diffmm_amd/graph.py: plan_tasks) emits the task list; padding tasks have row = -1.
+//   * blockIdx -> work is remapped so that each XCD (private 4 MiB L2) walks one contiguous slice of the task
+//     list: user-row tasks gather only item rows of X and vice versa, so a slice's gather set is about half
+//     of X and stays L2 resident.
+//
+// Epilogues (all optional, selected per problem):
+//   y      = alpha*acc + beta*c1[row] + gamma*c2[row]
+//   y_pert = y + sign(y) * normalize_row(noise[row]) * noise_degree      (Main.py:320-321; noise read from a
+//            buffer for parity tests, or drawn in-kernel with Philox when noise == nullptr)
+//   y_mean = (y_pert + m1[row] + m2[row]) / 3                             (Main.py:325, mean of the 3 CL layers)
+#include "common.h"
+
+namespace dmm {
+
+struct SpmmBatch {
+  dmm_spmm_problem p[DMM_SPMM_MAX_BATCH];
+  int block_begin[DMM_SPMM_MAX_BATCH + 1];
+  int n;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
+  constexpr int LANES = D / 4;      // lanes per task group
+  constexpr int G = 256 / LANES;    // task groups per workgroup
+  __shared__ float4 part[256];
+
+  // which problem does this workgroup belong to (n <= 4: a short uniform scan)
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < DMM_SPMM_MAX_BATCH; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.block_begin[i]) pi = i;
+  const dmm_spmm_problem& P = batch.p[pi];
+  const int nblk = batch.block_begin[pi + 1] - batch.block_begin[pi];
+  const int lb = xcd_remap((int)blockIdx.x - batch.block_begin[pi], nblk);
+
+  const int g = threadIdx.x / LANES;
+  const int l = threadIdx.x % LANES;
+  const int4 task = reinterpret_cast<const int4*>(P.tasks)[lb * G + g];
+  const int row = task.x, beg = task.y, end = task.z;
+  const int run_len = task.w & 0xffff, run_pos = task.w >> 16;
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row >= 0) {
+    const int* __restrict__ col = P.col;
+    const float* __restrict__ val = P.val;
+    const float* __restrict__ xlo = P.x_lo;
+    const float* __restrict__ xhi = P.x_hi;
+    const int split = P.split;
+    int p = beg;
+    // 4 independent gathers in flight per lane
+    for (; p + 4 <= end; p += 4) {
+      int c[4];
+      float v[4];
+      float4 x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = col[p + j];
+        v[j] = val[p + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* src = c[j] < split ? xlo + (size_t)c[j] * D : xhi + (size_t)(c[j] - split) * D;
+        x[j] = *reinterpret_cast<const float4*>(src + 4 * l);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc.x = fmaf(v[j], x[j].x, acc.x);
+        acc.y = fmaf(v[j], x[j].y, acc.y);
+        acc.z = fmaf(v[j], x[j].z, acc.z);
+        acc.w = fmaf(v[j], x[j].w, acc.w);
+      }
+    }
+    for (; p < end; ++p) {
+      const int c = col[p];
+      const float v = val[p];
+      const float* src = c < split ? xlo + (size_t)c * D : xhi + (size_t)(c - split) * D;
+      const float4 x = *reinterpret_cast<const float4*>(src + 4 * l);
+      acc.x = fmaf(v, x.x, acc.x);
+      acc.y = fmaf(v, x.y, acc.y);
+      acc.z = fmaf(v, x.z, acc.z);
+      acc.w = fmaf(v, x.w, acc.w);
+    }
+  }
+  // combine the tasks of a split row in task order (deterministic)
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (row < 0 || run_pos != 0) return;
+  for (int t = 1; t < run_len; ++t) {
+    const float4 o = part[(g + t) * LANES + l];
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  const size_t off = (size_t)row * D + 4 * l;
+  float4 y = make_float4(P.alpha * acc.x, P.alpha * acc.y, P.alpha * acc.z, P.alpha * acc.w);
+  if (P.c1) {
+    const float4 c = *reinterpret_cast<const float4*>(P.c1 + off);
+    y.x = fmaf(P.beta, c.x, y.x); y.y = fmaf(P.beta, c.y, y.y); y.z = fmaf(P.beta, c.z, y.z); y.w = fmaf(P.beta, c.w, y.w);
+  }
+  if (P.c2) {
+    const float4 c = *reinterpret_cast<const float4*>(P.c2 + off);
+    y.x = fmaf(P.gamma, c.x, y.x); y.y = fmaf(P.gamma, c.y, y.y); y.z = fmaf(P.gamma, c.z, y.z); y.w = fmaf(P.gamma, c.w, y.w);
+  }
+  if (P.y) *reinterpret_cast<float4*>(P.y + off) = y;
+  if (P.y_pert) {
+    float4 n;
+    if (P.noise) {
+      n = *reinterpret_cast<const float4*>(P.noise + off);
+    } else {
+      const uint4 r = philox4(P.seed, P.offset + (unsigned long long)row * LANES + l, 0x5eedu);
+      n = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    }
+    float ss = n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w;
+    ss = group_sum<LANES>(ss);
+    const float sc = P.noise_degree / fmaxf(sqrtf(ss), 1e-12f);
+    float4 yp = make_float4(y.x + sgn(y.x) * (n.x * sc), y.y + sgn(y.y) * (n.y * sc), y.z + sgn(y.z) * (n.z * sc),
+                            y.w + sgn(y.w) * (n.w * sc));
+    *reinterpret_cast<float4*>(P.y_pert + off) = yp;
+    if (P.y_mean) {
+      const float4 a = *reinterpret_cast<const float4*>(P.m1 + off);
+      const float4 b = *reinterpret_cast<const float4*>(P.m2 + off);
+      const float t = 1.0f / 3.0f;
+      *reinterpret_cast<float4*>(P.y_mean + off) =
+          make_float4((yp.x + a.x + b.x) * t, (yp.y + a.y + b.y) * t, (yp.z + a.z + b.z) * t, (yp.w + a.w + b.w) * t);
+    }
+  }
+}
+
+template <int D>
+static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(spmm_kernel<D>, dim3(blocks), dim3(256), 0, s, b);
+  DMM_LAUNCH_CHECK("dmm_spmm_csr_f32");
+  return 0;
+}
+
+}  // namespace dmm
+
+extern "C" int dmm_spmm_tasks_per_block(int D) {
+  if (D != 8 && D != 16 && D != 32 && D != 64 && D != 128 && D != 256) return -1;
+  return 1024 / D;
+}
+
+extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int D, void* stream) {
+  DMM_CHECK_ARG(probs && n_probs >= 1 && n_probs <= DMM_SPMM_MAX_BATCH, "dmm_spmm_csr_f32: n_probs must be 1..%d", DMM_SPMM_MAX_BATCH);
+  const int G = dmm_spmm_tasks_per_block(D);
+  DMM_CHECK_ARG(G > 0, "dmm_spmm_csr_f32: D=%d unsupported (8,16,32,64,128,256)", D);
+  dmm::SpmmBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n_probs;
+  int blocks = 0;
+  for (int i = 0; i < n_probs; ++i) {
+    const dmm_spmm_problem& p = probs[i];
+    DMM_CHECK_ARG(p.tasks && p.col && p.val && p.x_lo, "dmm_spmm_csr_f32: problem %d has a null operand", i);
+    DMM_CHECK_ARG(p.n_tasks > 0 && p.n_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: n_tasks=%d is not a multiple of %d", i, p.n_tasks, G);
+    DMM_CHECK_ARG(p.y || p.y_pert, "dmm_spmm_csr_f32: problem %d has no output", i);
+    DMM_CHECK_ARG(!p.y_mean || (p.y_pert && p.m1 && p.m2), "dmm_spmm_csr_f32: problem %d: y_mean needs y_pert, m1, m2", i);
+    DMM_CHECK_ARG(p.x_hi || p.split >= (1 << 30), "dmm_spmm_csr_f32: problem %d: x_hi missing", i);
+    b.p[i] = p;
+    b.block_begin[i] = blocks;
+    blocks += p.n_tasks / G;
+  }
+  for (int i = n_probs; i <= DMM_SPMM_MAX_BATCH; ++i) b.block_begin[i] = blocks;
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 8: return dmm::launch<8>(b, blocks, s);
+    case 16: return dmm::launch<16>(b, blocks, s);
+    case 32: return dmm::launch<32>(b, blocks, s);
+    case 64: return dmm::launch<64>(b, blocks, s);
+    case 128: return dmm::launch<128>(b, blocks, s);
+    case 256: return dmm::launch<256>(b, blocks, s);
+  }
+  return DMM_ERR_INVALID_ARG;
+}

@@ -1,0 +1,162 @@
+"""Adjacency construction and SpMM work planning (host side, numpy).
+
+Mirrors DataHandler.normalizeAdj / DataHandler.makeTorchAdj of the reference (DataHandler.py:52-93): the
+bipartite block matrix [[0, R], [R^T, 0]], binarised, plus self loops, scaled by D^-1/2 on both sides in
+float64 and cast to fp32 once.  Instead of an uncoalesced torch COO tensor the result is CSR (int32 row
+pointers / column ids, fp32 values) plus the task list the HIP SpMM kernel consumes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def normalized_bipartite_csr(rows: np.ndarray, cols: np.ndarray, users: int, items: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(user, item) edge list -> CSR of D^-1/2 (A + I) D^-1/2 over N = users + items nodes.
+    Duplicate edges collapse (the reference binarises, DataHandler.py:83).  Columns ascend inside a row."""
+    n = users + items
+    r = np.asarray(rows, dtype=np.int64)
+    c = np.asarray(cols, dtype=np.int64)
+    if r.size and (r.min() < 0 or r.max() >= users or c.min() < 0 or c.max() >= items):
+        raise ValueError("edge list out of range")
+    # de-duplicate user->item edges once, then mirror
+    e = np.unique(r * items + c)
+    eu, ei = e // items, e % items + users
+    diag = np.arange(n, dtype=np.int64)
+    src = np.concatenate([eu, ei, diag])
+    dst = np.concatenate([ei, eu, diag])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    counts = np.bincount(src, minlength=n)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    scale = np.zeros(n, dtype=np.float64)
+    nz = counts > 0
+    scale[nz] = counts[nz].astype(np.float64) ** -0.5
+    val = ((scale[src] * 1.0) * scale[dst]).astype(np.float32)
+    if rowptr[-1] >= 2 ** 31:
+        raise ValueError("more than 2^31 non-zeros: shard the graph")
+    return rowptr.astype(np.int32), dst.astype(np.int32), val
+
+
+def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32) -> np.ndarray:
+    """Work list for dmm_spmm_csr_f32: int32 [T, 4] rows of (row, nz_begin, nz_end, run_pos << 16 | run_len).
+
+    A workgroup of the kernel holds G = 1024 / D task groups.  Rows with at most `task_len` non-zeros are one
+    task.  Longer rows are cut into k <= G tasks that sit in consecutive groups of ONE workgroup (they are
+    combined through LDS in task order): k is rounded up to a power of two and runs are placed largest first,
+    so every run is aligned to its own size and never straddles a workgroup.  Padding tasks have row = -1.
+    """
+    G = 1024 // D
+    if G * D != 1024 or D % 4:
+        raise ValueError(f"D={D} unsupported")
+    rp = np.asarray(rowptr, dtype=np.int64)
+    n = rp.shape[0] - 1
+    length = rp[1:] - rp[:-1]
+    k = np.maximum(1, -(-length // task_len))
+    k = np.minimum(k, G)
+    multi = np.flatnonzero(k > 1)
+    single = np.flatnonzero(k == 1)
+    parts = []
+    if multi.size:
+        kp = 1 << np.ceil(np.log2(k[multi])).astype(np.int64)  # slots reserved per run (power of two <= G)
+        order = np.argsort(-kp, kind="stable")
+        multi, kp = multi[order], kp[order]
+        km = np.minimum(kp, G)
+        start = np.concatenate([[0], np.cumsum(km)[:-1]])
+        total = int(km.sum())
+        t = np.full((total, 4), -1, dtype=np.int64)
+        t[:, 1:] = 0
+        # expand: task j of run i covers [beg + j*chunk, min(beg + (j+1)*chunk, end))
+        run_of = np.repeat(np.arange(multi.size), km)
+        j = np.arange(total) - np.repeat(start, km)
+        # use all reserved slots (km tasks) -> shorter tasks, still one run
+        chunk = -(-length[multi] // km)
+        beg = rp[multi][run_of] + j * chunk[run_of]
+        end = np.minimum(beg + chunk[run_of], rp[multi + 1][run_of])
+        live = beg < end
+        # number of live tasks per run (tasks are a prefix because chunks are equal)
+        nlive = np.bincount(run_of[live], minlength=multi.size)
+        t[live, 0] = multi[run_of[live]]
+        t[live, 1] = beg[live]
+        t[live, 2] = end[live]
+        t[live, 3] = (j[live] << 16) | nlive[run_of[live]]
+        t[~live, 3] = 1
+        pad = (-total) % G
+        if pad:
+            t = np.concatenate([t, np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int64), (pad, 1))])
+        parts.append(t)
+    if single.size:
+        t = np.stack([single, rp[single], rp[single + 1], np.ones_like(single)], axis=1)
+        pad = (-t.shape[0]) % G
+        if pad:
+            t = np.concatenate([t, np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int64), (pad, 1))])
+        parts.append(t)
+    if not parts:
+        return np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int32), (G, 1))
+    return np.ascontiguousarray(np.concatenate(parts).astype(np.int32))
+
+
+def check_plan(rowptr: np.ndarray, tasks: np.ndarray, D: int) -> None:
+    """Host-side validation of a task list (run before any launch: a bad plan would read out of bounds)."""
+    G = 1024 // D
+    rp = np.asarray(rowptr, dtype=np.int64)
+    n = rp.shape[0] - 1
+    t = np.asarray(tasks, dtype=np.int64)
+    assert t.ndim == 2 and t.shape[1] == 4 and t.shape[0] % G == 0 and t.shape[0] > 0, "task list shape"
+    live = t[:, 0] >= 0
+    r, b, e = t[live, 0], t[live, 1], t[live, 2]
+    assert (r < n).all() and (b >= rp[r]).all() and (e <= rp[r + 1]).all() and (b <= e).all(), "task range outside its row"
+    covered = np.zeros(n, dtype=np.int64)
+    np.add.at(covered, r, e - b)
+    assert np.array_equal(covered, rp[1:] - rp[:-1]), "tasks do not tile every row exactly"
+    pos, ln = t[:, 3] >> 16, t[:, 3] & 0xFFFF
+    slot = np.arange(t.shape[0]) % G
+    assert (ln[live] >= 1).all() and (pos[live] < ln[live]).all(), "run fields"
+    assert ((slot - pos + ln)[live] <= G).all(), "a run straddles a workgroup"
+    heads = np.flatnonzero(live & (pos == 0))
+    assert np.array_equal(np.sort(t[heads, 0]), np.arange(n)), "every row needs exactly one run head"
+    for h in heads[ln[heads] > 1][:64]:  # spot-check run contiguity
+        m = ln[h]
+        assert (t[h:h + m, 0] == t[h, 0]).all() and np.array_equal(pos[h:h + m], np.arange(m)), "run not contiguous"
+
+
+@dataclass
+class Adjacency:
+    """A normalised adjacency resident in HBM: CSR arrays + the SpMM task list for one embedding width."""
+    n: int
+    nnz: int
+    D: int
+    rowptr: torch.Tensor  # int32 [n+1]
+    col: torch.Tensor  # int32 [nnz]
+    val: torch.Tensor  # fp32 [nnz]
+    tasks: torch.Tensor  # int32 [T, 4]
+    host: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
+
+    @property
+    def n_tasks(self) -> int:
+        return int(self.tasks.shape[0])
+
+    def algorithmic_bytes(self, elem_bytes: int = 4) -> int:
+        """Compulsory HBM traffic of one SpMM: indices + values + row pointers + X + Y."""
+        return self.nnz * 8 + (self.n + 1) * 4 + 2 * self.n * self.D * elem_bytes
+
+
+def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = 32,
+                   keep_host: bool = False) -> Adjacency:
+    rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)
+    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host)
+
+
+def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, keep_host: bool = False) -> Adjacency:
+    tasks = plan_tasks(rowptr, D, task_len)
+    check_plan(rowptr, tasks, D)
+    assert col.size == 0 or (col.min() >= 0 and col.max() < rowptr.shape[0] - 1), "column id out of range"
+    dev = torch.device(device)
+    return Adjacency(n=int(rowptr.shape[0] - 1), nnz=int(col.shape[0]), D=D,
+                     rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
+                     val=torch.from_numpy(val).to(dev), tasks=torch.from_numpy(tasks).to(dev),
+                     host=(rowptr, col, val) if keep_host else None)

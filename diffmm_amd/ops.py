@@ -1,0 +1,286 @@
+"""Tensor-level wrappers over the C ABI (one Python function per exported kernel family).
+
+Every function launches asynchronously on torch's current stream and returns torch tensors that alias
+caller-visible HBM buffers.  No CPU path exists: non-CUDA tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .graph import Adjacency
+
+Tensor = torch.Tensor
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def _i32c(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous int32 tensor")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# SpMM
+# ------------------------------------------------------------------------------------------------
+class SpmmOp:
+    """One problem of a batched SpMM launch; see include/diffmm_hip.h (dmm_spmm_problem)."""
+
+    def __init__(self, adj: Adjacency, x_lo: Tensor, y: Optional[Tensor] = None, x_hi: Optional[Tensor] = None, split: Optional[int] = None,
+                 alpha: float = 1.0, c1: Optional[Tensor] = None, beta: float = 0.0, c2: Optional[Tensor] = None, gamma: float = 0.0,
+                 y_pert: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_degree: float = 0.0, seed: int = 0, offset: int = 0,
+                 y_mean: Optional[Tensor] = None, m1: Optional[Tensor] = None, m2: Optional[Tensor] = None):
+        D = adj.D
+        n = adj.n
+        if x_hi is None:
+            split = 1 << 30
+            if tuple(x_lo.shape) != (n, D):
+                raise ValueError(f"SpMM operand must be [{n}, {D}], got {tuple(x_lo.shape)}")
+        else:
+            split = x_lo.shape[0] if split is None else split
+            if x_lo.shape[0] != split or x_lo.shape[0] + x_hi.shape[0] != n or x_lo.shape[1] != D or x_hi.shape[1] != D:
+                raise ValueError("split SpMM operand: row counts must add up to the adjacency size")
+        for nm, t in (("x_lo", x_lo), ("x_hi", x_hi), ("y", y), ("c1", c1), ("c2", c2), ("y_pert", y_pert), ("noise", noise),
+                      ("y_mean", y_mean), ("m1", m1), ("m2", m2)):
+            if t is not None:
+                _f32c(t, nm)
+                if nm not in ("x_lo", "x_hi") and tuple(t.shape) != (n, D):
+                    raise ValueError(f"SpMM {nm} must be [{n}, {D}], got {tuple(t.shape)}")
+        self.keep = (adj, x_lo, x_hi, y, c1, c2, y_pert, noise, y_mean, m1, m2)
+        p = L.SpmmProblem()
+        p.tasks, p.col, p.val = L.ptr(adj.tasks), L.ptr(adj.col), L.ptr(adj.val)
+        p.x_lo, p.x_hi, p.split = L.ptr(x_lo), L.ptr(x_hi), split
+        p.y, p.c1, p.c2 = L.ptr(y), L.ptr(c1), L.ptr(c2)
+        p.alpha, p.beta, p.gamma = alpha, beta, gamma
+        p.y_pert, p.noise, p.noise_degree, p.seed, p.offset = L.ptr(y_pert), L.ptr(noise), noise_degree, seed, offset
+        p.y_mean, p.m1, p.m2 = L.ptr(y_mean), L.ptr(m1), L.ptr(m2)
+        p.n_tasks = adj.n_tasks
+        self.p, self.D = p, D
+
+
+def spmm_batched(ops: Sequence[SpmmOp]) -> None:
+    if not 1 <= len(ops) <= L.SPMM_MAX_BATCH:
+        raise ValueError("1..4 problems per launch")
+    D = ops[0].D
+    arr = (L.SpmmProblem * len(ops))(*[o.p for o in ops])
+    L.check(L.lib().dmm_spmm_csr_f32(arr, len(ops), D, L.stream()), "dmm_spmm_csr_f32")
+
+
+def spmm(adj: Adjacency, x: Tensor, **kw) -> Tensor:
+    y = torch.empty_like(x) if kw.get("y") is None and kw.get("x_hi") is None else kw.pop("y", None)
+    if y is None:
+        y = torch.empty((adj.n, adj.D), dtype=torch.float32, device=x.device)
+    kw.pop("y", None)
+    spmm_batched([SpmmOp(adj, x, y=y, **kw)])
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None,
+         act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
+         precision: int = 1, split_k: int = 1, accumulate: bool = False, M: Optional[int] = None, N: Optional[int] = None,
+         K: Optional[int] = None) -> Tensor:
+    """out[M,N] = post(act(alpha * op(A) op(B) + bias)); op(A) = A^T if trans_a (A stored [K, M]); op(B) = B^T if trans_b
+    (B stored [N, K], the nn.Linear weight layout).  A, B, out, residual may be row-strided views (last dim contiguous)."""
+    for nm, t in (("A", A), ("B", B)):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm {nm}: need a 2-D float32 tensor with unit inner stride")
+    m = (A.shape[1] if trans_a else A.shape[0]) if M is None else M
+    k = (A.shape[0] if trans_a else A.shape[1]) if K is None else K
+    n = (B.shape[0] if trans_b else B.shape[1]) if N is None else N
+    kb = B.shape[1] if trans_b else B.shape[0]
+    if K is None and kb != k:
+        raise ValueError(f"gemm: inner dimensions differ ({k} vs {kb})")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=A.device)
+        if split_k > 1:
+            out.zero_()
+    if out.dtype != torch.float32 or out.stride(1) != 1 or out.shape[0] < m or out.shape[1] < n:
+        raise ValueError("gemm out: bad shape / dtype / stride")
+    g = L.GemmArgs()
+    g.A, g.B, g.C = L.ptr(A), L.ptr(B), L.ptr(out)
+    g.sam, g.sak = (1, A.stride(0)) if trans_a else (A.stride(0), 1)
+    g.sbk, g.sbn = (1, B.stride(0)) if trans_b else (B.stride(0), 1)
+    g.ldc = out.stride(0)
+    g.bias = L.ptr(_f32c(bias, "bias")) if bias is not None else None
+    if bias is not None and bias.numel() < n:
+        raise ValueError("gemm bias too short")
+    if residual is not None:
+        if residual.dtype != torch.float32 or residual.stride(1) != 1 or residual.shape[0] < m or residual.shape[1] < n:
+            raise ValueError("gemm residual: bad shape / dtype / stride")
+        g.R, g.ldr = L.ptr(residual), residual.stride(0)
+    g.M, g.N, g.K = m, n, k
+    g.alpha, g.e1, g.e2, g.act = alpha, e1, e2, act
+    g.split_k, g.precision, g.accumulate = split_k, precision, int(accumulate)
+    L.check(L.lib().dmm_gemm(C.byref(g), L.stream()), "dmm_gemm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation / mixing
+# ------------------------------------------------------------------------------------------------
+def rownorm_fwd(x: Tensor, y: Optional[Tensor] = None, norm: Optional[Tensor] = None):
+    _f32c(x, "x")
+    y = torch.empty_like(x) if y is None else _f32c(y, "y")
+    norm = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if norm is None else norm
+    L.check(L.lib().dmm_rownorm_fwd(L.ptr(x), L.ptr(y), L.ptr(norm), x.shape[0], x.shape[1], L.stream()), "dmm_rownorm_fwd")
+    return y, norm
+
+
+def rownorm_bwd(dy: Tensor, y: Tensor, norm: Tensor, dx: Optional[Tensor] = None) -> Tensor:
+    dx = torch.empty_like(dy) if dx is None else dx
+    L.check(L.lib().dmm_rownorm_bwd(L.ptr(_f32c(dy, "dy")), L.ptr(_f32c(y, "y")), L.ptr(norm), L.ptr(_f32c(dx, "dx")), dy.shape[0], dy.shape[1],
+                                    L.stream()), "dmm_rownorm_bwd")
+    return dx
+
+
+def _ptr_array(ts: Sequence[Tensor]):
+    return (C.c_void_p * len(ts))(*[L.ptr(_f32c(t, "tensor list")) for t in ts])
+
+
+def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, mx: Optional[Tensor] = None) -> Tensor:
+    mx = torch.empty_like(bx) if mx is None else mx
+    L.check(L.lib().dmm_gcn_mix_fwd(L.ptr(_f32c(bx, "bx")), _ptr_array(z), L.ptr(w_logits), len(z), maw, L.ptr(mx), bx.numel(), L.stream()),
+            "dmm_gcn_mix_fwd")
+    return mx
+
+
+def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tensor], dbx_extra: Optional[Tensor], w_logits: Tensor, maw: float,
+                dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None):
+    n = dmx.numel()
+    dbx = torch.empty_like(dmx) if dbx is None else dbx
+    dw = torch.empty(len(z), dtype=torch.float32, device=dmx.device) if dw is None else dw
+    if partials is None:
+        partials = torch.empty(int(L.lib().dmm_gcn_mix_partials(n)), dtype=torch.float32, device=dmx.device)
+    L.check(L.lib().dmm_gcn_mix_bwd(L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
+                                    L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, L.stream()), "dmm_gcn_mix_bwd")
+    return dbx, dw
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+class Slots:
+    """(tensor, index) pairs whose gathered rows feed InfoNCE terms; `grad` receives the scatter-add backward."""
+
+    def __init__(self, entries):  # entries: list of (src, idx, grad-or-None)
+        self.entries = entries
+        self.arr = (L.GatherDesc * len(entries))()
+        for i, (src, idx, grad) in enumerate(entries):
+            _f32c(src, "slot src"); _i32c(idx, "slot idx")
+            self.arr[i].src, self.arr[i].idx, self.arr[i].grad = L.ptr(src), L.ptr(idx), L.ptr(grad)
+        self.n = len(entries)
+
+
+def make_terms(terms):  # list of (a, b, temp, weight)
+    arr = (L.InfoNCETerm * len(terms))()
+    for i, (a, b, temp, w) in enumerate(terms):
+        arr[i].a, arr[i].b, arr[i].temp, arr[i].weight = a, b, temp, w
+    return arr
+
+
+def gather_normalize(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor) -> None:
+    L.check(L.lib().dmm_gather_normalize(slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.stream()), "dmm_gather_normalize")
+
+
+def infonce_fwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, row_loss: Tensor) -> None:
+    L.check(L.lib().dmm_infonce_fwd(L.ptr(zhat), terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.stream()), "dmm_infonce_fwd")
+
+
+def infonce_bwd(zhat: Tensor, lse: Tensor, terms, n_terms: int, B: int, D: int, dzhat: Tensor) -> None:
+    L.check(L.lib().dmm_infonce_bwd(L.ptr(zhat), L.ptr(lse), terms, n_terms, B, D, L.ptr(dzhat), L.stream()), "dmm_infonce_bwd")
+
+
+def scatter_normalize_bwd(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, dzhat: Tensor) -> None:
+    L.check(L.lib().dmm_scatter_normalize_bwd(slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(dzhat), L.stream()),
+            "dmm_scatter_normalize_bwd")
+
+
+def bpr_fwd_bwd(fin: Tensor, users: Tensor, pos: Tensor, neg: Tensor, U: int, row_loss: Tensor, dfin: Optional[Tensor]) -> None:
+    B, D = users.shape[0], fin.shape[1]
+    L.check(L.lib().dmm_bpr_fwd_bwd(L.ptr(_f32c(fin, "fin")), L.ptr(_i32c(users, "users")), L.ptr(_i32c(pos, "pos")), L.ptr(_i32c(neg, "neg")),
+                                    B, D, U, L.ptr(row_loss), L.ptr(dfin), L.stream()), "dmm_bpr_fwd_bwd")
+
+
+def segment_sum(x: Tensor, n_seg: int, seg_len: int, scale: float, out: Tensor) -> None:
+    L.check(L.lib().dmm_segment_sum(L.ptr(x), n_seg, seg_len, scale, L.ptr(out), L.stream()), "dmm_segment_sum")
+
+
+def sumsq(x: Tensor, scale: float, out: Tensor, scratch: Optional[Tensor] = None) -> None:
+    n = x.numel()
+    if scratch is None:
+        scratch = torch.empty(int(L.lib().dmm_sumsq_scratch(n)), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dmm_sumsq(L.ptr(x), n, scale, L.ptr(scratch), L.ptr(out), L.stream()), "dmm_sumsq")
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, extra: Sequence[Tensor] = (), extra_n: Sequence[int] = (),
+              l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    n = p.numel()
+    if not (g.numel() == n and m.numel() == n and v.numel() == n):
+        raise ValueError("adam: size mismatch")
+    ex = (C.c_void_p * max(1, len(extra)))(*[L.ptr(t) for t in extra]) if extra else (C.c_void_p * 1)()
+    en = (C.c_int64 * max(1, len(extra)))(*extra_n) if extra else (C.c_int64 * 1)()
+    L.check(L.lib().dmm_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream()),
+            "dmm_adam_step")
+
+
+# ------------------------------------------------------------------------------------------------
+# diffusion path
+# ------------------------------------------------------------------------------------------------
+def qsample_temb(x0: Optional[Tensor], noise: Optional[Tensor], t: Tensor, sqrt_ac: Optional[Tensor], sqrt_1mac: Optional[Tensor],
+                 w_emb: Tensor, b_emb: Tensor, xcat: Tensor, I: int, draw_noise: bool = False, seed: int = 0, offset: int = 0,
+                 eps_out: Optional[Tensor] = None) -> None:
+    B, te = t.shape[0], w_emb.shape[0]
+    L.check(L.lib().dmm_qsample_temb(L.ptr(x0), x0.stride(0) if x0 is not None else 0, L.ptr(noise), L.ptr(_i32c(t, "t")), L.ptr(sqrt_ac),
+                                     L.ptr(sqrt_1mac), L.ptr(w_emb), L.ptr(b_emb), te, L.ptr(xcat), xcat.stride(0), B, I, int(draw_noise), seed,
+                                     offset, L.ptr(eps_out), L.stream()), "dmm_qsample_temb")
+
+
+def temb_bwd(t: Tensor, dxcat: Tensor, I: int, te: int, dw: Tensor, db: Tensor) -> None:
+    L.check(L.lib().dmm_temb_bwd(L.ptr(t), L.ptr(dxcat), dxcat.stride(0), I, te, t.shape[0], L.ptr(dw), L.ptr(db), L.stream()), "dmm_temb_bwd")
+
+
+def mul(a: Tensor, b: Tensor, out: Tensor) -> None:
+    L.check(L.lib().dmm_mul_sigmoid_fwd(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream()), "dmm_mul_sigmoid_fwd")
+
+
+def gate_bwd(dout: Tensor, proj: Tensor, gate: Tensor, dproj: Tensor, dpre: Tensor) -> None:
+    L.check(L.lib().dmm_gate_bwd(L.ptr(dout), L.ptr(proj), L.ptr(gate), L.ptr(dproj), L.ptr(dpre), dout.numel(), L.stream()), "dmm_gate_bwd")
+
+
+def tanh_bwd(dh: Tensor, h: Tensor, dpre: Tensor) -> None:
+    L.check(L.lib().dmm_tanh_bwd(L.ptr(dh), L.ptr(h), L.ptr(dpre), dh.numel(), L.stream()), "dmm_tanh_bwd")
+
+
+def add_inplace(y: Tensor, x: Tensor, alpha: float = 1.0) -> None:
+    L.check(L.lib().dmm_add_inplace(L.ptr(y), L.ptr(x), alpha, y.numel(), L.stream()), "dmm_add_inplace")
+
+
+def colsum(x: Tensor, rows: int, cols: int, out: Tensor) -> None:
+    L.check(L.lib().dmm_colsum(L.ptr(x), x.stride(0), rows, cols, L.ptr(out), L.stream()), "dmm_colsum")
+
+
+def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, gscale: float,
+              loss: Tensor, dout: Optional[Tensor], dum: Optional[Tensor]) -> None:
+    B, d = um.shape
+    if out.stride(0) != x0.stride(0) or (dout is not None and dout.stride(0) != out.stride(0)):
+        raise ValueError("diff_loss: out, x0 and dout must share one leading dimension")
+    if w.dtype != torch.float64 or loss.dtype != torch.float64:
+        raise ValueError("diff_loss: w and loss are float64")
+    L.check(L.lib().dmm_diff_loss(L.ptr(out), L.ptr(x0), out.stride(0), L.ptr(w), L.ptr(um), L.ptr(ui), B, I, d, sim_weight, reg_term, gscale,
+                                  L.ptr(loss), L.ptr(dout), L.ptr(dum), L.stream()), "dmm_diff_loss")
+
+
+def topk_rows(x: Tensor, row_ids: Tensor, out_ptr: Tensor, out_idx: Tensor, cols: int) -> None:
+    L.check(L.lib().dmm_topk_rows(L.ptr(x), x.stride(0), L.ptr(_i32c(row_ids, "row_ids")), L.ptr(_i32c(out_ptr, "out_ptr")), L.ptr(out_idx),
+                                  row_ids.shape[0], cols, L.stream()), "dmm_topk_rows")

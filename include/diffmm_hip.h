@@ -1,0 +1,192 @@
+/* libdiffmm_hip -- C ABI of the MI355X (gfx950) kernels behind the DiffMM training hot path.
+ *
+ * The reference (sun2ot/DiffMM) has no native layer: its hot path is a sequence of PyTorch op call sites.
+ * Each entry point below replaces the call sites it cites (file:line in /root/reference); the Python
+ * surface in diffmm_amd/ (Model, Denoise, GaussianDiffusion, InfoNCE, bpr_loss, Coach ...) binds them
+ * through ctypes -- see INTEGRATION.md for the stubs a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator) unless marked "host";
+ *   - every launch is asynchronous on the given hipStream_t (passed as void*); no hidden allocation,
+ *     no hidden synchronisation, no global mutable state besides the last-error string;
+ *   - return value 0 = ok; >0 = hipError_t of a failed launch; <0 = DMM_ERR_*; text via
+ *     dmm_last_error_string();
+ *   - matrices are row-major fp32 unless stated; indices are int32.
+ */
+#ifndef DIFFMM_HIP_H
+#define DIFFMM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMM_VERSION 100
+#define DMM_ERR_INVALID_ARG (-1)
+#define DMM_ERR_UNSUPPORTED (-2)
+#define DMM_SPMM_MAX_BATCH 4
+
+int dmm_version(void);
+const char* dmm_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CSR SpMM with fused epilogues.  Replaces torch.sparse.mm(adj, X) and its backward (A symmetric):
+ * Model.py:90,93,105,111,114,123,130 and Main.py:319; the epilogues absorb Model.py:116-131 (scale /
+ * residual adds), Main.py:320-321 (sign-aligned noise) and Main.py:325 (mean over the 3 CL layers).
+ *   y      = alpha * (A X)[row] + beta * c1[row] + gamma * c2[row]
+ *   y_pert = y + sign(y) * noise[row] / max(||noise[row]||, 1e-12) * noise_degree
+ *   y_mean = (y_pert + m1[row] + m2[row]) / 3
+ * X row r is read from x_lo[r] when r < split, else x_hi[r - split] (lets [u_embs ; feats] stay two tensors).
+ * `tasks` is the int4 work list {row, nz_begin, nz_end, run_pos<<16 | run_len} produced by the planner
+ * (diffmm_amd/graph.py: plan_tasks); n_tasks must be a multiple of dmm_spmm_tasks_per_block(D).
+ * noise == NULL with y_pert != NULL draws uniform noise in-kernel: Philox4x32-10(seed, offset + row*D/4 + lane). */
+typedef struct dmm_spmm_problem {
+  const void* tasks;
+  const int32_t* col;
+  const float* val;
+  const float* x_lo;
+  const float* x_hi;
+  float* y;
+  const float* c1;
+  const float* c2;
+  float* y_pert;
+  const float* noise;
+  float* y_mean;
+  const float* m1;
+  const float* m2;
+  uint64_t seed;
+  uint64_t offset;
+  int32_t n_tasks;
+  int32_t split;
+  float alpha, beta, gamma;
+  float noise_degree;
+} dmm_spmm_problem;
+
+int dmm_spmm_tasks_per_block(int D);
+int dmm_spmm_csr_f32(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense GEMM on the matrix cores (bf16 MFMA 32x32x16, fp32 accumulate; operands stay fp32 in HBM and are
+ * rounded while staged into LDS).  precision = 1: one bf16 product; precision = 3: hi/lo split, three
+ * products (~fp32 accuracy) -- the mode the parity tests use.
+ *   C[m,n] = post( act( alpha * sum_k A(m,k) B(k,n) + bias[n] ) )     post(v) = e1 * v + e2 * R[m,n]
+ * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]  (any of NN / NT / TN by strides).
+ * split_k > 1: K is cut in split_k slices added into C with fp32 atomics (C must be pre-zeroed or hold the
+ * value to accumulate into; only act = NONE, R = NULL; the bias is added by slice 0).
+ * Replaces nn.Linear / torch.mm call sites: Model.py:48,51,57,84-85,103 (modality projection), :205-208
+ * (gate), :211-215 (Denoise MLP), :375 (posterior mean as epilogue), :416-417 and their backward. */
+enum { DMM_ACT_NONE = 0, DMM_ACT_TANH = 1, DMM_ACT_SIGMOID = 2 };
+typedef struct dmm_gemm_args {
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbk, sbn;
+  float* C; int64_t ldc;
+  const float* bias;  /* [N] or NULL */
+  const float* R; int64_t ldr; /* residual or NULL */
+  int32_t M, N, K;
+  float alpha, e1, e2;
+  int32_t act;
+  int32_t split_k;
+  int32_t precision; /* 1 or 3 */
+  int32_t accumulate; /* 1: C += result (plain read-modify-write, split_k == 1) */
+} dmm_gemm_args;
+int dmm_gemm(const dmm_gemm_args* a /*host*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Row L2 normalisation, F.normalize(x, p=2, dim=1, eps=1e-12): Model.py:89,92,104; Utils.py:72.
+ * fwd writes y = x / max(||x||, eps) and norm = ||x||.  bwd: dx = (dy - y (y.dy)) / ||x||  (dy / eps below eps). */
+int dmm_rownorm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream);
+int dmm_rownorm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Modal mixing of gcn_MM, Model.py:87,116-127:  mx = sum_m softmax(w)_m * (bx + maw * z_m).
+ * bwd: dbx = (sum_m w_m) dmx + dbx_extra;  dz_m += maw * w_m * dmx;  dlogits = softmax-bwd(<dmx, bx + maw z_m>).
+ * `partials` is scratch of dmm_gcn_mix_partials(n) floats. */
+int dmm_gcn_mix_fwd(const float* bx, const float* const* z /*host array of M device ptrs*/, const float* w_logits, int M,
+                    float maw, float* mx, int64_t n, void* stream);
+int64_t dmm_gcn_mix_partials(int64_t n);
+int dmm_gcn_mix_bwd(const float* dmx, const float* bx, const float* const* z /*host*/, float* const* dz /*host, in/out*/,
+                    const float* dbx_extra, float* dbx, const float* w_logits, float* dw_logits, int M, float maw,
+                    float* partials, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Contrastive + ranking losses.  Utils/Utils.py:57-75 (InfoNCE), :78-98 (bpr_loss), :45-54 (l2_reg_loss).
+ * Views are gathered and row-normalised once per (tensor, index) pair ("slot"); a term is a pair of slots.
+ *   loss_t = weight_t * mean_i( lse_i - s_ii ),  s = zhat_a zhat_b^T / temp
+ * dmm_infonce_bwd accumulates d(zhat) for every slot (dzhat must be zeroed by the caller);
+ * dmm_scatter_normalize_bwd pushes it through the normalisation and adds it to grad[idx[b]] (fp32 atomics,
+ * duplicate indices allowed -- the backward of view[idx]). */
+typedef struct dmm_gather_desc {
+  const float* src;   /* [rows, D] */
+  const int32_t* idx; /* [B] */
+  float* grad;        /* [rows, D] gradient buffer of src (used by dmm_scatter_normalize_bwd) or NULL */
+} dmm_gather_desc;
+typedef struct dmm_infonce_term {
+  int32_t a, b; /* slot ids */
+  float temp, weight;
+} dmm_infonce_term;
+int dmm_gather_normalize(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, float* zhat /*[n_slots,B,D]*/,
+                         float* norm /*[n_slots,B]*/, void* stream);
+int dmm_infonce_fwd(const float* zhat, const dmm_infonce_term* terms /*host*/, int n_terms, int B, int D,
+                    float* lse /*[n_terms,B]*/, float* row_loss /*[n_terms,B], weight/B folded in*/, void* stream);
+int dmm_infonce_bwd(const float* zhat, const float* lse, const dmm_infonce_term* terms /*host*/, int n_terms, int B, int D,
+                    float* dzhat /*[n_slots,B,D], accumulated*/, void* stream);
+int dmm_scatter_normalize_bwd(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const float* zhat,
+                              const float* norm, const float* dzhat, void* stream);
+/* BPR forward + backward in one pass: row_loss[b] = -log(1e-5 + sigmoid(u.p - u.n)) / B and, when dfin != NULL,
+ * dfin[user/pos/neg rows] += d(row_loss) (atomics).  `fin` is [U + I, D]; item i lives at row U + i. */
+int dmm_bpr_fwd_bwd(const float* fin, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D, int U,
+                    float* row_loss, float* dfin, void* stream);
+/* out[s] = scale * sum(in[s*len .. (s+1)*len)) in a fixed order (deterministic loss reduction). */
+int dmm_segment_sum(const float* in, int n_seg, int64_t len, float scale, float* out, void* stream);
+/* out[0] = scale * sum(x^2) (l2_reg_loss, Utils.py:45-54); scratch: dmm_sumsq_scratch(n) floats. */
+int64_t dmm_sumsq_scratch(int64_t n);
+int dmm_sumsq(const float* x, int64_t n, float scale, float* scratch, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam defaults: betas 0.9/0.999, eps 1e-8, weight_decay 0; Main.py:92-110,189-192,377).
+ * g_total = g + sum_k extra_k (first extra_n[k] elements only) + l2_coef * p -- lets the embedding update absorb
+ * the user-row parts of the modal SpMM backward and the 2*reg*p term of l2_reg_loss without extra passes.
+ * bias corrections use `step` (1-based). */
+int dmm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/,
+                  const int64_t* extra_n /*host*/, int n_extra, float l2_coef, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Diffusion path.
+ * dmm_qsample: x_t = a[t_b] x0 + b[t_b] eps  (GaussianDiffusion.forward_cal_xt, Model.py:324-341) written into the
+ * first I columns of xcat [B, ldx]; columns I..I+te get the time embedding emb_layer(cat[cos, sin](t f_k))
+ * (Denoise.forward, Model.py:196-202), the rest of the row up to ldx is zeroed.  eps read from `noise` [B, I]
+ * or drawn in-kernel (Philox + Box-Muller) when noise == NULL and draw_noise != 0; with both off, eps = 0 and
+ * a = 1 (the reverse chain's x_t passes through).  `eps_out` (optional) receives the noise used. */
+int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const int32_t* t, const float* sqrt_ac,
+                     const float* sqrt_1mac, const float* w_emb /*[te,te]*/, const float* b_emb /*[te]*/, int te,
+                     float* xcat, int64_t ldx, int B, int I, int draw_noise, uint64_t seed, uint64_t offset,
+                     float* eps_out, void* stream);
+/* Backward of the time-embedding linear layer: d w_emb += temb_in^T d(temb), d b_emb += colsum (one block). */
+int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, int I, int te, int B, float* dw_emb, float* db_emb,
+                 void* stream);
+/* Elementwise pieces of Denoise / training_losses (Model.py:204-218, 407-425). */
+int dmm_mul_sigmoid_fwd(const float* proj, const float* gate_pre_sig /*sigmoid already applied*/, float* out, int64_t n,
+                        void* stream); /* out = proj * gate */
+int dmm_gate_bwd(const float* dout, const float* proj, const float* gate, float* dproj /*out: dout*gate*/,
+                 float* dgate_pre /*out: dout*proj*gate*(1-gate)*/, int64_t n, void* stream);
+int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* stream); /* dpre = dh * (1 - h^2) */
+int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n, void* stream);   /* y += alpha * x */
+int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out /*[cols], overwritten*/, void* stream);
+/* Diffusion loss, Model.py:407-425.  per row b: mse_b = mean_j (out - x0)^2; cos_b = cosine(um_b, ui_b);
+ * loss_b = w_b * mse_b + sim_weight * (1 - cos_b) + reg_term  (float64 out, like the reference).
+ * Also emits d loss / d out (the direct MSE part) and d loss / d um scaled by gscale (= 1 / (B * total)). */
+int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w /*[B]*/, const float* um,
+                  const float* ui, int B, int I, int d, float sim_weight, double reg_term, double gscale,
+                  double* loss /*[B]*/, float* dout /*[B,ld] or NULL*/, float* dum /*[B,d] or NULL*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Rebuild: per-row top-k with k = the user's degree (Main.py:224-230).  One workgroup per row; writes the k
+ * selected column ids of row r to out_idx[out_ptr[r] .. out_ptr[r] + k) (ascending column order; ties at the
+ * threshold resolved towards the smaller column id). */
+int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids /*[rows] global user ids*/, const int32_t* out_ptr
+                  /*[U+1] indexed by user id*/, int32_t* out_idx, int rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

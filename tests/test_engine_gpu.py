@@ -1,0 +1,83 @@
+"""Step-level parity of the HIP engines against the reference's golden vectors and the CPU oracle (pytest -m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+from test_kernels_gpu import T, close, load, need_gpu  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    need_gpu()
+    return torch.device("cuda:0")
+
+
+HP = dict(modal_adj_weight=0.2, residual_weight=0.5, noise_degree=1.5, cross_cl_temp=0.2, cross_cl_rate=0.5, modal_cl_temp=0.5,
+          modal_cl_rate=0.01, reg=1e-4, lr=1e-3, cl_method=0)
+
+
+def _engine_from_gcn_fixture(z, dev, B_max=256, **over):
+    from diffmm_amd import graph
+    from diffmm_amd.engine import JointEngine
+    U, I, M, D = int(z["users"]), int(z["items"]), int(z["M"]), int(z["d"])
+    hp = dict(HP); hp.update(over)
+    E = JointEngine(U, I, D, [T(z[f"feat{m}"]) for m in range(M)], hp, dev, B_max)
+    E.load_reference_state({k[2:]: z[k] for k in z.files if k.startswith("p/")})
+    adj = graph.make_adjacency(z["trn_rows"], z["trn_cols"], U, I, D, dev)
+    madj = [graph.make_adjacency(z[f"m{m}_rows"], z[f"m{m}_cols"], U, I, D, dev) for m in range(M)]
+    E.set_adjacency(adj, madj)
+    return E
+
+
+@pytest.mark.parametrize("fx", ["gcn_toy_M3", "gcn_mid_M3", "gcn_mid_M2"])
+def test_gcn_mm_forward_vs_reference(dev, fx):
+    z = load(fx + ".npz")
+    E = _engine_from_gcn_fixture(z, dev)
+    E.forward(with_cl=False, precision=3)
+    out = E.gcn_output()
+    for k in [f[4:] for f in z.files if f.startswith("out/")]:
+        close(out[k], z[f"out/{k}"], rtol=1e-4, atol=1e-5, what=k)
+
+
+@pytest.mark.parametrize("fx,cl_method", [("gcn_mid_M3", 0), ("gcn_mid_M3", 1), ("gcn_mid_M2", 0), ("gcn_mid_M2", 1), ("gcn_toy_M3", 0)])
+def test_joint_step_loss_grads_and_update_vs_oracle(dev, fx, cl_method):
+    """One full joint step: losses, the gradient of every parameter (vs autograd on the oracle) and the Adam update."""
+    from oracle import diffmm_oracle as O
+    z = load(fx + ".npz")
+    U, I, M, D = int(z["users"]), int(z["items"]), int(z["M"]), int(z["d"])
+    E = _engine_from_gcn_fixture(z, dev, cl_method=cl_method)
+    rng = np.random.default_rng(7)
+    B = 6 if U < 50 else 200
+    e = rng.integers(0, len(z["trn_rows"]), size=B)
+    users, pos = z["trn_rows"][e].astype(np.int32), z["trn_cols"][e].astype(np.int32)
+    neg = rng.integers(0, I, size=B).astype(np.int32)
+    noise = [T(rng.random((U + I, D)).astype(np.float32)) for _ in range(3)]
+    # oracle
+    P = {k[2:]: T(z[k]).clone().requires_grad_() for k in z.files if k.startswith("p/")}
+    adj = O.csr_to_torch(*O.build_adj_csr(z["trn_rows"], z["trn_cols"], U, I))
+    madj = [O.csr_to_torch(*O.build_adj_csr(z[f"m{m}_rows"], z[f"m{m}_cols"], U, I)) for m in range(M)]
+    hp = dict(HP); hp["cl_method"] = cl_method
+    loss, parts = O.joint_loss(P, [T(z[f"feat{m}"]) for m in range(M)], adj, madj, T(users.astype(np.int64)), T(pos.astype(np.int64)),
+                               T(neg.astype(np.int64)), noise, hp)
+    loss.backward()
+    # HIP
+    E.step(T(users).to(dev), T(pos).to(dev), T(neg).to(dev), noise=[n.to(dev) for n in noise], precision=3, update=False)
+    got = E.losses()
+    close(got["bpr"], float(parts["bpr"]), rtol=2e-5, what="bpr"); close(got["reg"], float(parts["reg"]), rtol=2e-5, what="reg")
+    close(got["cl"], float(parts["cl"]), rtol=5e-5, what="cl"); close(got["loss"], float(loss), rtol=5e-5, what="loss")
+    g = E.full_grads()
+    for k in P:
+        ref = P[k].grad
+        close(g[k], ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max()) + 1e-9, what="grad " + k)
+    # Adam update
+    opt = O.Adam({k: v for k, v in P.items()}, 1e-3)
+    opt.step({k: v.grad for k, v in P.items()})
+    E.apply_adam()
+    sd = E.state_dict()
+    for k in P:
+        close(sd[k], P[k].detach(), rtol=1e-4, atol=2e-5, what="after Adam " + k)  # lr = 1e-3 bounds any sign flip of a ~0 gradient
