@@ -1,0 +1,232 @@
+"""Data side of the reference's surface (DataHandler.py:10-228), re-designed for HBM residency.
+
+Same names and call order as the reference -- DataHandler(config).LoadData(), .trainData/.trainLoader/.testData/
+.testLoader/.diffusionData/.diffusionLoader/.torchBiAdj/.image_feats ..., static normalizeAdj / makeTorchAdj,
+getUserDegrees(), TrainData.negSampling() -- but:
+  * interactions come from a pickle-free bundle (`Datasets/<name>/<name>.npz` with trn_rows, trn_cols, tst_rows,
+    tst_cols, feat0..featM-1) or, when none is present, from the synthetic generator of the named shape
+    (diffmm_amd/synth.py).  The reference's pickles are never read (they cannot be loaded safely);
+  * makeTorchAdj returns a CSR `Adjacency` with its SpMM task list instead of an uncoalesced torch COO tensor;
+  * the loaders hand out int32 index tensors that already live on the device; negative sampling is vectorised
+    (the reference's python rejection loop, DataHandler.py:159-169, is O(E) interpreter steps);
+  * DiffusionData materialises only the requested user rows (the reference keeps a dense U x I matrix in HBM,
+    DataHandler.py:128 -- impossible at the 10M x 1M configuration).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import graph, synth
+from .Conf import Config
+
+
+class BatchLoader:
+    """Minimal stand-in for torch DataLoader(shuffle=..., num_workers=0): index batches drawn on the device."""
+
+    def __init__(self, dataset, batch_size: int, shuffle: bool, device):
+        self.dataset, self.batch_size, self.shuffle, self.device = dataset, batch_size, shuffle, device
+        self.fixed_perm: Optional[torch.Tensor] = None  # tests pin the order through this
+
+    def __len__(self) -> int:
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator:
+        n = len(self.dataset)
+        if self.fixed_perm is not None:
+            perm = self.fixed_perm.to(self.device)
+        elif self.shuffle:
+            perm = torch.randperm(n, device=self.device)
+        else:
+            perm = torch.arange(n, device=self.device)
+        for s in range(0, n, self.batch_size):
+            yield self.dataset.batch(perm[s:s + self.batch_size])
+
+
+class TrainData:
+    """(user, positive item, sampled negative item) triples -- one per train interaction."""
+
+    def __init__(self, rows: np.ndarray, cols: np.ndarray, config: Config, device="cpu"):
+        self.config, self.device = config, torch.device(device)
+        self.rows, self.cols = np.asarray(rows, dtype=np.int32), np.asarray(cols, dtype=np.int32)
+        self.negs = np.zeros(len(self.rows), dtype=np.int32)
+        items = int(config.data.item_num)
+        self._keys = torch.from_numpy(np.sort(self.rows.astype(np.int64) * items + self.cols)).to(self.device)
+        self._rows_d = torch.from_numpy(self.rows).to(self.device)
+        self._cols_d = torch.from_numpy(self.cols).to(self.device)
+        self._negs_d = torch.zeros(len(self.rows), dtype=torch.int32, device=self.device)
+        order = np.argsort(self.rows, kind="stable")
+        ptr = np.searchsorted(self.rows[order], np.arange(int(config.data.user_num) + 1))
+        self.user_pos_items: List[np.ndarray] = [self.cols[order[ptr[u]:ptr[u + 1]]] for u in range(int(config.data.user_num))]
+
+    def negSampling(self) -> None:
+        """One uniform negative per interaction, re-drawn while (user, item) is a train interaction."""
+        items = int(self.config.data.item_num)
+        n = len(self.rows)
+        rows64 = self._rows_d.long()
+        neg = torch.randint(0, items, (n,), device=self.device)
+        bad = torch.arange(n, device=self.device)
+        while bad.numel():
+            key = rows64[bad] * items + neg[bad]
+            pos = torch.searchsorted(self._keys, key).clamp_(max=self._keys.numel() - 1)
+            bad = bad[self._keys[pos] == key]
+            if bad.numel():
+                neg[bad] = torch.randint(0, items, (int(bad.numel()),), device=self.device)
+        self._negs_d = neg.to(torch.int32)
+        self.negs = self._negs_d.cpu().numpy()
+
+    def set_negs(self, negs: np.ndarray) -> None:
+        self.negs = np.asarray(negs, dtype=np.int32)
+        self._negs_d = torch.from_numpy(self.negs).to(self.device)
+
+    def __len__(self) -> int:
+        return len(self.rows)
+
+    def __getitem__(self, idx):
+        return self.rows[idx], self.cols[idx], self.negs[idx]
+
+    def batch(self, idx: torch.Tensor):
+        return self._rows_d[idx].contiguous(), self._cols_d[idx].contiguous(), self._negs_d[idx].contiguous()
+
+
+class TestData:
+    def __init__(self, tst_rows: np.ndarray, tst_cols: np.ndarray, trn_rows: np.ndarray, trn_cols: np.ndarray, users: int, items: int,
+                 device="cpu"):
+        self.device = torch.device(device)
+        self.users, self.items = users, items
+        order = np.argsort(tst_rows, kind="stable")
+        r, c = np.asarray(tst_rows)[order], np.asarray(tst_cols)[order]
+        self.test_users = np.unique(r)
+        ptr = np.searchsorted(r, np.arange(users + 1))
+        self.test_user_its: List[Optional[list]] = [list(c[ptr[u]:ptr[u + 1]]) if ptr[u + 1] > ptr[u] else None for u in range(users)]
+        # train interactions as CSR over users, for the score mask
+        o2 = np.argsort(trn_rows, kind="stable")
+        self._trn_ptr = torch.from_numpy(np.searchsorted(np.asarray(trn_rows)[o2], np.arange(users + 1)).astype(np.int64)).to(self.device)
+        self._trn_col = torch.from_numpy(np.asarray(trn_cols)[o2].astype(np.int64)).to(self.device)
+        self._users_d = torch.from_numpy(self.test_users.astype(np.int64)).to(self.device)
+
+    def __len__(self) -> int:
+        return len(self.test_users)
+
+    def batch(self, idx: torch.Tensor):
+        usr = self._users_d[idx]
+        return usr, dense_rows(self._trn_ptr, self._trn_col, usr, self.items)
+
+    def __getitem__(self, idx):
+        u = int(self.test_users[idx])
+        mask = np.zeros(self.items, dtype=np.float32)
+        mask[self._trn_col[self._trn_ptr[u]:self._trn_ptr[u + 1]].cpu().numpy()] = 1.0
+        return u, mask
+
+
+def dense_rows(ptr: torch.Tensor, col: torch.Tensor, users: torch.Tensor, items: int, ld: Optional[int] = None) -> torch.Tensor:
+    """0/1 rows of the interaction matrix for the given users, built on the device from its CSR."""
+    users = users.long()
+    start, cnt = ptr[users], ptr[users + 1] - ptr[users]
+    total = int(cnt.sum())
+    out = torch.zeros((users.shape[0], ld or items), dtype=torch.float32, device=ptr.device)
+    if total:
+        b = torch.repeat_interleave(torch.arange(users.shape[0], device=ptr.device), cnt, output_size=total)
+        first = torch.cumsum(cnt, 0) - cnt
+        pos = torch.arange(total, device=ptr.device) - first[b] + start[b]
+        out[b, col[pos]] = 1.0
+    return out
+
+
+class DiffusionData:
+    """User rows of the train interaction matrix (what the Denoise MLP sees)."""
+
+    def __init__(self, trn_rows: np.ndarray, trn_cols: np.ndarray, users: int, items: int, device="cpu"):
+        self.device = torch.device(device)
+        self.users, self.items = users, items
+        o = np.argsort(trn_rows, kind="stable")
+        self.ptr = torch.from_numpy(np.searchsorted(np.asarray(trn_rows)[o], np.arange(users + 1)).astype(np.int64)).to(self.device)
+        self.col = torch.from_numpy(np.asarray(trn_cols)[o].astype(np.int64)).to(self.device)
+        self.deg_ptr32 = self.ptr.to(torch.int32)
+
+    def __len__(self) -> int:
+        return self.users
+
+    def rows(self, idx: torch.Tensor) -> torch.Tensor:
+        return dense_rows(self.ptr, self.col, idx, self.items)
+
+    def batch(self, idx: torch.Tensor):
+        return self.rows(idx), idx
+
+    def __getitem__(self, index):
+        i = torch.as_tensor([index], device=self.device)
+        return self.rows(i)[0], index
+
+
+class DataHandler:
+    def __init__(self, config: Config):
+        self.config = config
+        self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
+        self.predir = f"./Datasets/{config.data.name}/"
+        self.bundle = os.path.join(self.predir, f"{config.data.name}.npz")
+
+    # -- reference statics ---------------------------------------------------------------------------
+    @staticmethod
+    def normalizeAdj(mat):
+        """D^-1/2 A D^-1/2 of a scipy sparse matrix (DataHandler.py:52-66), host side, for API compatibility."""
+        import scipy.sparse as sp
+        csr = mat.tocsr()
+        deg = np.asarray(csr.sum(axis=1)).reshape(-1)
+        dinv = np.zeros_like(deg, dtype=np.float64)
+        dinv[deg > 0] = deg[deg > 0] ** -0.5
+        d = sp.diags(dinv)
+        return (d @ csr @ d).tocoo()
+
+    @staticmethod
+    def makeTorchAdj(mat, rows: int, cols: int, device, latdim: int = 64) -> graph.Adjacency:
+        """(user x item) scipy matrix (or (row, col) arrays) -> normalised bipartite adjacency in HBM (DataHandler.py:68-93)."""
+        if isinstance(mat, tuple):
+            r, c = mat
+        else:
+            m = mat.tocoo()
+            keep = m.data != 0
+            r, c = m.row[keep], m.col[keep]
+        return graph.make_adjacency(r, c, rows, cols, latdim, device)
+
+    # -- loading ---------------------------------------------------------------------------------------
+    def _read(self) -> synth.SynthGraph:
+        if os.path.exists(self.bundle):
+            z = np.load(self.bundle, allow_pickle=False)
+            feats = [z[k].astype(np.float32) for k in sorted(f for f in z.files if f.startswith("feat"))]
+            return synth.SynthGraph(int(z["users"]), int(z["items"]), z["trn_rows"], z["trn_cols"], z["tst_rows"], z["tst_cols"], feats)
+        if self.config.data.name in synth.SHAPES:
+            return synth.named(self.config.data.name, seed=int(self.config.base.seed))
+        raise ValueError(f"Unknown dataset: {self.config.data.name} (no {self.bundle} and no synthetic shape of that name)")
+
+    def LoadData(self, graph_data: Optional[synth.SynthGraph] = None) -> None:
+        import scipy.sparse as sp
+        g = graph_data if graph_data is not None else self._read()
+        cfg, dev = self.config, self.device
+        U, I = g.users, g.items
+        cfg.data.user_num, cfg.data.item_num = U, I
+        self.graph = g
+        self.trainMat = sp.coo_matrix((np.ones(g.nnz, np.float32), (g.trn_rows, g.trn_cols)), shape=(U, I))
+        self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev)
+        self.trainData = TrainData(g.trn_rows, g.trn_cols, cfg, dev)
+        self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev)
+        self.testData = TestData(g.tst_rows, g.tst_cols, g.trn_rows, g.trn_cols, U, I, dev)
+        self.testLoader = BatchLoader(self.testData, int(cfg.train.test_batch), False, dev)
+        f = [torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dev) for x in g.feats]
+        self.image_feats, cfg.data.image_feat_dim = f[0], int(f[0].shape[1])
+        self.text_feats, cfg.data.text_feat_dim = f[1], int(f[1].shape[1])
+        if len(f) > 2:
+            self.audio_feats, cfg.data.audio_feat_dim = f[2], int(f[2].shape[1])
+        self.diffusionData = DiffusionData(g.trn_rows, g.trn_cols, U, I, dev)
+        self.diffusionLoader = BatchLoader(self.diffusionData, int(cfg.train.batch), True, dev)
+        self.user_pos_items = self.trainData.user_pos_items
+
+    def getUserDegrees(self) -> np.ndarray:
+        if not hasattr(self, "trainMat"):
+            raise ValueError("Training matrix not loaded. Please call LoadData() first.")
+        return np.bincount(self.graph.trn_rows, minlength=self.graph.users).astype(int)
+
+    def modalities(self) -> int:
+        return len(self.graph.feats)

@@ -1,0 +1,233 @@
+"""Training driver with the reference's surface (Main.py:18-487): Coach(handler, config).run() /.prepareModel() /
+.trainEpoch() / .testEpoch() / .calcRes() / .makePrint() / .save_max(), seed_it(seed), CLI `-c/--config`.
+
+The three phases of an epoch (diffusion training, reverse-chain rebuild of the modality graphs, joint BPR +
+contrastive training) run on diffmm_amd.engine (HIP kernels only).  Host synchronisation points per epoch: one per
+diffusion iteration (the loss normalisation needs host values, as in the reference), one per modality for the
+rebuilt edge list, one at the end of the joint phase for the logged losses.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import random
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import graph
+from .Conf import Config, load_config
+from .DataHandler import DataHandler
+from .Model import Denoise, GaussianDiffusion, Model, denoise_dims, hyper_dict
+from .engine import DiffusionEngine, modality_names
+
+main_log = None  # set by the CLI; any object with .info(str)
+
+
+def _log(msg: str) -> None:
+    if main_log is not None:
+        main_log.info(msg)
+
+
+class Coach:
+    def __init__(self, handler: DataHandler, config: Config, precision: int = 1):
+        """precision: 1 = single bf16 MFMA product in the dense GEMMs (fast path), 3 = hi/lo split (~fp32, parity tests)."""
+        self.handler, self.config, self.precision = handler, config, precision
+        self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
+        _log(f"USER: {config.data.user_num}, ITEM: {config.data.item_num}")
+        _log(f"NUM OF INTERACTIONS: {len(handler.trainData)}")
+        self.epoch_idx = 0
+
+    def makePrint(self, name, epoch, results: dict) -> str:
+        body = ", ".join(f"{k}={v:.5f}" for k, v in results.items())
+        return f"Epoch {epoch}/{self.config.train.epoch}, {name}: {body}  "
+
+    def save_max(self, new: list, old: list) -> list:
+        return [n if n > o else o for n, o in zip(new, old)]
+
+    # ---------------------------------------------------------------------------------------------
+    def prepareModel(self) -> None:
+        cfg, h = self.config, self.handler
+        M = h.modalities()
+        feats = [h.image_feats, h.text_feats] + ([h.audio_feats] if M == 3 else [])
+        self.M = M
+        self.model = Model(cfg, *feats, precision=self.precision)
+        self.diffusion_model = GaussianDiffusion(cfg)
+        in_dims, out_dims = denoise_dims(cfg)
+        self.diff_engine = DiffusionEngine(int(cfg.data.item_num), int(cfg.base.latdim), int(in_dims[1]), int(cfg.base.d_emb_size), M,
+                                           int(cfg.hyper.steps), hyper_dict(cfg), self.device, int(cfg.train.batch))
+        dens = [Denoise(in_dims, out_dims, cfg, _engine=self.diff_engine, _slot=m, precision=self.precision) for m in range(M)]
+        self.image_denoise_model, self.text_denoise_model = dens[0], dens[1]
+        if M == 3:
+            self.audio_denoise_model = dens[2]
+        self.base_lr = float(cfg.train.lr)
+        self.image_adj = self.text_adj = self.audio_adj = None
+
+    def _set_lr(self) -> None:
+        """CosineAnnealingLR(T_max=train.epoch, eta_min=1e-4), stepped once per epoch (Main.py:59-65,93,101,105,110)."""
+        lr = self.base_lr
+        if self.config.train.use_lr_scheduler:
+            lr = 1e-4 + (self.base_lr - 1e-4) * (1.0 + math.cos(math.pi * self.epoch_idx / self.config.train.epoch)) / 2.0
+        self.model.engine.lr = lr
+        self.diff_engine.lr = lr
+
+    def run(self) -> None:
+        self.prepareModel()
+        _log("Model Initialized")
+        best = dict(Recall=0.0, NDCG=0.0, Precision=0.0, epoch=0)
+        his_max = [0, 0, 0]
+        try:
+            for epoch in range(int(self.config.train.epoch)):
+                result = self.trainEpoch()
+                _log(self.makePrint("Train", epoch, result))
+                if epoch % int(self.config.train.tstEpoch) == 0:
+                    result = self.testEpoch()
+                    his_max = self.save_max([result["Recall"], result["NDCG"], result["Precision"]], his_max)
+                    if result["Recall"] > best["Recall"]:
+                        best = dict(result, epoch=epoch)
+                    _log(self.makePrint("Test", epoch, result))
+                _log(f"Current best: Epoch: {best['epoch']}, Recall: {best['Recall']:.5f}({his_max[0]:.5f}), NDCG: {best['NDCG']:.5f}"
+                     f"({his_max[1]:.5f}), Precision: {best['Precision']:.5f}({his_max[2]:.5f})")
+        except KeyboardInterrupt:
+            _log("Training interrupted by user!")
+        self.best = best
+
+    def makeTorchAdj(self, u_list, i_list, edge_list=None) -> graph.Adjacency:
+        cfg = self.config
+        return graph.make_adjacency(np.asarray(u_list), np.asarray(i_list), int(cfg.data.user_num), int(cfg.data.item_num), int(cfg.base.latdim),
+                                    self.device)
+
+    # ---------------------------------------------------------------------------------------------
+    def trainEpoch(self, draws=None, modal_adj_override: Optional[List[graph.Adjacency]] = None) -> Dict[str, float]:
+        """One epoch (Main.py:136-388).  `draws` (tests only) supplies the random draws in the reference's call order."""
+        cfg, h, M, dev = self.config, self.handler, self.M, self.device
+        J, DE, prec = self.model.engine, self.diff_engine, self.precision
+        self._set_lr()
+        if draws is None:
+            h.trainData.negSampling()
+        B = int(cfg.train.batch)
+        train_steps = max(1, len(h.trainData) // B)
+        diffusion_steps = max(1, len(h.diffusionData) // B)
+        T = int(cfg.hyper.steps)
+
+        # ---- phase 1: diffusion training (Main.py:145-192) ----
+        J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
+        feats = [J.feat[m] for m in range(M)]
+        dl = [0.0] * M
+        diff_batches = []
+        for x0, idx in h.diffusionLoader:
+            diff_batches.append(idx)
+            t = noise = None
+            if draws is not None:
+                t, noise = [], []
+                for m in range(M):
+                    t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
+                    noise.append(draws.randn(tuple(x0.shape)).to(dev))
+            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec)
+            tot = sum(means)
+            for m in range(M):  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
+                dl[m] += means[m]
+            for m in range(M):
+                dl[m] /= tot
+
+        # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
+        if modal_adj_override is None:
+            dd = h.diffusionData
+            n_edges = int(dd.ptr[-1])
+            if int(cfg.hyper.sampling_step) != 0:
+                raise NotImplementedError("sampling_step > 0 (noised start of the reverse chain) is not on the HIP path yet")
+            edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, n_edges, precision=prec)
+            u_list = np.repeat(np.arange(dd.users), np.diff(dd.ptr.cpu().numpy()))
+            adjs = [self.makeTorchAdj(u_list, e[:n_edges].cpu().numpy()) for e in edges]
+        else:
+            adjs = list(modal_adj_override)
+        self.image_adj, self.text_adj = adjs[0], adjs[1]
+        self.audio_adj = adjs[2] if M == 3 else None
+        J.set_adjacency(h.torchBiAdj, adjs)
+
+        # ---- phase 3: joint training (Main.py:292-377) ----
+        acc = torch.zeros(J.n_terms + 2, dtype=torch.float64, device=dev)
+        for users, pos, neg in h.trainLoader:
+            noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
+            acc += J.step(users, pos, neg, noise=noise, precision=prec)
+        a = acc.cpu().numpy()
+        nT = J.n_terms
+        cl, bpr, reg = float(a[:nT].sum()), float(a[nT]), float(a[nT + 1])
+        result = {"Loss": (bpr + reg + cl) / train_steps, "BPR Loss": bpr / train_steps, "reg loss": reg / train_steps, "CL loss": cl / train_steps}
+        for m, n in enumerate(modality_names(M)):
+            result[f"{n} loss"] = dl[m] / diffusion_steps
+        self.epoch_idx += 1
+        return result
+
+    # ---------------------------------------------------------------------------------------------
+    def testEpoch(self) -> Dict[str, float]:
+        """Full-ranking evaluation (Main.py:390-420).  Scores and top-k use torch ops: evaluation is outside the timed hot path."""
+        h, J = self.handler, self.model.engine
+        adjs = [self.image_adj, self.text_adj] + ([self.audio_adj] if self.M == 3 else [])
+        J.set_adjacency(h.torchBiAdj, adjs)
+        J.forward(with_cl=False, precision=self.precision)
+        U = J.U
+        uf, itf = J.Fin[:U], J.Fin[U:]
+        rec = ndcg = prec = 0.0
+        for usr, mask in h.testLoader:
+            score = (uf[usr] @ itf.t()) * (1 - mask) - mask * 1e8
+            top = torch.topk(score, int(self.config.base.topk)).indices
+            r, n, p = self.calcRes(top.cpu().numpy(), h.testData.test_user_its, usr)
+            rec, ndcg, prec = rec + r, ndcg + n, prec + p
+        n_u = len(h.testData)
+        return {"Recall": rec / n_u, "NDCG": ndcg / n_u, "Precision": prec / n_u}
+
+    def calcRes(self, top_idxs: np.ndarray, test_u_its: list, users):
+        """Sums of Recall / NDCG / Precision over the batch's users (Main.py:422-448)."""
+        k = int(self.config.base.topk)
+        disc = 1.0 / np.log2(np.arange(k) + 2.0)
+        ideal = np.cumsum(disc)
+        rec = ndcg = prec = 0.0
+        assert top_idxs.shape[0] == len(users)
+        for row, u in zip(top_idxs, users):
+            truth = np.asarray(test_u_its[int(u)])
+            hit = np.isin(row, truth)
+            n_hit = int(hit.sum())
+            rec += n_hit / len(truth)
+            ndcg += float(disc[hit].sum()) / ideal[min(len(truth), k) - 1]
+            prec += n_hit / k
+        return rec, ndcg, prec
+
+
+def seed_it(seed: int) -> None:
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def main(argv=None) -> None:
+    global main_log
+    ap = argparse.ArgumentParser(description="Model Configs")
+    ap.add_argument("--config", "-c", default="conf/tiktok.toml", type=str, help="config file path")
+    ap.add_argument("--precision", type=int, default=1, choices=(1, 3), help="1: bf16 MFMA GEMMs, 3: hi/lo split (~fp32)")
+    args = ap.parse_args(argv)
+    try:
+        config = load_config(args.config)
+        print(f"Load configuration ({config.data.name}) file successfully")
+    except Exception as e:  # same behaviour as the reference: report and exit 1
+        print(f"Error loading configuration file: {e}")
+        raise SystemExit(1)
+    seed_it(config.base.seed)
+    from .Utils.Log import Log
+    main_log = Log("main", config.data.name)
+    main_log.info("Start")
+    for section, options in vars(config).items():
+        main_log.info(f"{section}: {options}")
+    handler = DataHandler(config)
+    main_log.info("Load Data")
+    handler.LoadData()
+    Coach(handler, config, precision=args.precision).run()
+
+
+if __name__ == "__main__":
+    main()

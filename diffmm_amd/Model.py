@@ -1,0 +1,218 @@
+"""Model-side surface of the reference (Model.py:15-428) on top of the HIP engines.
+
+Model / Denoise / GaussianDiffusion keep the reference's constructor signatures, attribute and method names.
+They hold no nn.Parameters: weights live in the engines' flat HBM buffers (engine.FlatParams) and every method
+launches HIP kernels.  Parameter initialisation follows the reference's distributions (xavier_uniform embeddings,
+nn.Linear default init for the projections and the gate, xavier_normal + N(0, 1e-3) bias for the Denoise MLP).
+"""
+from __future__ import annotations
+
+import ast
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import ops
+from .Conf import Config
+from .engine import DiffusionEngine, JointEngine, modality_names, schedule_tables
+from .graph import Adjacency
+
+
+def _linear_default_init(out_f: int, in_f: int):
+    """torch.nn.Linear's default: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in)) for weight and bias."""
+    bound = 1.0 / math.sqrt(in_f)
+    return torch.empty(out_f, in_f).uniform_(-bound, bound), torch.empty(out_f).uniform_(-bound, bound)
+
+
+def hyper_dict(config: Config) -> dict:
+    h, t, b = config.hyper, config.train, config.base
+    return dict(modal_adj_weight=h.modal_adj_weight, residual_weight=h.residual_weight, noise_degree=h.noise_degree,
+                cross_cl_temp=h.cross_cl_temp, cross_cl_rate=h.cross_cl_rate, modal_cl_temp=h.modal_cl_temp, modal_cl_rate=h.modal_cl_rate,
+                reg=t.reg, lr=t.lr, cl_method=b.cl_method, seed=b.seed, noise_scale=h.noise_scale, noise_min=h.noise_min,
+                noise_max=h.noise_max, sim_weight=h.sim_weight, sampling_step=h.sampling_step)
+
+
+@dataclass
+class GCNOutput:
+    u_final_embs: Tensor
+    i_final_embs: Tensor
+    u_image_embs: Tensor
+    i_image_embs: Tensor
+    u_text_embs: Tensor
+    i_text_embs: Tensor
+    u_audio_embs: Optional[Tensor] = None
+    i_audio_embs: Optional[Tensor] = None
+
+
+class Model:
+    """Multi-modal graph encoder (Model.py:15-134).  `gcn_MM` returns views into the engine's HBM buffers."""
+
+    def __init__(self, config: Config, image_embedding: Tensor, text_embedding: Tensor, audio_embedding: Optional[Tensor] = None,
+                 batch_max: Optional[int] = None, precision: int = 1):
+        self.config = config
+        self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
+        feats = [image_embedding, text_embedding] + ([audio_embedding] if audio_embedding is not None else [])
+        U, I, D = int(config.data.user_num), int(config.data.item_num), int(config.base.latdim)
+        self.engine = JointEngine(U, I, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch))
+        self.precision = precision
+        self.image_embedding, self.text_embedding, self.audio_embedding = image_embedding, text_embedding, audio_embedding
+        sd = {"u_embs": torch.nn.init.xavier_uniform_(torch.empty(U, D)), "i_embs": torch.nn.init.xavier_uniform_(torch.empty(I, D))}
+        for n, f in zip(modality_names(len(feats)), feats):
+            sd[f"{n}_layer.weight"], sd[f"{n}_layer.bias"] = _linear_default_init(D, int(f.shape[1]))
+        sd["modal_weight"] = torch.tensor([0.3333, 0.3333, 0.3333]) if len(feats) == 3 else torch.tensor([0.5, 0.5])
+        self.engine.load_reference_state(sd)
+
+    def cuda(self, *_a, **_k):
+        return self
+
+    @property
+    def u_embs(self) -> Tensor:
+        return self.engine.u_embs
+
+    @property
+    def i_embs(self) -> Tensor:
+        return self.engine.i_embs
+
+    @property
+    def modal_weight(self) -> Tensor:
+        return self.engine.P.view("modal_weight")
+
+    def getItemEmbs(self) -> Tensor:
+        return self.engine.i_embs
+
+    def getUserEmbs(self) -> Tensor:
+        return self.engine.u_embs
+
+    def _feat(self, m: int) -> Tensor:
+        n = modality_names(self.engine.M)[m]
+        return ops.gemm(self.engine.feats[m], self.engine.P.view(f"{n}_layer.weight"), trans_b=True, bias=self.engine.P.view(f"{n}_layer.bias"),
+                        precision=self.precision)
+
+    def getImageFeats(self) -> Tensor:
+        return self._feat(0)
+
+    def getTextFeats(self) -> Tensor:
+        return self._feat(1)
+
+    def getAudioFeats(self) -> Optional[Tensor]:
+        return self._feat(2) if self.engine.M == 3 else None
+
+    def gcn_MM(self, adj: Adjacency, image_adj: Adjacency, text_adj: Adjacency, audio_adj: Optional[Adjacency] = None) -> GCNOutput:
+        madj = [image_adj, text_adj] + ([audio_adj] if audio_adj is not None else [])
+        self.engine.set_adjacency(adj, madj)
+        self.engine.forward(with_cl=False, precision=self.precision)
+        return GCNOutput(**self.engine.gcn_output())
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+
+class Denoise:
+    """Denoise MLP handle (Model.py:136-220): one slot of a DiffusionEngine."""
+
+    def __init__(self, in_dims: List[int], out_dims: List[int], config: Config, dropout: float = 0.5, _engine: Optional[DiffusionEngine] = None,
+                 _slot: int = 0, precision: int = 1):
+        self.in_dims, self.out_dims = in_dims, out_dims
+        self.time_emb_dim = int(config.base.d_emb_size)
+        self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
+        if len(in_dims) != 2 or len(out_dims) != 2:
+            raise ValueError("the HIP Denoise supports the reference's shipped shape: one hidden layer (denoise_dim = '[H]')")
+        I, H, D = int(in_dims[0]), int(in_dims[1]), int(config.base.latdim)
+        self.precision = precision
+        if _engine is None:
+            _engine = DiffusionEngine(I, D, H, self.time_emb_dim, 1, int(config.hyper.steps), hyper_dict(config), self.device, int(config.train.batch))
+        self.engine, self.slot = _engine, _slot
+        te = self.time_emb_dim
+        xn = torch.nn.init.xavier_normal_
+        sd = {"emb_layer.weight": xn(torch.empty(te, te)), "emb_layer.bias": torch.empty(te).normal_(0.0, 0.001),
+              "in_layers.0.weight": xn(torch.empty(H, I + te)), "in_layers.0.bias": torch.empty(H).normal_(0.0, 0.001),
+              "out_layers.0.weight": xn(torch.empty(I, H)), "out_layers.0.bias": torch.empty(I).normal_(0.0, 0.001)}
+        sd["gate_layer.weight"], sd["gate_layer.bias"] = _linear_default_init(D, D)  # created after init_weights(): default init
+        self.engine.load_reference_state(self.slot, sd)
+
+    def cuda(self, *_a, **_k):
+        return self
+
+    def forward(self, x_t: Tensor, timesteps: Tensor, modal_feat: Optional[Tensor] = None) -> Tensor:
+        return self.engine.denoise_forward(self.slot, x_t.contiguous(), timesteps.to(torch.int32), modal_feat, precision=self.precision).clone()
+
+    __call__ = forward
+
+    def state_dict(self):
+        return self.engine.state_dict(self.slot)
+
+
+class GaussianDiffusion:
+    """Noise schedule + forward / reverse process arithmetic (Model.py:222-428)."""
+
+    def __init__(self, config: Config, beta_fixed: bool = True):
+        self.config = config
+        self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
+        self.noise_scale, self.noise_min, self.noise_max = config.hyper.noise_scale, config.hyper.noise_min, config.hyper.noise_max
+        self.steps = int(config.hyper.steps)
+        self.beta_fixed = beta_fixed
+        if self.noise_scale != 0:
+            self.betas = torch.tensor(self.get_betas(), dtype=torch.float64, device=self.device)
+            if beta_fixed:
+                self.betas[0] = 0.0001
+            self.calculate_for_diffusion()
+
+    def cuda(self, *_a, **_k):
+        return self
+
+    def get_betas(self) -> np.ndarray:
+        return schedule_tables(self.steps, self.noise_scale, self.noise_min, self.noise_max, beta_fixed=False)["betas"]
+
+    def calculate_for_diffusion(self) -> None:
+        t = schedule_tables(self.steps, self.noise_scale, self.noise_min, self.noise_max, self.beta_fixed)
+        for k, v in t.items():
+            if k not in ("betas", "snr"):
+                setattr(self, k, torch.tensor(v, dtype=torch.float64, device=self.device))
+        self._snr = torch.tensor(t["snr"], dtype=torch.float64, device=self.device)
+
+    def _extract_into_tensor(self, var: Tensor, timesteps: Tensor, broadcast_shape) -> Tensor:
+        res = var[timesteps.long()].float()
+        while res.dim() < len(broadcast_shape):
+            res = res.unsqueeze(-1)
+        return res.expand(broadcast_shape)
+
+    def SNR(self, t: Tensor) -> Tensor:
+        return self._snr[t.long()]
+
+    def forward_cal_xt(self, x_0: Tensor, timesteps: Tensor, noise: Optional[Tensor] = None) -> Tensor:
+        if noise is None:
+            noise = torch.sign(x_0) * torch.nn.functional.normalize(torch.randn_like(x_0))
+        a = self._extract_into_tensor(self.sqrt_alphas_cumprod, timesteps, x_0.shape)
+        b = self._extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, timesteps, x_0.shape)
+        return a * x_0 + b * noise
+
+    def p_mean_variance(self, denoise: Denoise, x_t: Tensor, timesteps: Tensor, noise: Optional[Tensor] = None):
+        pred = denoise.forward(x_t, timesteps)
+        c1 = self._extract_into_tensor(self.posterior_mean_coef1, timesteps, x_t.shape)
+        c2 = self._extract_into_tensor(self.posterior_mean_coef2, timesteps, x_t.shape)
+        return c1 * pred + c2 * x_t, self._extract_into_tensor(self.posterior_log_variance_clipped, timesteps, x_t.shape)
+
+    def generate_view(self, model: Denoise, x_start: Tensor, sampling_step: int) -> Tensor:
+        if sampling_step != 0:
+            ts = torch.full((x_start.shape[0],), sampling_step - 1, device=x_start.device)
+            x_start = self.forward_cal_xt(x_start, ts)
+        return model.engine.generate_view(model.slot, x_start.contiguous(), precision=model.precision).clone()
+
+    def training_losses(self, model: Denoise, x_start: Tensor, i_embs: Tensor, modal_feat: Tensor) -> Tensor:
+        """Per-row loss vector (float64, like the reference).  Forward only: the optimiser step of the diffusion phase is
+        DiffusionEngine.train_step, which also needs the other modalities' losses (Main.py:175-176)."""
+        E, m, B = model.engine, model.slot, x_start.shape[0]
+        t = torch.randint(0, self.steps, (B,), device=x_start.device, dtype=torch.int32)
+        reg = float(self.config.train.reg)
+        reg_term = reg * reg * float((i_embs.double() ** 2).sum())
+        E.loss_forward(m, E._set_x0(x_start.contiguous()), t, None, modal_feat.contiguous(), i_embs.contiguous(), reg_term, model.precision)
+        return E.act[m]["loss"][:B].clone()
+
+
+def denoise_dims(config: Config):
+    out_dims = ast.literal_eval(config.base.denoise_dim) + [int(config.data.item_num)]
+    return out_dims[::-1], out_dims

@@ -74,11 +74,10 @@ def spmm_batched(ops: Sequence[SpmmOp]) -> None:
     L.check(L.lib().dmm_spmm_csr_f32(arr, len(ops), D, L.stream()), "dmm_spmm_csr_f32")
 
 
-def spmm(adj: Adjacency, x: Tensor, **kw) -> Tensor:
-    y = torch.empty_like(x) if kw.get("y") is None and kw.get("x_hi") is None else kw.pop("y", None)
+def spmm(adj: Adjacency, x: Tensor, y: Optional[Tensor] = None, **kw) -> Tensor:
+    """Y = A X (+ epilogues, see SpmmOp) as a single-problem launch."""
     if y is None:
         y = torch.empty((adj.n, adj.D), dtype=torch.float32, device=x.device)
-    kw.pop("y", None)
     spmm_batched([SpmmOp(adj, x, y=y, **kw)])
     return y
 

@@ -80,4 +80,9 @@ def test_joint_step_loss_grads_and_update_vs_oracle(dev, fx, cl_method):
     E.apply_adam()
     sd = E.state_dict()
     for k in P:
-        close(sd[k], P[k].detach(), rtol=1e-4, atol=2e-5, what="after Adam " + k)  # lr = 1e-3 bounds any sign flip of a ~0 gradient
+        # first Adam step moves every weight by lr * g / (|g| + 1e-8): where |g| is far above eps both sides move by ~lr exactly;
+        # where g ~ eps the step is ill-conditioned in g and only bounded by lr
+        big = (P[k].grad.abs() > 1e-5).numpy()
+        a, b = sd[k].cpu().numpy(), P[k].detach().numpy()
+        close(a[big], b[big], rtol=1e-4, atol=2e-5, what="after Adam " + k)
+        assert np.abs(a - b).max() <= 2.1e-3, "after Adam (tiny-gradient entries) " + k

@@ -1,0 +1,110 @@
+"""End-to-end parity: diffmm_amd.Main.Coach.trainEpoch()/testEpoch() on the HIP path against full epochs of the
+REFERENCE (tests/golden/epoch_*.npz: same graph, same initial weights, same batches, same random draws)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_kernels_gpu import T, close, load, need_gpu  # noqa: E402
+
+
+def close_weights(a, b, n_steps, lr, what):
+    """Weights after n Adam steps.  Adam moves every weight by ~lr per step whatever the gradient's size, so an entry whose
+    gradient is ~eps (1e-8) is ill-conditioned: bound those by the total possible travel, and require everything else tight."""
+    a = a.detach().double().cpu().numpy(); b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b)
+    ok = err <= 3e-4 + 1e-3 * np.abs(b)
+    assert ok.mean() >= 0.995, f"{what}: only {ok.mean():.4f} of the entries within tolerance"
+    assert err.max() <= 2.0 * lr * n_steps + 1e-6, f"{what}: max abs err {err.max():.3e} exceeds the Adam travel bound"
+
+
+class _Draws:
+    """Replays the recorded / re-generated draws in the reference's call order (same logic as oracle.Draws)."""
+
+    def __init__(self, z):
+        self.stored = [z[f"draw/{i}"] for i in range(int(z["n_draws"]))] if "draw/0" in z.files else None
+        self.gen = torch.Generator().manual_seed(int(z["draw_seed"]))
+        self.i, self.checks = 0, []
+
+    def _next(self, make):
+        r = torch.from_numpy(np.asarray(self.stored[self.i])) if self.stored is not None else make()
+        self.i += 1
+        self.checks.append(float(r.double().sum()))
+        return r
+
+    def randint(self, hi, n):
+        return self._next(lambda: torch.randint(0, hi, (n,), generator=self.gen))
+
+    def randn(self, shape):
+        return self._next(lambda: torch.randn(shape, generator=self.gen, dtype=torch.float32))
+
+    def rand(self, shape):
+        return self._next(lambda: torch.rand(shape, generator=self.gen, dtype=torch.float32))
+
+
+def _coach(z):
+    from diffmm_amd import synth
+    from diffmm_amd.Conf import Config
+    from diffmm_amd.DataHandler import DataHandler
+    from diffmm_amd.Main import Coach
+    M = int(z["M"])
+    cfg = Config()
+    cfg.data.name = "tiktok" if M == 3 else "sports"
+    cfg.base.latdim, cfg.base.denoise_dim, cfg.base.topk, cfg.base.cl_method = int(z["d"]), f"[{int(z['H'])}]", int(z["topk"]), int(z["cl_method"])
+    h_ = cfg.hyper
+    h_.steps, h_.noise_scale, h_.noise_degree, h_.cross_cl_rate, h_.cross_cl_temp = int(z["T"]), 0.5, 1.5, 0.5, 0.2
+    h_.modal_cl_rate, h_.modal_cl_temp, h_.sim_weight, h_.residual_weight, h_.modal_adj_weight = 0.01, 0.5, 0.01, 0.5, 0.2
+    t_ = cfg.train
+    t_.batch, t_.test_batch, t_.reg, t_.lr, t_.epoch = int(z["B"]), 64, float(z["reg"]), float(z["lr"]), int(z["train_epochs_cfg"])
+    g = synth.SynthGraph(int(z["users"]), int(z["items"]), z["trn_rows"], z["trn_cols"], z["tst_rows"], z["tst_cols"], [z[f"feat{m}"] for m in range(M)])
+    h = DataHandler(cfg)
+    h.LoadData(graph_data=g)
+    h.trainLoader.fixed_perm = T(z["train_perm"].astype(np.int64))
+    h.diffusionLoader.fixed_perm = T(z["diff_perm"].astype(np.int64))
+    coach = Coach(h, cfg, precision=3)
+    coach.prepareModel()
+    coach.model.engine.load_reference_state({k[len("init/model/"):]: z[k] for k in z.files if k.startswith("init/model/")})
+    for m in range(M):
+        coach.diff_engine.load_reference_state(m, {k[len(f"init/den{m}/"):]: z[k] for k in z.files if k.startswith(f"init/den{m}/")})
+    return coach, h, M
+
+
+@pytest.mark.parametrize("fx", ["epoch_toy", "epoch_mid", "epoch_mid_cl1", "epoch_mid_M2"])
+def test_epochs_match_reference(fx):
+    need_gpu()
+    z = load(fx + ".npz")
+    coach, h, M = _coach(z)
+    draws = _Draws(z)
+    for ep in range(int(z["epochs"])):
+        h.trainData.set_negs(z[f"ep{ep}/negs"])
+        res = coach.trainEpoch(draws=draws)
+        # rebuilt modality graphs: the same edge set as the reference's python top-k loop
+        same_edges = True
+        for m, adj in enumerate([coach.image_adj, coach.text_adj] + ([coach.audio_adj] if M == 3 else [])):
+            rp, col = adj.rowptr.cpu().numpy(), adj.col.cpu().numpy()
+            row = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+            ref = set(zip(z[f"ep{ep}/adj{m}_row"].tolist(), z[f"ep{ep}/adj{m}_col"].tolist()))
+            got = set(zip(row.tolist(), col.tolist()))
+            inter = len(ref & got) / max(1, len(ref))
+            assert inter >= 0.995, f"epoch {ep} modality {m}: only {inter:.4f} of the rebuilt edges agree"
+            same_edges &= ref == got
+        tol = dict(rtol=2e-4, atol=1e-6) if same_edges else dict(rtol=5e-3, atol=1e-5)
+        for k, v in res.items():
+            close(v, z[f"ep{ep}/train/{k}"], what=f"ep{ep} {k}", **tol)
+        tres = coach.testEpoch()
+        if same_edges:
+            for k, v in tres.items():
+                close(v, z[f"ep{ep}/test/{k}"], rtol=0.02, atol=2e-3, what=f"ep{ep} test {k}")
+            B, lr = int(z["B"]), float(z["lr"])
+            n_joint = (ep + 1) * -(-len(z["trn_rows"]) // B)
+            n_diff = (ep + 1) * -(-int(z["users"]) // B)
+            for k, p in coach.model.state_dict().items():
+                close_weights(p, z[f"ep{ep}/model/{k}"], n_joint, lr, f"ep{ep} model {k}")
+            for m in range(M):
+                for k, p in coach.diff_engine.state_dict(m).items():
+                    close_weights(p, z[f"ep{ep}/den{m}/{k}"], n_diff, lr, f"ep{ep} den{m} {k}")
+    assert draws.i == int(z["n_draws"])
+    close(np.array(draws.checks), z["draw_checksum"], rtol=1e-12, what="the random draws must be the recorded ones")

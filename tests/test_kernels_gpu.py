@@ -103,7 +103,7 @@ def test_spmm_perturb_mean_and_batch(dev, name, D):
     ys = [torch.empty((n, D), device=dev) for _ in range(4)]
     ops.spmm_batched([ops.SpmmOp(adj, x.to(dev), y=yy, alpha=float(i + 1)) for i, (x, yy) in enumerate(zip(Xs, ys))])
     for i in range(4):
-        close(ys[i], (i + 1) * torch.sparse.mm(A, Xs[i]), what=f"batched {i}")
+        close(ys[i], (i + 1) * torch.sparse.mm(A, Xs[i]), atol=2e-5, what=f"batched {i}")
 
 
 def test_spmm_is_deterministic_and_symmetric_backward(dev):
@@ -131,7 +131,8 @@ def test_gemm_layouts(dev, M, N, K, prec):
     A = T(rng.standard_normal((M, K)).astype(np.float32)); Bm = T(rng.standard_normal((K, N)).astype(np.float32))
     bias = T(rng.standard_normal(N).astype(np.float32)); R = T(rng.standard_normal((M, N)).astype(np.float32))
     ref = A.double() @ Bm.double()
-    tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K)) if prec == 3 else dict(rtol=2e-2, atol=2e-2 * np.sqrt(K))
+    # hi/lo split keeps 16 mantissa bits per operand: ~1.5e-5 relative per product
+    tol = dict(rtol=5e-5, atol=5e-5 * np.sqrt(K)) if prec == 3 else dict(rtol=2e-2, atol=2e-2 * np.sqrt(K))
     Ad, Bd = A.to(dev), Bm.to(dev)
     close(ops.gemm(Ad, Bd, precision=prec), ref, what="NN", **tol)
     close(ops.gemm(Ad, Bd.t().contiguous(), trans_b=True, precision=prec), ref, what="NT", **tol)
