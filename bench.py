@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BPR + diffusion training iterations per second on the TikTok-shape graph (d=64, T=40).
+
+A "step" is one EPOCH of the hot path on synthetic inputs resident in HBM: n_diff diffusion-training iterations
+(all modalities), the reverse-chain rebuild of the modality graphs (T Denoise forwards per user batch and modality,
+per-user top-k, adjacency build) and n_joint joint BPR + contrastive iterations -- the blended rate of SURVEY.md
+section 8(d):  value = (n_diff + n_joint) * K / wall_seconds, B-sized minibatches consumed per second, whole job.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: one process per GPU over RCCL; every rank holds the (small) graph, the minibatches of an epoch are dealt
+round-robin to the ranks, gradients are averaged with all-reduce before Adam, the rebuild's user batches are sharded
+and their edges all-gathered.  The data set is fixed, so this is strong scaling.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def make_coach(args, rank: int, world: int):
+    from diffmm_amd.Conf import load_config
+    from diffmm_amd.DataHandler import DataHandler
+    from diffmm_amd.Main import Coach, seed_it
+    cfg = load_config(os.path.join(REPO, "conf", "tiktok.toml"))
+    cfg.base.gpu = str(int(os.environ.get("LOCAL_RANK", 0)))
+    cfg.base.latdim, cfg.hyper.steps, cfg.train.batch = args.latdim, args.T, args.batch
+    cfg.data.name = args.workload
+    seed_it(cfg.base.seed)
+    h = DataHandler(cfg)
+    h.LoadData()
+    coach = Coach(h, cfg, precision=args.precision)
+    coach.prepareModel()
+    if world > 1:
+        coach.enable_distributed(rank, world)
+    return coach, h, cfg
+
+
+def timed_launches(fn, n: int) -> float:
+    """Average duration (seconds) of n back-to-back launches, HIP events on the stream the kernels run on."""
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def roofline(coach, args):
+    """Live measurement of the two kernels that bound the epoch: the Denoise layer-1 GEMM (MFMA bound; the reverse
+    chain issues it T * batches * modalities times per epoch) and the CSR SpMM (HBM bound; north_star's figure)."""
+    from diffmm_amd import ops, _lib as L
+    DE, J = coach.diff_engine, coach.model.engine
+    B, H, I, Kp = args.batch, DE.H, DE.I, DE.Kp
+    P = DE.P[0]
+    x, h = DE.xa[:B], DE.dh[:B]
+    x.normal_()
+    t1 = timed_launches(lambda: ops.gemm(x, P.view("in_layers.0.weight"), out=h, trans_b=True, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH,
+                                         precision=args.precision), 20)
+    flops1 = 2.0 * B * Kp * H * (3 if args.precision == 3 else 1)
+    t2 = timed_launches(lambda: ops.gemm(h, P.view("out_layers.0.weight"), out=DE.xb[:B], trans_b=True, bias=P.view("out_layers.0.bias"),
+                                         precision=args.precision, N=I, residual=x, e1=0.5, e2=0.5), 20)
+    flops2 = 2.0 * B * H * I * (3 if args.precision == 3 else 1)
+    A = J.adj
+    emb = J.P.view("emb")
+    ts = timed_launches(lambda: ops.spmm_batched([ops.SpmmOp(A, emb, y=J.Bx)]), 50)
+    sb = A.algorithmic_bytes(4)
+    gemm = {"bound": "mfma", "kernel": "gemm_kernel<NT,bf16> Denoise layer 1 (B x (I+te) x H)", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
+            "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6,
+            "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6}
+    spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": sb / ts / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": ts * 1e6, "algorithmic_bytes": sb}
+    return gemm, spmm
+
+
+def cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint):
+    """The CPU oracle (a validated restatement of the reference's PyTorch-CPU path) timed on this box's host cores on a
+    bounded sample of the same workload, extrapolated to one epoch."""
+    from oracle import diffmm_oracle as O
+    g = h.graph
+    U, I, D, M, B, T = g.users, g.items, args.latdim, len(g.feats), args.batch, args.T
+    threads = torch.get_num_threads()
+    rng = np.random.default_rng(0)
+    feats = [torch.from_numpy(f) for f in g.feats]
+    model = {"u_embs": torch.nn.init.xavier_uniform_(torch.empty(U, D)), "i_embs": torch.nn.init.xavier_uniform_(torch.empty(I, D)),
+             "modal_weight": torch.full((M,), 1.0 / M)}
+    for n, f in zip(O.modality_names(M), feats):
+        model[f"{n}_layer.weight"], model[f"{n}_layer.bias"] = torch.randn(D, f.shape[1]) * 0.05, torch.zeros(D)
+    H, te = 1024, 10
+    den = lambda: {"emb_layer.weight": torch.randn(te, te) * 0.3, "emb_layer.bias": torch.zeros(te), "in_layers.0.weight": torch.randn(H, I + te) * 0.02,
+                   "in_layers.0.bias": torch.zeros(H), "out_layers.0.weight": torch.randn(I, H) * 0.02, "out_layers.0.bias": torch.zeros(I),
+                   "gate_layer.weight": torch.randn(D, D) * 0.1, "gate_layer.bias": torch.zeros(D)}
+    st = O.EpochState(model, [den() for _ in range(M)], 1e-3, 100)
+    hp = dict(T=T, sim_weight=0.01, reg=1e-4, modal_adj_weight=0.2, residual_weight=0.5, noise_degree=1.5, cross_cl_temp=0.2, cross_cl_rate=0.5,
+              modal_cl_temp=0.5, modal_cl_rate=0.01, cl_method=0)
+    sched = O.schedule(T, 0.5, 0.0001, 0.02)
+    dense = torch.zeros(U, I); dense[torch.from_numpy(g.trn_rows.astype(np.int64)), torch.from_numpy(g.trn_cols.astype(np.int64))] = 1.0
+    adj = O.csr_to_torch(*O.build_adj_csr(g.trn_rows, g.trn_cols, U, I))
+    draws = O.Draws(seed=1)
+    idx = rng.permutation(U)[:B]
+    x0 = dense[torch.from_numpy(idx)]
+    t0 = time.perf_counter(); O.diffusion_step(st, feats, x0, draws, sched, hp); t_diff = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        view = O.generate_view(st.dens[0], x0, sched, 0)
+        O.topk_edges(view[:256], idx[:256], np.bincount(g.trn_rows, minlength=U))
+    t_reb_unit = time.perf_counter() - t0
+    e = rng.integers(0, g.nnz, size=B)
+    u, p = torch.from_numpy(g.trn_rows[e].astype(np.int64)), torch.from_numpy(g.trn_cols[e].astype(np.int64))
+    ng = torch.from_numpy(rng.integers(0, I, size=B))
+    t0 = time.perf_counter()
+    for _ in range(2):
+        O.joint_step(st, feats, adj, [adj] * M, u, p, ng, draws, hp)
+    t_joint = (time.perf_counter() - t0) / 2
+    n_batches = -(-U // B)
+    epoch = n_diff * t_diff + n_batches * M * t_reb_unit + n_joint * t_joint
+    return {"value": iters_per_epoch / epoch, "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"1 diffusion iter ({t_diff:.2f}s) + 1 of {n_batches * M} rebuild units: T={T} reverse steps on one {B}-user batch, one modality "
+                      f"({t_reb_unit:.2f}s) + 2 joint iters ({t_joint:.2f}s each), extrapolated to an epoch of {epoch:.1f}s; torch {torch.__version__} CPU, "
+                      f"{threads} threads of {os.cpu_count()} cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="tiktok"); ap.add_argument("--T", type=int, default=40); ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--latdim", type=int, default=64); ap.add_argument("--precision", type=int, default=1, choices=(1, 3))
+    ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    coach, h, cfg = make_coach(args, rank, world)
+    n_diff, n_joint = len(h.diffusionLoader), len(h.trainLoader)
+    iters_per_epoch = n_diff + n_joint
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        coach.trainEpoch()
+    sync()
+    t0 = time.perf_counter()
+    phases = np.zeros(3)
+    for _ in range(args.steps):
+        coach.trainEpoch()
+        phases += np.array(getattr(coach, "phase_seconds", [0, 0, 0]))
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if rank != 0:
+        return
+    out = {"metric": "BPR+diffusion train iters/sec on TikTok d=64 T=40", "value": iters_per_epoch * args.steps / dt, "unit": "iters/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
+           "data": "synthetic",
+           "config": {"workload": f"synthetic {args.workload}-shape graph: U={h.graph.users} I={h.graph.items} E={h.graph.nnz}, M={len(h.graph.feats)} modalities, "
+                                  f"d={args.latdim}, T={args.T}, batch={args.batch}; step = 1 epoch = {n_diff} diffusion iters + rebuild + {n_joint} joint iters",
+                      "parallelism": f"dp{world}", "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
+                      "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3}}}
+    if not args.no_roofline:
+        g, s = roofline(coach, args)
+        out["roofline"], out["roofline_spmm"] = g, s
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -27,9 +27,12 @@ from .Conf import Config
 class BatchLoader:
     """Minimal stand-in for torch DataLoader(shuffle=..., num_workers=0): index batches drawn on the device."""
 
-    def __init__(self, dataset, batch_size: int, shuffle: bool, device):
+    def __init__(self, dataset, batch_size: int, shuffle: bool, device, seed: int = 0):
         self.dataset, self.batch_size, self.shuffle, self.device = dataset, batch_size, shuffle, device
         self.fixed_perm: Optional[torch.Tensor] = None  # tests pin the order through this
+        # own generator: data-parallel replicas must draw identical permutations whatever else consumed the global RNG
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
 
     def __len__(self) -> int:
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -39,7 +42,7 @@ class BatchLoader:
         if self.fixed_perm is not None:
             perm = self.fixed_perm.to(self.device)
         elif self.shuffle:
-            perm = torch.randperm(n, device=self.device)
+            perm = torch.randperm(n, device=self.device, generator=self.gen)
         else:
             perm = torch.arange(n, device=self.device)
         for s in range(0, n, self.batch_size):
@@ -51,6 +54,8 @@ class TrainData:
 
     def __init__(self, rows: np.ndarray, cols: np.ndarray, config: Config, device="cpu"):
         self.config, self.device = config, torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(config.base.seed) + 17)
         self.rows, self.cols = np.asarray(rows, dtype=np.int32), np.asarray(cols, dtype=np.int32)
         self.negs = np.zeros(len(self.rows), dtype=np.int32)
         items = int(config.data.item_num)
@@ -67,14 +72,14 @@ class TrainData:
         items = int(self.config.data.item_num)
         n = len(self.rows)
         rows64 = self._rows_d.long()
-        neg = torch.randint(0, items, (n,), device=self.device)
+        neg = torch.randint(0, items, (n,), device=self.device, generator=self.gen)
         bad = torch.arange(n, device=self.device)
         while bad.numel():
             key = rows64[bad] * items + neg[bad]
             pos = torch.searchsorted(self._keys, key).clamp_(max=self._keys.numel() - 1)
             bad = bad[self._keys[pos] == key]
             if bad.numel():
-                neg[bad] = torch.randint(0, items, (int(bad.numel()),), device=self.device)
+                neg[bad] = torch.randint(0, items, (int(bad.numel()),), device=self.device, generator=self.gen)
         self._negs_d = neg.to(torch.int32)
         self.negs = self._negs_d.cpu().numpy()
 
@@ -211,7 +216,7 @@ class DataHandler:
         self.trainMat = sp.coo_matrix((np.ones(g.nnz, np.float32), (g.trn_rows, g.trn_cols)), shape=(U, I))
         self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev)
         self.trainData = TrainData(g.trn_rows, g.trn_cols, cfg, dev)
-        self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev)
+        self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 1)
         self.testData = TestData(g.tst_rows, g.tst_cols, g.trn_rows, g.trn_cols, U, I, dev)
         self.testLoader = BatchLoader(self.testData, int(cfg.train.test_batch), False, dev)
         f = [torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dev) for x in g.feats]
@@ -220,7 +225,7 @@ class DataHandler:
         if len(f) > 2:
             self.audio_feats, cfg.data.audio_feat_dim = f[2], int(f[2].shape[1])
         self.diffusionData = DiffusionData(g.trn_rows, g.trn_cols, U, I, dev)
-        self.diffusionLoader = BatchLoader(self.diffusionData, int(cfg.train.batch), True, dev)
+        self.diffusionLoader = BatchLoader(self.diffusionData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 2)
         self.user_pos_items = self.trainData.user_pos_items
 
     def getUserDegrees(self) -> np.ndarray:

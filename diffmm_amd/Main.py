@@ -39,6 +39,16 @@ class Coach:
         _log(f"USER: {config.data.user_num}, ITEM: {config.data.item_num}")
         _log(f"NUM OF INTERACTIONS: {len(handler.trainData)}")
         self.epoch_idx = 0
+        self.world, self.rank = 1, 0
+        self.phase_seconds = [0.0, 0.0, 0.0]
+
+    def enable_distributed(self, rank: int, world: int) -> None:
+        """Data-parallel replicas (one process per GPU, torch.distributed 'nccl' == RCCL): minibatches are dealt round-robin,
+        gradients averaged by all-reduce, rebuild user batches sharded.  Call after prepareModel()."""
+        self.rank, self.world = rank, world
+        for e in (self.model.engine, self.diff_engine):
+            e.world, e.rank = world, rank
+            e.hp["seed"] = int(e.hp.get("seed", 1818)) + 7919 * rank  # decorrelate the in-kernel Philox streams
 
     def makePrint(self, name, epoch, results: dict) -> str:
         body = ", ".join(f"{k}={v:.5f}" for k, v in results.items())
@@ -112,25 +122,35 @@ class Coach:
         diffusion_steps = max(1, len(h.diffusionData) // B)
         T = int(cfg.hyper.steps)
 
+        import time
+        W, R = self.world, self.rank
+        t_start = time.perf_counter()
         # ---- phase 1: diffusion training (Main.py:145-192) ----
         J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
         feats = [J.feat[m] for m in range(M)]
         dl = [0.0] * M
         diff_batches = []
-        for x0, idx in h.diffusionLoader:
-            diff_batches.append(idx)
+        batches = list(h.diffusionLoader)
+        for gs in range(0, len(batches), W):  # one global step = up to W minibatches, one per replica
+            group = batches[gs:gs + W]
+            diff_batches += [idx for _, idx in group]
+            if R >= len(group):
+                DE.idle_step(len(group))
+                continue
+            x0, idx = group[R]
             t = noise = None
             if draws is not None:
                 t, noise = [], []
                 for m in range(M):
                     t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
                     noise.append(draws.randn(tuple(x0.shape)).to(dev))
-            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec)
+            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, n_contrib=len(group))
             tot = sum(means)
             for m in range(M):  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
                 dl[m] += means[m]
             for m in range(M):
                 dl[m] /= tot
+        t_diff = time.perf_counter()
 
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
         if modal_adj_override is None:
@@ -146,13 +166,25 @@ class Coach:
         self.image_adj, self.text_adj = adjs[0], adjs[1]
         self.audio_adj = adjs[2] if M == 3 else None
         J.set_adjacency(h.torchBiAdj, adjs)
+        t_reb = time.perf_counter()
 
         # ---- phase 3: joint training (Main.py:292-377) ----
         acc = torch.zeros(J.n_terms + 2, dtype=torch.float64, device=dev)
-        for users, pos, neg in h.trainLoader:
+        batches = list(h.trainLoader)
+        for gs in range(0, len(batches), W):
+            group = batches[gs:gs + W]
+            if R >= len(group):
+                J.allreduce_grads(contributing=False, n_contrib=len(group))
+                J.apply_adam(fold_extras=False)
+                continue
+            users, pos, neg = group[R]
             noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
-            acc += J.step(users, pos, neg, noise=noise, precision=prec)
+            acc += J.step(users, pos, neg, noise=noise, precision=prec, n_contrib=len(group))
+        if W > 1:
+            import torch.distributed as dist
+            dist.all_reduce(acc)
         a = acc.cpu().numpy()
+        self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]
         nT = J.n_terms
         cl, bpr, reg = float(a[:nT].sum()), float(a[nT]), float(a[nT + 1])
         result = {"Loss": (bpr + reg + cl) / train_steps, "BPR Loss": bpr / train_steps, "reg loss": reg / train_steps, "CL loss": cl / train_steps}

@@ -108,6 +108,7 @@ class JointEngine:
         self.adj: Optional[Adjacency] = None
         self.modal_adj: List[Adjacency] = []
         self.rng_step = 0
+        self.world, self.rank = 1, 0  # data-parallel replicas (gradient all-reduce over RCCL) when world > 1
 
     # -- parameters as the reference names them -------------------------------------------------
     @property
@@ -192,7 +193,7 @@ class JointEngine:
         return ops.Slots(e), ops.make_terms(terms)
 
     def step(self, users: Tensor, pos: Tensor, neg: Tensor, noise: Optional[Sequence[Tensor]] = None, precision: int = 3,
-             update: bool = True) -> Tensor:
+             update: bool = True, n_contrib: Optional[int] = None) -> Tensor:
         """Runs forward + backward (+ Adam).  Returns the device tensor loss_parts = [InfoNCE terms..., bpr, reg]
         (weights folded in); no host synchronisation happens here."""
         B, D, U, N, M, hp = int(users.shape[0]), self.D, self.U, self.N, self.M, self.hp
@@ -234,15 +235,31 @@ class JointEngine:
             ops.gemm(self.dfeat[m], self.feats[m], out=gw, trans_a=True, precision=precision, split_k=16)
             ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"))
         if update:
-            self.apply_adam()
+            if self.world > 1:
+                self.allreduce_grads(contributing=True, n_contrib=n_contrib)
+            self.apply_adam(fold_extras=self.world == 1)
         self.rng_step += 1
         return self.loss_parts
 
-    def apply_adam(self):
+    def allreduce_grads(self, contributing: bool, n_contrib: Optional[int] = None):
+        """Data-parallel step: average the local gradients of the replicas that hold a minibatch (RCCL all-reduce on the
+        flat gradient buffer).  A replica without a minibatch in this global step contributes zeros."""
+        import torch.distributed as dist
+        ne = self.U * self.D
+        if contributing:
+            for t in self.T:  # fold the user-row parts of the modal SpMM backward into the flat buffer first
+                ops.add_inplace(self.P.grad[:ne], t.view(-1)[:ne], 1.0)
+        else:
+            self.P.grad.zero_()
+        dist.all_reduce(self.P.grad)
+        self.P.grad.mul_(1.0 / float(n_contrib or self.world))
+
+    def apply_adam(self, fold_extras: bool = True):
         P, U, D = self.P, self.U, self.D
         P.step += 1
         ne = self.N * D
-        ops.adam_step(P.data[:ne], P.grad[:ne], P.m[:ne], P.v[:ne], self.lr, P.step, extra=[t for t in self.T], extra_n=[U * D] * self.M,
+        extra = [t for t in self.T] if fold_extras else []
+        ops.adam_step(P.data[:ne], P.grad[:ne], P.m[:ne], P.v[:ne], self.lr, P.step, extra=extra, extra_n=[U * D] * len(extra),
                       l2_coef=2.0 * self.hp["reg"])
         ops.adam_step(P.data[ne:], P.grad[ne:], P.m[ne:], P.v[ne:], self.lr, P.step)
 
@@ -315,6 +332,7 @@ class DiffusionEngine:
         self.dh, self.dpre = z(B_max, H), z(B_max, H)
         self.xa, self.xb = z(B_max, Kp), z(B_max, Kp)  # ping-pong buffers of the reverse chain
         self.rng_step = 0
+        self.world, self.rank = 1, 0
 
     def load_reference_state(self, m: int, sd: Dict[str, Tensor]):
         t = {k: torch.as_tensor(v).float() for k, v in sd.items()}
@@ -403,7 +421,7 @@ class DiffusionEngine:
         ops.colsum(self.dgate[:B], B, D, P.g("gate_layer.bias"))
 
     def train_step(self, x0: Tensor, feats: Sequence[Tensor], i_embs: Tensor, t: Optional[Sequence[Tensor]] = None,
-                   noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True) -> List[float]:
+                   noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True, n_contrib: Optional[int] = None) -> List[float]:
         """One iteration of Main.py:145-192 over all modalities.  `feats` are the projected, detached modality features."""
         B, M = x0.shape[0], self.M
         x0p = self._set_x0(x0)
@@ -417,11 +435,25 @@ class DiffusionEngine:
         for m in range(M):
             self.loss_backward(m, x0p, feats[m], reg_term, 1.0 / (B * total), precision)
             if update:
-                P = self.P[m]
-                P.step += 1
-                ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step)
+                self.reduce_and_step(m, contributing=True, n_contrib=n_contrib)
         self.rng_step += 1
         return means
+
+    def reduce_and_step(self, m: int, contributing: bool, n_contrib: Optional[int] = None):
+        P = self.P[m]
+        if self.world > 1:
+            import torch.distributed as dist
+            if not contributing:
+                P.grad.zero_()
+            dist.all_reduce(P.grad)
+            P.grad.mul_(1.0 / float(n_contrib or self.world))
+        P.step += 1
+        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step)
+
+    def idle_step(self, n_contrib: int):
+        """A replica with no user batch in this global step still joins the gradient all-reduces."""
+        for m in range(self.M):
+            self.reduce_and_step(m, contributing=False, n_contrib=n_contrib)
 
     # -- reverse chain (generate_view, Model.py:300-322) ------------------------------------------------
     def generate_view(self, m: int, x0: Tensor, precision: int = 1) -> Tensor:
@@ -442,9 +474,15 @@ class DiffusionEngine:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
         int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]])."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
-        for ub in user_batches:
+        for i, ub in enumerate(user_batches):
+            if i % self.world != self.rank:  # user batches are sharded over the replicas
+                continue
             x0 = dense_rows(ub)
             for m in range(self.M):
                 den = self.generate_view(m, x0, precision)
                 ops.topk_rows(den, ub.to(torch.int32), deg_ptr, out[m], self.I)
+        if self.world > 1:  # every edge slot is written by exactly one replica: a sum all-reduce is an all-gather
+            import torch.distributed as dist
+            for o in out:
+                dist.all_reduce(o)
         return out
