@@ -69,24 +69,26 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
   }
 }
 
-// d w_emb[c][k] = sum_b dtemb[b][c] * e_b[k],  d b_emb[c] = sum_b dtemb[b][c]   (single workgroup; te <= 32)
+// d w_emb[c][k] += sum_b dtemb[b][c] * e_b[k],  d b_emb[c] += sum_b dtemb[b][c]   (te <= 32; one workgroup per 64 batch rows,
+// thread = one (c, k) pair, partial sums added with fp32 atomics)
 __global__ __launch_bounds__(1024) void temb_bwd_kernel(const int32_t* __restrict__ t, const float* __restrict__ dxcat, long long ldx, int I,
                                                          int te, int B, float* __restrict__ dw, float* __restrict__ db) {
   const int c = threadIdx.x / te, k = threadIdx.x % te;
   if (c >= te) return;
+  const int b0 = blockIdx.x * 64, b1 = min(B, b0 + 64);
   double aw = 0.0, ab = 0.0;
   const int half = te / 2;
   const bool is_pad = (te & 1) && k == te - 1;
   const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const float ang = (float)t[b] * f;
     const float ek = is_pad ? 0.f : (k < half ? cosf(ang) : sinf(ang));
     const float g = dxcat[(long long)b * ldx + I + c];
     aw += (double)g * (double)ek;
     ab += (double)g;
   }
-  dw[c * te + k] += (float)aw;
-  if (k == 0) db[c] += (float)ab;
+  atomicAdd(dw + c * te + k, (float)aw);
+  if (k == 0) atomicAdd(db + c, (float)ab);
 }
 
 // diffusion loss: one workgroup per batch row
@@ -220,7 +222,7 @@ extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* nois
 
 extern "C" int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, int I, int te, int B, float* dw_emb, float* db_emb, void* stream) {
   DMM_CHECK_ARG(t && dxcat && dw_emb && db_emb && te >= 2 && te <= MAX_TE && B > 0, "dmm_temb_bwd: bad arguments");
-  hipLaunchKernelGGL(temb_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t, dxcat, (long long)ldx, I, te, B, dw_emb, db_emb);
+  hipLaunchKernelGGL(temb_bwd_kernel, dim3(cdiv(B, 64)), dim3(1024), 0, (hipStream_t)stream, t, dxcat, (long long)ldx, I, te, B, dw_emb, db_emb);
   DMM_LAUNCH_CHECK("dmm_temb_bwd");
   return 0;
 }

@@ -235,17 +235,20 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = fmaf(alpha, x[i], y[i]);
 }
-// column sums: block (64 columns) x all rows; 4 waves split the rows, combine through LDS
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, float* __restrict__ out) {
+// column sums: grid (column groups of 64, row chunks); every wave strides its chunk's rows reading 256-byte row segments,
+// the workgroup combines its 4 waves through LDS and adds the chunk's partial into out[] (fp32 atomic; out pre-zeroed)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, int rows_per_chunk,
+                                                      float* __restrict__ out) {
   __shared__ float sm[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
-  double a = 0.0;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float a = 0.f;
   if (c < cols)
-    for (int r = w; r < rows; r += 4) a += (double)x[(size_t)r * ldx + c];
-  sm[w][threadIdx.x & 63] = (float)a;
+    for (int r = r0 + w; r < r1; r += 4) a += x[(size_t)r * ldx + c];
+  sm[w][threadIdx.x & 63] = a;
   __syncthreads();
-  if (w == 0 && c < cols) out[c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+  if (w == 0 && c < cols) atomicAdd(out + c, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 template <int D>
@@ -372,7 +375,9 @@ extern "C" int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n,
 }
 extern "C" int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, void* stream) {
   DMM_CHECK_ARG(x && out && rows > 0 && cols > 0, "dmm_colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out);
+  const int chunk = rows > 64 ? 64 : rows;
+  hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), cdiv(rows, chunk)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, chunk, out);
   DMM_LAUNCH_CHECK("dmm_colsum");
   return 0;
 }

@@ -21,19 +21,54 @@ struct TermTable {
 // ---------------------------------------------------------------------------------------------
 // zhat[s][b] = normalize(src_s[idx_s[b]]),  norm[s][b] = ||src_s[idx_s[b]]||
 // ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// bf16 operand packs for the MFMA InfoNCE kernels, all [n_slots][...] with Bp = B rounded up to 32 (pad rows zero):
+//   hi [s][Bp][D], lo [s][Bp][D] (lo = bf16(x - hi)), hiT [s][D][Bp], loT [s][D][Bp]
+struct Bf16Pack {
+  __bf16 *hi, *lo, *hiT, *loT;
+  int Bp;
+};
+
 template <int D>
-__global__ __launch_bounds__(256) void gather_normalize_kernel(SlotTable S, int B, float* __restrict__ zhat, float* __restrict__ norm) {
+__global__ __launch_bounds__(256) void gather_normalize_kernel(SlotTable S, int B, float* __restrict__ zhat, float* __restrict__ norm,
+                                                                Bf16Pack pk) {
   constexpr int LANES = D / 4, G = 256 / LANES;
   const int s = blockIdx.y;
   const int l = threadIdx.x % LANES;
   const float* __restrict__ src = S.src[s];
   const int32_t* __restrict__ idx = S.idx[s];
-  for (int b = blockIdx.x * G + threadIdx.x / LANES; b < B; b += gridDim.x * G) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)idx[b] * D + 4 * l);
-    const float nrm = sqrtf(group_sum<LANES>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
-    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-    *reinterpret_cast<float4*>(zhat + ((size_t)s * B + b) * D + 4 * l) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-    if (l == 0) norm[(size_t)s * B + b] = nrm;
+  const int rows = pk.hi ? pk.Bp : B;
+  for (int b = blockIdx.x * G + threadIdx.x / LANES; b < rows; b += gridDim.x * G) {
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < B) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)idx[b] * D + 4 * l);
+      const float nrm = sqrtf(group_sum<LANES>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
+      const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+      y = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+      *reinterpret_cast<float4*>(zhat + ((size_t)s * B + b) * D + 4 * l) = y;
+      if (l == 0) norm[(size_t)s * B + b] = nrm;
+    }
+    if (pk.hi) {
+      const float f[4] = {y.x, y.y, y.z, y.w};
+      __bf16 h[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)f[j];
+        lo[j] = (__bf16)(f[j] - (float)h[j]);
+      }
+      const size_t o = ((size_t)s * pk.Bp + b) * D + 4 * l;
+      *reinterpret_cast<bf16x4*>(pk.hi + o) = bf16x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<bf16x4*>(pk.lo + o) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t ot = ((size_t)s * D + 4 * l + j) * pk.Bp + b;
+        pk.hiT[ot] = h[j];
+        pk.loT[ot] = lo[j];
+      }
+    }
   }
 }
 
@@ -154,6 +189,156 @@ __global__ void infonce_bwd_kernel(const float* __restrict__ zhat, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// InfoNCE on the matrix cores (D % 32 == 0).  One wave owns 32 "own" rows and walks the other view in tiles of 32.
+// The logit tile is computed TRANSPOSED (rows = other index in the 16 accumulator registers, column = own index on
+// the lane), so the softmax statistics of an own row are lane-local, and the probability tile, converted to bf16 in
+// place, is directly the A operand (X^T B form) of the MFMA that accumulates d(own) = sum_k P[k][own] * other[k][:] --
+// no LDS, no cross-lane traffic.  PREC = 3 adds the hi*lo + lo*hi products (operands split as hi + lo bf16).
+// ---------------------------------------------------------------------------------------------
+template <int D, int PREC>
+__device__ __forceinline__ f32x16 logits_tile(const __bf16* __restrict__ oth_hi, const __bf16* __restrict__ oth_lo, const bf16x8 (&own_h)[D / 16],
+                                              const bf16x8 (&own_l)[D / 16], int fh) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(oth_hi + ks * 16 + fh * 8);
+    if (PREC == 3) {
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(oth_lo + ks * 16 + fh * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, own_h[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, own_l[ks], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, own_h[ks], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int D, int PREC>
+__global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, TermTable T, int B, float* __restrict__ lse,
+                                                                float* __restrict__ row_loss) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+  const int t = blockIdx.y;
+  const int i0 = (blockIdx.x * 4 + wave) * 32;
+  if (i0 >= B) return;  // wave-uniform; the kernel has no workgroup barrier
+  const dmm_infonce_term term = T.t[t];
+  const int Bp = pk.Bp;
+  bf16x8 own_h[D / 16], own_l[D / 16];
+  {
+    const size_t o = ((size_t)term.a * Bp + i0 + fr) * D;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o + ks * 16 + fh * 8);
+      own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o + ks * 16 + fh * 8);
+    }
+  }
+  const float inv_t = 1.0f / term.temp;
+  const int i = i0 + fr;
+  float m = -INFINITY, ssum = 0.f, diag = 0.f;
+  for (int j0 = 0; j0 < B; j0 += 32) {
+    const size_t o = ((size_t)term.b * Bp + j0 + fr) * D;
+    const f32x16 acc = logits_tile<D, PREC>(pk.hi + o, pk.lo + o, own_h, own_l, fh);
+    float v[16], tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      v[r] = j < B ? acc[r] * inv_t : -INFINITY;
+      if (j == i) diag = v[r];
+      tmax = fmaxf(tmax, v[r]);
+    }
+    if (tmax > -INFINITY) {
+      const float mn = fmaxf(m, tmax);
+      float add = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) add += __expf(v[r] - mn);
+      ssum = ssum * __expf(m - mn) + add;
+      m = mn;
+    }
+  }
+  // the two lane halves hold disjoint column subsets of the same own row
+  const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64), d2 = __shfl_xor(diag, 32, 64);
+  const float M = fmaxf(m, m2);
+  const float L = (m > -INFINITY ? ssum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
+  if (fh == 0 && i < B) {
+    const float l = M + __logf(L);
+    lse[(size_t)t * B + i] = l;
+    row_loss[(size_t)t * B + i] = (l - (diag + d2)) * (term.weight / (float)B);
+  }
+}
+
+// blockIdx.z = 0: own = anchor view a (lse indexed by the own row); 1: own = view b (lse indexed by the other row)
+template <int D, int PREC>
+__global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
+                                                                float* __restrict__ dzhat) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+  const int t = blockIdx.y, pass = blockIdx.z;
+  const int o0 = (blockIdx.x * 4 + wave) * 32;
+  if (o0 >= B) return;
+  const dmm_infonce_term term = T.t[t];
+  const int own_slot = pass == 0 ? term.a : term.b, oth_slot = pass == 0 ? term.b : term.a;
+  const int Bp = pk.Bp;
+  bf16x8 own_h[D / 16], own_l[D / 16];
+  {
+    const size_t o = ((size_t)own_slot * Bp + o0 + fr) * D;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o + ks * 16 + fh * 8);
+      own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o + ks * 16 + fh * 8);
+    }
+  }
+  f32x16 out[D / 32];
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[cb][r] = 0.f;
+  const float inv_t = 1.0f / term.temp;
+  const float* __restrict__ ls = lse + (size_t)t * B;
+  const int oidx = o0 + fr;
+  const float lse_own = ls[oidx < B ? oidx : B - 1];
+  for (int k0 = 0; k0 < B; k0 += 32) {
+    const size_t o = ((size_t)oth_slot * Bp + k0 + fr) * D;
+    const f32x16 acc = logits_tile<D, PREC>(pk.hi + o, pk.lo + o, own_h, own_l, fh);
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kidx = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      const float l = pass == 0 ? lse_own : ls[kidx < B ? kidx : B - 1];
+      p[r] = kidx < B ? __expf(acc[r] * inv_t - l) - (kidx == oidx ? 1.f : 0.f) : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {  // k-step s of the output MFMA covers tile rows 16s .. 16s+15 (permuted, see header comment)
+      bf16x8 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ph[j] = (__bf16)p[8 * s + j];
+        if (PREC == 3) pl[j] = (__bf16)(p[8 * s + j] - (float)ph[j]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < D / 32; ++cb) {
+        const size_t ot = ((size_t)oth_slot * D + cb * 32 + fr) * Bp + k0 + 16 * s + 4 * fh;
+        const bf16x4 x0 = *reinterpret_cast<const bf16x4*>(pk.hiT + ot), x1 = *reinterpret_cast<const bf16x4*>(pk.hiT + ot + 8);
+        const bf16x8 bh = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        if (PREC == 3) {
+          const bf16x4 y0 = *reinterpret_cast<const bf16x4*>(pk.loT + ot), y1 = *reinterpret_cast<const bf16x4*>(pk.loT + ot + 8);
+          const bf16x8 bl = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, bh, out[cb], 0, 0, 0);
+          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bl, out[cb], 0, 0, 0);
+        }
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, out[cb], 0, 0, 0);
+      }
+    }
+  }
+  const float coef = term.weight * inv_t / (float)B;
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = o0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (row < B) atomicAdd(dzhat + ((size_t)own_slot * B + row) * D + cb * 32 + fr, out[cb][r] * coef);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // BPR forward + backward
 // ---------------------------------------------------------------------------------------------
 template <int D>
@@ -231,13 +416,32 @@ static bool d_ok(int D) { return D == 8 || D == 16 || D == 32 || D == 64 || D ==
 }  // namespace dmm
 using namespace dmm;
 
-extern "C" int dmm_gather_normalize(const dmm_gather_desc* slots, int n_slots, int B, int D, float* zhat, float* norm, void* stream) {
+static Bf16Pack make_pack(void* base, int n_slots, int B, int D) {
+  Bf16Pack pk = {nullptr, nullptr, nullptr, nullptr, (B + 31) & ~31};
+  if (base) {
+    const size_t n = (size_t)n_slots * pk.Bp * D;
+    pk.hi = (__bf16*)base;
+    pk.lo = pk.hi + n;
+    pk.hiT = pk.lo + n;
+    pk.loT = pk.hiT + n;
+  }
+  return pk;
+}
+static bool mfma_ok(int D) { return D == 32 || D == 64 || D == 128 || D == 256; }
+
+extern "C" int64_t dmm_infonce_pack_bytes(int n_slots, int B, int D) { return (int64_t)4 * n_slots * ((B + 31) & ~31) * D * 2; }
+
+extern "C" int dmm_gather_normalize(const dmm_gather_desc* slots, int n_slots, int B, int D, float* zhat, float* norm, void* bf16_pack,
+                                    void* stream) {
   SlotTable S;
   if (int e = fill_slots(slots, n_slots, S)) return e;
   DMM_CHECK_ARG(zhat && norm && B > 0 && d_ok(D), "dmm_gather_normalize: bad arguments (B=%d D=%d)", B, D);
+  DMM_CHECK_ARG(!bf16_pack || (((uintptr_t)bf16_pack & 15) == 0), "dmm_gather_normalize: bf16 pack must be 16-byte aligned");
+  const Bf16Pack pk = make_pack(bf16_pack, n_slots, B, D);
   const int G = 1024 / D;
-  dim3 grid(cdiv(B, G) > 1024 ? 1024 : cdiv(B, G), n_slots);
-  DISPATCH_D(D, hipLaunchKernelGGL(gather_normalize_kernel<DD>, grid, dim3(256), 0, (hipStream_t)stream, S, B, zhat, norm));
+  const int rows = bf16_pack ? pk.Bp : B;
+  dim3 grid(cdiv(rows, G) > 1024 ? 1024 : cdiv(rows, G), n_slots);
+  DISPATCH_D(D, hipLaunchKernelGGL(gather_normalize_kernel<DD>, grid, dim3(256), 0, (hipStream_t)stream, S, B, zhat, norm, pk));
   DMM_LAUNCH_CHECK("dmm_gather_normalize");
   return 0;
 }
@@ -261,11 +465,26 @@ static int infonce_waves(int B, int D, bool bwd) {
   return 0;
 }
 
-extern "C" int dmm_infonce_fwd(const float* zhat, const dmm_infonce_term* terms, int n_terms, int B, int D, float* lse, float* row_loss,
-                               void* stream) {
+#define DISPATCH_MFMA(D, PREC, KERNEL, ...)                                                                    \
+  switch (D) {                                                                                                 \
+    case 32: if (PREC == 3) hipLaunchKernelGGL((KERNEL<32, 3>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<32, 1>), __VA_ARGS__); break;     \
+    case 64: if (PREC == 3) hipLaunchKernelGGL((KERNEL<64, 3>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<64, 1>), __VA_ARGS__); break;     \
+    case 128: if (PREC == 3) hipLaunchKernelGGL((KERNEL<128, 3>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<128, 1>), __VA_ARGS__); break; \
+    case 256: if (PREC == 3) hipLaunchKernelGGL((KERNEL<256, 3>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<256, 1>), __VA_ARGS__); break; \
+  }
+
+extern "C" int dmm_infonce_fwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const dmm_infonce_term* terms, int n_terms,
+                               int B, int D, float* lse, float* row_loss, void* stream) {
   TermTable T;
   if (int e = fill_terms(terms, n_terms, T)) return e;
   DMM_CHECK_ARG(zhat && lse && row_loss && B > 0 && D % 4 == 0 && D > 0, "dmm_infonce_fwd: bad arguments");
+  if (bf16_pack && precision != 0 && mfma_ok(D)) {
+    DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_fwd: precision must be 0 (fp32 VALU), 1 or 3");
+    const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
+    DISPATCH_MFMA(D, precision, infonce_fwd_mfma_kernel, dim3(cdiv(B, 128), n_terms), dim3(256), 0, (hipStream_t)stream, pk, T, B, lse, row_loss);
+    DMM_LAUNCH_CHECK("dmm_infonce_fwd(mfma)");
+    return 0;
+  }
   const int w = infonce_waves(B, D, false);
   DMM_CHECK_ARG(w > 0, "dmm_infonce_fwd: D=%d too large", D);
   hipLaunchKernelGGL(infonce_fwd_kernel, dim3(cdiv(B, w), n_terms), dim3(64 * w), (size_t)w * D * sizeof(float), (hipStream_t)stream,
@@ -274,11 +493,18 @@ extern "C" int dmm_infonce_fwd(const float* zhat, const dmm_infonce_term* terms,
   return 0;
 }
 
-extern "C" int dmm_infonce_bwd(const float* zhat, const float* lse, const dmm_infonce_term* terms, int n_terms, int B, int D, float* dzhat,
-                               void* stream) {
+extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const float* lse,
+                               const dmm_infonce_term* terms, int n_terms, int B, int D, float* dzhat, void* stream) {
   TermTable T;
   if (int e = fill_terms(terms, n_terms, T)) return e;
   DMM_CHECK_ARG(zhat && lse && dzhat && B > 0 && D % 4 == 0 && D > 0, "dmm_infonce_bwd: bad arguments");
+  if (bf16_pack && precision != 0 && mfma_ok(D)) {
+    DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_bwd: precision must be 0 (fp32 VALU), 1 or 3");
+    const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
+    DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
+    DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma)");
+    return 0;
+  }
   const int w = infonce_waves(B, D, true);
   DMM_CHECK_ARG(w > 0, "dmm_infonce_bwd: batch %d too large for the v1 kernel (LDS row buffer)", B);
   hipLaunchKernelGGL(infonce_bwd_kernel, dim3(cdiv(B, w), n_terms, 2), dim3(64 * w), (size_t)w * ((D + B + 3) & ~3) * sizeof(float),

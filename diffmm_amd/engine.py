@@ -99,6 +99,8 @@ class JointEngine:
         self.zhat = z(self.n_slots, B_max, D)
         self.znorm = z(self.n_slots, B_max)
         self.dzhat = z(self.n_slots, B_max, D)
+        self.mfma_cl = D in (32, 64, 128, 256)  # MFMA InfoNCE kernels; smaller widths use the fp32 VALU kernels
+        self.pack = ops.infonce_pack(self.n_slots, B_max, D, self.dev) if self.mfma_cl else None
         pairs = M * (M - 1) // 2
         self.n_terms = 2 + (2 * pairs if self.hp["cl_method"] == 1 else 2 * M)
         self.lse = z(self.n_terms, B_max)
@@ -210,13 +212,14 @@ class JointEngine:
             dzhat = self.dzhat.view(-1)[: self.n_slots * B * D].view(self.n_slots, B, D)
         lse = self.lse.view(-1)[: nT * B].view(nT, B)
         row_loss = self.row_loss.view(-1)[: (nT + 1) * B].view(nT + 1, B)
-        ops.gather_normalize(slots, B, D, zhat, znorm)
-        ops.infonce_fwd(zhat, terms, nT, B, D, lse, row_loss)
+        pk = dict(pack=self.pack, n_slots=self.n_slots, precision=precision) if self.mfma_cl else {}
+        ops.gather_normalize(slots, B, D, zhat, znorm, self.pack)
+        ops.infonce_fwd(zhat, terms, nT, B, D, lse, row_loss, **pk)
         ops.bpr_fwd_bwd(self.Fin, users, pos, neg, U, row_loss[nT], self.dFin)
         ops.segment_sum(row_loss, nT + 1, B, 1.0, self.loss_parts)
         ops.sumsq(self.P.view("emb"), hp["reg"], self.loss_parts[nT + 1:], self.sumsq_scratch)
         # ---- backward ----
-        ops.infonce_bwd(zhat, lse, terms, nT, B, D, dzhat)
+        ops.infonce_bwd(zhat, lse, terms, nT, B, D, dzhat, **pk)
         ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
         A = self.adj
         s = 1.0 + hp["residual_weight"]

@@ -188,16 +188,25 @@ def make_terms(terms):  # list of (a, b, temp, weight)
     return arr
 
 
-def gather_normalize(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor) -> None:
-    L.check(L.lib().dmm_gather_normalize(slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.stream()), "dmm_gather_normalize")
+def infonce_pack(n_slots: int, B: int, D: int, device) -> Tensor:
+    """bf16 operand pack for the MFMA InfoNCE kernels (filled by gather_normalize)."""
+    return torch.zeros(int(L.lib().dmm_infonce_pack_bytes(n_slots, B, D)) // 2, dtype=torch.bfloat16, device=device)
 
 
-def infonce_fwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, row_loss: Tensor) -> None:
-    L.check(L.lib().dmm_infonce_fwd(L.ptr(zhat), terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.stream()), "dmm_infonce_fwd")
+def gather_normalize(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, pack: Optional[Tensor] = None) -> None:
+    L.check(L.lib().dmm_gather_normalize(slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(pack), L.stream()), "dmm_gather_normalize")
 
 
-def infonce_bwd(zhat: Tensor, lse: Tensor, terms, n_terms: int, B: int, D: int, dzhat: Tensor) -> None:
-    L.check(L.lib().dmm_infonce_bwd(L.ptr(zhat), L.ptr(lse), terms, n_terms, B, D, L.ptr(dzhat), L.stream()), "dmm_infonce_bwd")
+def infonce_fwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, row_loss: Tensor, pack: Optional[Tensor] = None,
+                n_slots: int = 0, precision: int = 0) -> None:
+    L.check(L.lib().dmm_infonce_fwd(L.ptr(zhat), L.ptr(pack), n_slots, precision, terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.stream()),
+            "dmm_infonce_fwd")
+
+
+def infonce_bwd(zhat: Tensor, lse: Tensor, terms, n_terms: int, B: int, D: int, dzhat: Tensor, pack: Optional[Tensor] = None,
+                n_slots: int = 0, precision: int = 0) -> None:
+    L.check(L.lib().dmm_infonce_bwd(L.ptr(zhat), L.ptr(pack), n_slots, precision, L.ptr(lse), terms, n_terms, B, D, L.ptr(dzhat), L.stream()),
+            "dmm_infonce_bwd")
 
 
 def scatter_normalize_bwd(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, dzhat: Tensor) -> None:

@@ -123,12 +123,18 @@ typedef struct dmm_infonce_term {
   int32_t a, b; /* slot ids */
   float temp, weight;
 } dmm_infonce_term;
+/* bf16_pack (optional, dmm_infonce_pack_bytes() bytes, 16-byte aligned): bf16 hi/lo copies of zhat, row-major and transposed,
+ * padded to 32 rows -- the operands of the MFMA InfoNCE kernels.  precision: 0 = fp32 VALU kernels (any D % 4 == 0),
+ * 1 = one bf16 MFMA product, 3 = hi/lo split (~fp32); the MFMA kernels need D in {32, 64, 128, 256} and the pack. */
+int64_t dmm_infonce_pack_bytes(int n_slots, int B, int D);
 int dmm_gather_normalize(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, float* zhat /*[n_slots,B,D]*/,
-                         float* norm /*[n_slots,B]*/, void* stream);
-int dmm_infonce_fwd(const float* zhat, const dmm_infonce_term* terms /*host*/, int n_terms, int B, int D,
-                    float* lse /*[n_terms,B]*/, float* row_loss /*[n_terms,B], weight/B folded in*/, void* stream);
-int dmm_infonce_bwd(const float* zhat, const float* lse, const dmm_infonce_term* terms /*host*/, int n_terms, int B, int D,
-                    float* dzhat /*[n_slots,B,D], accumulated*/, void* stream);
+                         float* norm /*[n_slots,B]*/, void* bf16_pack, void* stream);
+int dmm_infonce_fwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const dmm_infonce_term* terms /*host*/,
+                    int n_terms, int B, int D, float* lse /*[n_terms,B]*/, float* row_loss /*[n_terms,B], weight/B folded in*/,
+                    void* stream);
+int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const float* lse,
+                    const dmm_infonce_term* terms /*host*/, int n_terms, int B, int D, float* dzhat /*[n_slots,B,D], accumulated*/,
+                    void* stream);
 int dmm_scatter_normalize_bwd(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const float* zhat,
                               const float* norm, const float* dzhat, void* stream);
 /* BPR forward + backward in one pass: row_loss[b] = -log(1e-5 + sigmoid(u.p - u.n)) / B and, when dfin != NULL,
