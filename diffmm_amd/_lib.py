@@ -22,7 +22,7 @@ class SpmmProblem(C.Structure):
     _fields_ = [("tasks", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("x_lo", C.c_void_p), ("x_hi", C.c_void_p),
                 ("y", C.c_void_p), ("c1", C.c_void_p), ("c2", C.c_void_p), ("y_pert", C.c_void_p), ("noise", C.c_void_p),
                 ("y_mean", C.c_void_p), ("m1", C.c_void_p), ("m2", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
-                ("n_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
+                ("n_rows", C.c_int32), ("n_tasks", C.c_int32), ("n_head_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
                 ("noise_degree", C.c_float)]
 
 
@@ -31,6 +31,13 @@ class GemmArgs(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("alpha", C.c_float), ("e1", C.c_float), ("e2", C.c_float),
                 ("act", C.c_int32), ("split_k", C.c_int32), ("precision", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class GemmBf16Args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("Cb", C.c_void_p), ("ldcb", C.c_int64), ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("alpha", C.c_float), ("e1", C.c_float), ("e2", C.c_float),
+                ("act", C.c_int32)]
 
 
 class GatherDesc(C.Structure):
@@ -50,6 +57,9 @@ _SIGS = {
     "dmm_spmm_tasks_per_block": (C.c_int, [_I]),
     "dmm_spmm_csr_f32": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
     "dmm_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
+    "dmm_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmBf16Args), _P]),
+    "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
+    "dmm_temb_bf16": (C.c_int, [_I, _P, _P, _I, _P, _L, _I, _I, _P]),
     "dmm_rownorm_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "dmm_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "dmm_gcn_mix_fwd": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _L, _P]),
@@ -74,6 +84,7 @@ _SIGS = {
     "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P]),
     "dmm_topk_rows": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _P]),
+    "dmm_fill_zero": (C.c_int, [_P, _L, _P]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -101,6 +112,48 @@ def check(code: int, what: str = ""):
     if code != 0:
         msg = lib().dmm_last_error_string().decode(errors="replace")
         raise RuntimeError(f"libdiffmm_hip {what} failed with code {code}: {msg}")
+
+
+# ---- launch plans -----------------------------------------------------------------------------------
+# A training step is a fixed sequence of C calls on fixed HBM buffers.  Recording it once and replaying the prebuilt
+# (function, ctypes-arguments) list removes the Python-side argument marshalling from the steady state (the joint step
+# is ~45 launches of 5-15 us each, so per-launch host cost is first order).
+_recording: Optional[list] = None
+
+
+def call(name: str, *args) -> None:
+    """Launch (or, inside `Recorder`, only record) one C-ABI call."""
+    fn = getattr(lib(), name)
+    if _recording is not None:
+        _recording.append([fn, list(args), name])
+        return
+    rc = fn(*args)
+    if rc:
+        check(rc, name)
+
+
+class Recorder:
+    """`with Recorder() as plan:` -- calls made through `call()` are appended to `plan` instead of being launched."""
+
+    def __enter__(self):
+        global _recording
+        if _recording is not None:
+            raise RuntimeError("nested launch recording")
+        _recording = []
+        self.plan = _recording
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = None
+        return False
+
+
+def replay(plan) -> None:
+    for fn, args, name in plan:
+        rc = fn(*args)
+        if rc:
+            check(rc, name)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -376,8 +376,18 @@ extern "C" int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n,
 extern "C" int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, void* stream) {
   DMM_CHECK_ARG(x && out && rows > 0 && cols > 0, "dmm_colsum: bad arguments");
   const int chunk = rows > 64 ? 64 : rows;
-  hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+  (void)hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), cdiv(rows, chunk)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, chunk, out);
   DMM_LAUNCH_CHECK("dmm_colsum");
+  return 0;
+}
+
+extern "C" int dmm_fill_zero(void* p, int64_t bytes, void* stream) {
+  DMM_CHECK_ARG(p && bytes >= 0, "dmm_fill_zero: bad arguments");
+  hipError_t err = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  if (err != hipSuccess) {
+    dmm::set_error("dmm_fill_zero: %s", hipGetErrorString(err));
+    return (int)err;
+  }
   return 0;
 }

@@ -1,0 +1,250 @@
+// bf16 x bf16 -> fp32 NT GEMM for the reverse diffusion chain: C = post(act(alpha * A B^T + bias)).
+//   A [M, K] bf16 row-major (activations), B [N, K] bf16 row-major (nn.Linear weight layout), K % 8 == 0.
+// The chain (GaussianDiffusion.generate_view -> p_mean_variance -> Denoise.forward, Model.py:300-322,357-378,210-218) issues
+// two of these per timestep, user batch and modality: T * ceil(U/B) * M pairs per epoch -- the FLOP-dominant kernel of the
+// metric's T = 40 configuration.  Weights are cast to bf16 once per epoch, activations are produced in bf16 by the previous
+// GEMM's epilogue, so staging is a pure 16-byte copy:
+//   global_load_dwordx4 -> registers (issued one K tile ahead, in flight under the MFMAs) -> ds_write_b128 into the other
+//   LDS buffer -> one barrier per K tile (BK = 64: 16 / 8 MFMA 32x32x16 per wave between barriers).
+// LDS tiles are [rows][64 bf16] = 128-byte rows; 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7), which puts the
+// 16 rows of every ds_read_b128 lane group on 16 distinct slots of the 256-byte bank row (conflict-free fragment reads).
+// Epilogue per element: v = act(alpha*acc + bias[n]); v = e1*v + e2*R[m,n]; written as fp32 (C) and/or bf16 (Cb) -- the
+// posterior mean c1*pred + c2*x_t (Model.py:375) and the next step's bf16 operand come out of the same pass.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace dmm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmBf16P {
+  const __bf16* A; long long lda;
+  const __bf16* B; long long ldb;
+  float* C; long long ldc;
+  __bf16* Cb; long long ldcb;
+  const float* bias;
+  const float* R; long long ldr;
+  int M, N, K;
+  float alpha, e1, e2;
+  int act;
+};
+
+constexpr int GB_BM = 128, GB_BK = 64;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int ROWS>
+__device__ __forceinline__ void g_load(uint4 (&v)[ROWS / 32], const __bf16* __restrict__ base, long long ld, int row0, int rows, int k0, int K) {
+  const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int r = row0 + r0 + 32 * i, k = k0 + c * 8;
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (r < rows && k < K) x = *reinterpret_cast<const uint4*>(base + (long long)r * ld + k);
+    v[i] = x;
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void s_store(const uint4 (&v)[ROWS / 32], char* tile) {
+  const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) *reinterpret_cast<uint4*>(tile + swz(r0 + 32 * i, c)) = v[i];
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmBf16P P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BYTES = GB_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int WN = BN / 2;        // columns per wave
+  constexpr int NT = WN / 32;       // 32x32 tiles per wave along n (2 or 1)
+  const int m0 = blockIdx.y * GB_BM, n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int nk = (P.K + GB_BK - 1) / GB_BK;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[GB_BM / 32], rb[BN / 32];
+  g_load<GB_BM>(ra, P.A, P.lda, m0, P.M, 0, P.K);
+  g_load<BN>(rb, P.B, P.ldb, n0, P.N, 0, P.K);
+  s_store<GB_BM>(ra, smem);
+  s_store<BN>(rb, smem + A_BYTES);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* a_t = smem + cur * STAGE;
+    char* b_t = a_t + A_BYTES;
+    if (kt + 1 < nk) {  // next tile: global -> registers, in flight while this tile's MFMAs run
+      g_load<GB_BM>(ra, P.A, P.lda, m0, P.M, (kt + 1) * GB_BK, P.K);
+      g_load<BN>(rb, P.B, P.ldb, n0, P.N, (kt + 1) * GB_BK, P.K);
+    }
+#pragma unroll
+    for (int ks = 0; ks < GB_BK / 16; ++ks) {
+      const int chunk = ks * 2 + fh;
+      bf16x8 fa[2], fb[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a_t + swz(wm * 64 + i * 32 + fr, chunk));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b_t + swz(wn * WN + j * 32 + fr, chunk));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {  // the other buffer was last read before the previous barrier: safe to overwrite now
+      s_store<GB_BM>(ra, smem + (cur ^ 1) * STAGE);
+      s_store<BN>(rb, smem + (cur ^ 1) * STAGE + A_BYTES);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: transpose the wave's 64 x WN accumulator tile through LDS (the staging buffers are free after the last
+  // barrier) so that every lane then handles 4 consecutive columns: 16-byte residual loads and fp32 stores, 8-byte bf16 stores.
+  float* tile = reinterpret_cast<float*>(smem) + wave * 64 * WN;
+  constexpr int C4 = WN / 4;  // float4 chunks per tile row
+  const bool vec_ok = (!P.C || (P.ldc % 4 == 0 && ((uintptr_t)P.C & 15) == 0)) &&
+                      (!P.R || (P.ldr % 4 == 0 && ((uintptr_t)P.R & 15) == 0)) && (!P.Cb || (P.ldcb % 4 == 0 && ((uintptr_t)P.Cb & 7) == 0));
+  // residual rows are requested first so their HBM latency overlaps the LDS transpose below
+  float4 rr[C4];
+  if (P.R && vec_ok) {
+#pragma unroll
+    for (int it = 0; it < C4; ++it) {
+      const int idx = it * 64 + lane;
+      const int m = m0 + wm * 64 + idx / C4, n = n0 + wn * WN + (idx % C4) * 4;
+      rr[it] = (m < P.M && n + 3 < P.N) ? *reinterpret_cast<const float4*>(P.R + (long long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][r];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < C4; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / C4, c4 = idx % C4;
+    const int m = m0 + wm * 64 + row, n = n0 + wn * WN + c4 * 4;
+    if (m >= P.M || n >= P.N) continue;
+    const float4 a4 = *reinterpret_cast<const float4*>(tile + row * WN + c4 * 4);
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+    const int nv = min(4, P.N - n);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < nv) {
+        float x = P.alpha * v[u] + (P.bias ? P.bias[n + u] : 0.f);
+        if (P.act == DMM_ACT_TANH) x = tanhf(x);
+        else if (P.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+        v[u] = x;
+      }
+    }
+    if (nv == 4 && vec_ok) {
+      if (P.R) {
+        const float4 r4 = rr[it];
+        v[0] = P.e1 * v[0] + P.e2 * r4.x; v[1] = P.e1 * v[1] + P.e2 * r4.y; v[2] = P.e1 * v[2] + P.e2 * r4.z; v[3] = P.e1 * v[3] + P.e2 * r4.w;
+      }
+      if (P.C) *reinterpret_cast<float4*>(P.C + (long long)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (P.Cb) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4*>(P.Cb + (long long)m * P.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      }
+    } else {
+      for (int u = 0; u < nv; ++u) {
+        float x = v[u];
+        if (P.R) x = P.e1 * x + P.e2 * P.R[(long long)m * P.ldr + n + u];
+        if (P.C) P.C[(long long)m * P.ldc + n + u] = x;
+        if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)x;
+      }
+    }
+  }
+}
+
+// fp32 [rows, cols] (ld lds) -> bf16 (ld ldd); columns cols..cols_pad are zero-filled
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, long long lds, __bf16* __restrict__ dst, long long ldd,
+                                                         int rows, int cols, int cols_pad) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)rows * cols_pad; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+    dst[(long long)r * ldd + c] = c < cols ? (__bf16)src[(long long)r * lds + c] : (__bf16)0.f;
+  }
+}
+
+// time embedding of a single timestep (every row of the reverse chain shares it) -> bf16 columns I.. of xb, zero padded to ldx
+__global__ __launch_bounds__(256) void temb_bf16_kernel(int t, const float* __restrict__ w_emb, const float* __restrict__ b_emb, int te,
+                                                         __bf16* __restrict__ xb, long long ldx, int B, int I) {
+  __shared__ float e[32], o[32];
+  if (threadIdx.x < te) {
+    const int k = threadIdx.x, half = te / 2;
+    float v = 0.f;
+    if (!((te & 1) && k == te - 1)) {
+      const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
+      const float ang = (float)t * f;
+      v = k < half ? cosf(ang) : sinf(ang);
+    }
+    e[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < te) {
+    float v = b_emb[threadIdx.x];
+    for (int k = 0; k < te; ++k) v = fmaf(w_emb[threadIdx.x * te + k], e[k], v);
+    o[threadIdx.x] = v;
+  }
+  __syncthreads();
+  const int width = (int)(ldx - I);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)B * width; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / width), c = (int)(i % width);
+    xb[(long long)b * ldx + I + c] = c < te ? (__bf16)o[c] : (__bf16)0.f;
+  }
+}
+
+}  // namespace dmm
+using namespace dmm;
+
+extern "C" int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a, void* stream) {
+  DMM_CHECK_ARG(a && a->A && a->B && (a->C || a->Cb), "dmm_gemm_bf16_nt: null operand");
+  DMM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0, "dmm_gemm_bf16_nt: K=%d must be a positive multiple of 8", a->K);
+  DMM_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0,
+                "dmm_gemm_bf16_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  GemmBf16P P;
+  P.A = (const __bf16*)a->A; P.lda = a->lda; P.B = (const __bf16*)a->B; P.ldb = a->ldb;
+  P.C = a->C; P.ldc = a->ldc; P.Cb = (__bf16*)a->Cb; P.ldcb = a->ldcb;
+  P.bias = a->bias; P.R = a->R; P.ldr = a->ldr; P.M = a->M; P.N = a->N; P.K = a->K;
+  P.alpha = a->alpha; P.e1 = a->e1; P.e2 = a->e2; P.act = a->act;
+  const long long tiles128 = (long long)cdiv(a->M, GB_BM) * cdiv(a->N, 128);
+  hipStream_t s = (hipStream_t)stream;
+  static const int force_bn = [] { const char* e = getenv("DMM_GEMM_BN"); return e ? atoi(e) : 0; }();  // tuning knob
+  if ((tiles128 >= 512 && force_bn != 64) || force_bn == 128) {  // enough 128x128 tiles for two workgroups per CU
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<128>, dim3(cdiv(a->N, 128), cdiv(a->M, GB_BM)), dim3(256), 2 * (GB_BM + 128) * 128, s, P);
+  } else {
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<64>, dim3(cdiv(a->N, 64), cdiv(a->M, GB_BM)), dim3(256), 2 * (GB_BM + 64) * 128, s, P);
+  }
+  DMM_LAUNCH_CHECK("dmm_gemm_bf16_nt");
+  return 0;
+}
+
+extern "C" int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream) {
+  DMM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols_pad >= cols && ldd >= cols_pad, "dmm_cast_bf16: bad arguments");
+  const long long n = (long long)rows * cols_pad;
+  const unsigned grid = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)lds, (__bf16*)dst, (long long)ldd, rows, cols, cols_pad);
+  DMM_LAUNCH_CHECK("dmm_cast_bf16");
+  return 0;
+}
+
+extern "C" int dmm_temb_bf16(int t, const float* w_emb, const float* b_emb, int te, void* xb, int64_t ldx, int B, int I, void* stream) {
+  DMM_CHECK_ARG(w_emb && b_emb && xb && te >= 2 && te <= 32 && ldx >= I + te && B > 0, "dmm_temb_bf16: bad arguments");
+  const long long n = (long long)B * (ldx - I);
+  hipLaunchKernelGGL(temb_bf16_kernel, dim3((unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, w_emb,
+                     b_emb, te, (__bf16*)xb, (long long)ldx, B, I);
+  DMM_LAUNCH_CHECK("dmm_temb_bf16");
+  return 0;
+}

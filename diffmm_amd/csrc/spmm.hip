@@ -20,6 +20,8 @@
 //   y_pert = y + sign(y) * normalize_row(noise[row]) * noise_degree      (Main.py:320-321; noise read from a
 //            buffer for parity tests, or drawn in-kernel with Philox when noise == nullptr)
 //   y_mean = (y_pert + m1[row] + m2[row]) / 3                             (Main.py:325, mean of the 3 CL layers)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmm {
@@ -28,6 +30,7 @@ struct SpmmBatch {
   dmm_spmm_problem p[DMM_SPMM_MAX_BATCH];
   int block_begin[DMM_SPMM_MAX_BATCH + 1];
   int n;
+  int remap;
 };
 
 template <int D>
@@ -43,7 +46,9 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
     if (i < batch.n && (int)blockIdx.x >= batch.block_begin[i]) pi = i;
   const dmm_spmm_problem& P = batch.p[pi];
   const int nblk = batch.block_begin[pi + 1] - batch.block_begin[pi];
-  const int lb = xcd_remap((int)blockIdx.x - batch.block_begin[pi], nblk);
+  const int head = P.n_head_tasks / G;  // workgroups of split heavy rows: spread over the XCDs by the dispatcher itself
+  int lb = (int)blockIdx.x - batch.block_begin[pi];
+  if (batch.remap && lb >= head) lb = head + xcd_remap(lb - head, nblk - head);
 
   const int g = threadIdx.x / LANES;
   const int l = threadIdx.x % LANES;
@@ -58,39 +63,40 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
     const float* __restrict__ xlo = P.x_lo;
     const float* __restrict__ xhi = P.x_hi;
     const int split = P.split;
-    int p = beg;
-    // 4 independent gathers in flight per lane
-    for (; p + 4 <= end; p += 4) {
-      int c[4];
-      float v[4];
-      float4 x[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        c[j] = col[p + j];
-        v[j] = val[p + j];
+    // The group's lanes fetch LANES (column, value) pairs with one coalesced load each, then every pair is broadcast
+    // inside the group (ds_bpermute) and 8 independent X-row gathers are kept in flight per lane: a 32-non-zero task costs
+    // ~5 dependent memory round trips instead of 16.
+    for (int base = beg; base < end; base += LANES) {
+      const int cnt = min(LANES, end - base);
+      int myc = 0;
+      float myv = 0.f;
+      if (l < cnt) {
+        myc = col[base + l];
+        myv = val[base + l];
       }
+      for (int j0 = 0; j0 < cnt; j0 += 8) {
+        float4 x[8];
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* src = c[j] < split ? xlo + (size_t)c[j] * D : xhi + (size_t)(c[j] - split) * D;
-        x[j] = *reinterpret_cast<const float4*>(src + 4 * l);
-      }
+        for (int j = 0; j < 8; ++j) {
+          const int c = __shfl(myc, j0 + j, LANES);
+          v[j] = __shfl(myv, j0 + j, LANES);
+          x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j0 + j < cnt) {
+            const float* src = c < split ? xlo + (size_t)c * D : xhi + (size_t)(c - split) * D;
+            x[j] = *reinterpret_cast<const float4*>(src + 4 * l);
+          } else {
+            v[j] = 0.f;
+          }
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc.x = fmaf(v[j], x[j].x, acc.x);
-        acc.y = fmaf(v[j], x[j].y, acc.y);
-        acc.z = fmaf(v[j], x[j].z, acc.z);
-        acc.w = fmaf(v[j], x[j].w, acc.w);
+        for (int j = 0; j < 8; ++j) {
+          acc.x = fmaf(v[j], x[j].x, acc.x);
+          acc.y = fmaf(v[j], x[j].y, acc.y);
+          acc.z = fmaf(v[j], x[j].z, acc.z);
+          acc.w = fmaf(v[j], x[j].w, acc.w);
+        }
       }
-    }
-    for (; p < end; ++p) {
-      const int c = col[p];
-      const float v = val[p];
-      const float* src = c < split ? xlo + (size_t)c * D : xhi + (size_t)(c - split) * D;
-      const float4 x = *reinterpret_cast<const float4*>(src + 4 * l);
-      acc.x = fmaf(v, x.x, acc.x);
-      acc.y = fmaf(v, x.y, acc.y);
-      acc.z = fmaf(v, x.z, acc.z);
-      acc.w = fmaf(v, x.w, acc.w);
     }
   }
   // combine the tasks of a split row in task order (deterministic)
@@ -159,11 +165,18 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
   dmm::SpmmBatch b;
   memset(&b, 0, sizeof(b));
   b.n = n_probs;
+  {
+    // XCD-contiguous placement only pays when the gathered operand exceeds the on-die caches (measured: no effect on the
+    // 4 MB TikTok operand, where every XCD's L2 + the Infinity Cache hold all of X); DMM_SPMM_REMAP=0/1 overrides.
+    const char* e = getenv("DMM_SPMM_REMAP");
+    b.remap = e ? (e[0] == '1') : -1;
+  }
   int blocks = 0;
   for (int i = 0; i < n_probs; ++i) {
     const dmm_spmm_problem& p = probs[i];
     DMM_CHECK_ARG(p.tasks && p.col && p.val && p.x_lo, "dmm_spmm_csr_f32: problem %d has a null operand", i);
     DMM_CHECK_ARG(p.n_tasks > 0 && p.n_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: n_tasks=%d is not a multiple of %d", i, p.n_tasks, G);
+    DMM_CHECK_ARG(p.n_head_tasks >= 0 && p.n_head_tasks <= p.n_tasks && p.n_head_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: bad n_head_tasks", i);
     DMM_CHECK_ARG(p.y || p.y_pert, "dmm_spmm_csr_f32: problem %d has no output", i);
     DMM_CHECK_ARG(!p.y_mean || (p.y_pert && p.m1 && p.m2), "dmm_spmm_csr_f32: problem %d: y_mean needs y_pert, m1, m2", i);
     DMM_CHECK_ARG(p.x_hi || p.split >= (1 << 30), "dmm_spmm_csr_f32: problem %d: x_hi missing", i);
@@ -172,6 +185,11 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
     blocks += p.n_tasks / G;
   }
   for (int i = n_probs; i <= DMM_SPMM_MAX_BATCH; ++i) b.block_begin[i] = blocks;
+  if (b.remap < 0) {
+    long long max_rows = 0;
+    for (int i = 0; i < n_probs; ++i) max_rows = max_rows > probs[i].n_rows ? max_rows : probs[i].n_rows;
+    b.remap = max_rows * D * 4 > (256ll << 20);
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 8: return dmm::launch<8>(b, blocks, s);

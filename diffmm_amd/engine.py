@@ -111,6 +111,10 @@ class JointEngine:
         self.modal_adj: List[Adjacency] = []
         self.rng_step = 0
         self.world, self.rank = 1, 0  # data-parallel replicas (gradient all-reduce over RCCL) when world > 1
+        zi = lambda: torch.zeros(B_max, dtype=torch.int32, device=self.dev)
+        self.users_s, self.pos_s, self.neg_s = zi(), zi(), zi()  # static index buffers of the recorded launch plans
+        self._plans: Dict[tuple, dict] = {}
+        self._philox_refs: Optional[list] = None
 
     # -- parameters as the reference names them -------------------------------------------------
     @property
@@ -151,20 +155,27 @@ class JointEngine:
         lanes = self.D // 4
         seed, base = hp.get("seed", 1818), self.rng_step * 3 * self.N * lanes
         nz = lambda k: dict(noise=noise[k]) if noise is not None else dict(noise=None, seed=seed, offset=base + k * self.N * lanes)
+        refs = self._philox_refs  # when recording a plan: remember where the Philox offsets live
         batch = [ops.SpmmOp(self.modal_adj[m], self.u_embs, y=self.Z[m], x_hi=self.nf[m], split=self.U) for m in range(self.M)]
         if with_cl:
             batch.append(ops.SpmmOp(A, emb, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **nz(0)))
         else:
             batch.append(ops.SpmmOp(A, emb, y=self.Bx))
-        ops.spmm_batched(batch)
+        arr = ops.spmm_batched(batch)
+        if refs is not None and with_cl:
+            refs.append((arr, len(batch) - 1, 0))
         ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx)
         s = 1.0 + hp["residual_weight"]
         batch = [ops.SpmmOp(A, self.Mx, y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
         if with_cl:
             batch.append(ops.SpmmOp(A, self.X1p, y_pert=self.X2p, noise_degree=nd, **nz(1)))
-        ops.spmm_batched(batch)
+        arr = ops.spmm_batched(batch)
+        if refs is not None and with_cl:
+            refs.append((arr, 1, 1))
         if with_cl:
-            ops.spmm_batched([ops.SpmmOp(A, self.X2p, y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **nz(2))])
+            arr = ops.spmm_batched([ops.SpmmOp(A, self.X2p, y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **nz(2))])
+            if refs is not None:
+                refs.append((arr, 0, 2))
 
     def gcn_output(self) -> Dict[str, Tensor]:
         U = self.U
@@ -200,8 +211,10 @@ class JointEngine:
         (weights folded in); no host synchronisation happens here."""
         B, D, U, N, M, hp = int(users.shape[0]), self.D, self.U, self.N, self.M, self.hp
         assert B <= self.B_max
-        self.gblock.zero_()
-        self.dzhat.zero_()
+        if noise is None and update and self._philox_refs is None:
+            return self._step_planned(users, pos, neg, precision, n_contrib)
+        ops.zero_(self.gblock)
+        ops.zero_(self.dzhat)
         self.forward(noise=noise, with_cl=True, precision=precision)
         slots, terms = self._slots_terms(users, pos)
         nT = self.n_terms
@@ -234,13 +247,54 @@ class JointEngine:
         for m, n in enumerate(modality_names(M)):
             ops.rownorm_bwd(self.T[m][U:], self.nf[m], self.fnorm[m], self.dfeat[m])
             gw = self.P.g(f"{n}_layer.weight")
-            gw.zero_()
+            ops.zero_(gw)
             ops.gemm(self.dfeat[m], self.feats[m], out=gw, trans_a=True, precision=precision, split_k=16)
             ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"))
         if update:
             if self.world > 1:
                 self.allreduce_grads(contributing=True, n_contrib=n_contrib)
             self.apply_adam(fold_extras=self.world == 1)
+        self.rng_step += 1
+        return self.loss_parts
+
+    # -- steady state: the step as a recorded launch plan ------------------------------------------------
+    def _step_planned(self, users: Tensor, pos: Tensor, neg: Tensor, precision: int, n_contrib: Optional[int]) -> Tensor:
+        """Same launches as step(), replayed from a plan recorded once per (batch size, graph set): no per-launch Python
+        marshalling.  Per step only the batch indices (copied into static buffers), the Philox offsets and Adam's (lr, step)
+        change."""
+        B = int(users.shape[0])
+        key = (B, precision, id(self.adj), tuple(id(a) for a in self.modal_adj), self.world)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            self._philox_refs = []
+            try:
+                with L.Recorder() as calls:
+                    # recorded with update=False when gradients are exchanged between replicas (the all-reduce is not a C-ABI call)
+                    self.step(self.users_s[:B], self.pos_s[:B], self.neg_s[:B], noise=None, precision=precision, update=False)
+                    if self.world == 1:
+                        self.apply_adam(fold_extras=True)
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] == "dmm_adam_step"])
+            finally:
+                self._philox_refs = None
+            self.rng_step -= 1  # recording ran step()'s bookkeeping once without launching anything
+            if self.world == 1:
+                self.P.step -= 1
+            self._plans[key] = plan
+        self.users_s[:B].copy_(users); self.pos_s[:B].copy_(pos); self.neg_s[:B].copy_(neg)
+        lanes = self.D // 4
+        base = self.rng_step * 3 * self.N * lanes
+        for arr, i, k in plan["philox"]:
+            arr[i].offset = base + k * self.N * lanes
+        if self.world == 1:
+            self.P.step += 1
+            for c in plan["adam"]:
+                c[1][9], c[1][13] = self.lr, self.P.step
+        L.replay(plan["calls"])
+        if self.world > 1:
+            self.allreduce_grads(contributing=True, n_contrib=n_contrib)
+            self.apply_adam(fold_extras=False)
         self.rng_step += 1
         return self.loss_parts
 
@@ -334,6 +388,11 @@ class DiffusionEngine:
         self.dum, self.dpg, self.dgate, self.dproj = z(B_max, D), z(B_max, D), z(B_max, D), z(B_max, D)
         self.dh, self.dpre = z(B_max, H), z(B_max, H)
         self.xa, self.xb = z(B_max, Kp), z(B_max, Kp)  # ping-pong buffers of the reverse chain
+        zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
+        self.xa16, self.xb16, self.h16 = zb(B_max, Kp), zb(B_max, Kp), zb(B_max, H)  # bf16 operands of the chain's GEMMs
+        self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
+        self.w16_step = [-1] * M  # Adam step the bf16 weight copies were taken at
+        self._chain_plans: Dict[tuple, list] = {}
         self.rng_step = 0
         self.world, self.rank = 1, 0
 
@@ -459,8 +518,38 @@ class DiffusionEngine:
             self.reduce_and_step(m, contributing=False, n_contrib=n_contrib)
 
     # -- reverse chain (generate_view, Model.py:300-322) ------------------------------------------------
+    def _refresh_bf16_weights(self, m: int):
+        P = self.P[m]
+        if self.w16_step[m] != P.step or P.step == 0:
+            ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
+            ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+            self.w16_step[m] = P.step
+
+    def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
+        """Reverse chain on the dedicated bf16 NT GEMM: bf16 weights / activations as MFMA operands, fp32 accumulation, the
+        running x_t kept in fp32 for the posterior-mean residual and the final top-k."""
+        B, I, P, Kp = x0.shape[0], self.I, self.P[m], self.Kp
+        self._refresh_bf16_weights(m)
+        self.xa[:B, :I].copy_(x0)
+        plan = self._chain_plans.get((m, B))
+        if plan is None:  # 3 T + 1 launches on static buffers: record once, replay for every user batch and epoch
+            with L.Recorder() as plan:
+                cur, nxt, cur16, nxt16, h16 = self.xa[:B], self.xb[:B], self.xa16[:B], self.xb16[:B], self.h16[:B]
+                ops.cast_bf16(cur, cur16, cols=I, cols_pad=I)
+                w_emb, b_emb, b1, b2 = P.view("emb_layer.weight"), P.view("emb_layer.bias"), P.view("in_layers.0.bias"), P.view("out_layers.0.bias")
+                for i in range(self.T - 1, -1, -1):
+                    ops.temb_bf16(i, w_emb, b_emb, cur16, I)
+                    ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=b1, act=L.ACT_TANH)
+                    ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
+                    cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
+            self._chain_plans[(m, B)] = plan
+        L.replay(plan)
+        return (self.xa if self.T % 2 == 0 else self.xb)[:B, :I]
+
     def generate_view(self, m: int, x0: Tensor, precision: int = 1) -> Tensor:
         """sampling_step == 0 path: x_T = x0, then T deterministic posterior-mean steps.  Returns a [B, I] view (ld = Kp)."""
+        if precision == 1:
+            return self.generate_view_bf16(m, x0)
         B, I, P = x0.shape[0], self.I, self.P[m]
         cur, nxt = self.xa[:B], self.xb[:B]
         cur[:, :I].copy_(x0)

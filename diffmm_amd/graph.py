@@ -42,7 +42,7 @@ def normalized_bipartite_csr(rows: np.ndarray, cols: np.ndarray, users: int, ite
     return rowptr.astype(np.int32), dst.astype(np.int32), val
 
 
-def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32) -> np.ndarray:
+def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False):
     """Work list for dmm_spmm_csr_f32: int32 [T, 4] rows of (row, nz_begin, nz_end, run_pos << 16 | run_len).
 
     A workgroup of the kernel holds G = 1024 / D task groups.  Rows with at most `task_len` non-zeros are one
@@ -95,9 +95,12 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32) -> np.ndarray:
         if pad:
             t = np.concatenate([t, np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int64), (pad, 1))])
         parts.append(t)
+    head = int(parts[0].shape[0]) if multi.size else 0  # tasks of the split (heavy) rows come first
     if not parts:
-        return np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int32), (G, 1))
-    return np.ascontiguousarray(np.concatenate(parts).astype(np.int32))
+        out = np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int32), (G, 1))
+    else:
+        out = np.ascontiguousarray(np.concatenate(parts).astype(np.int32))
+    return (out, head) if return_head else out
 
 
 def check_plan(rowptr: np.ndarray, tasks: np.ndarray, D: int) -> None:
@@ -134,6 +137,7 @@ class Adjacency:
     col: torch.Tensor  # int32 [nnz]
     val: torch.Tensor  # fp32 [nnz]
     tasks: torch.Tensor  # int32 [T, 4]
+    n_head_tasks: int = 0  # leading tasks that belong to split rows
     host: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
 
     @property
@@ -152,11 +156,11 @@ def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D
 
 
 def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, keep_host: bool = False) -> Adjacency:
-    tasks = plan_tasks(rowptr, D, task_len)
+    tasks, head = plan_tasks(rowptr, D, task_len, return_head=True)
     check_plan(rowptr, tasks, D)
     assert col.size == 0 or (col.min() >= 0 and col.max() < rowptr.shape[0] - 1), "column id out of range"
     dev = torch.device(device)
     return Adjacency(n=int(rowptr.shape[0] - 1), nnz=int(col.shape[0]), D=D,
                      rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
-                     val=torch.from_numpy(val).to(dev), tasks=torch.from_numpy(tasks).to(dev),
+                     val=torch.from_numpy(val).to(dev), tasks=torch.from_numpy(tasks).to(dev), n_head_tasks=head,
                      host=(rowptr, col, val) if keep_host else None)

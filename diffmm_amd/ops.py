@@ -62,16 +62,19 @@ class SpmmOp:
         p.alpha, p.beta, p.gamma = alpha, beta, gamma
         p.y_pert, p.noise, p.noise_degree, p.seed, p.offset = L.ptr(y_pert), L.ptr(noise), noise_degree, seed, offset
         p.y_mean, p.m1, p.m2 = L.ptr(y_mean), L.ptr(m1), L.ptr(m2)
+        p.n_rows = adj.n
         p.n_tasks = adj.n_tasks
+        p.n_head_tasks = adj.n_head_tasks
         self.p, self.D = p, D
 
 
-def spmm_batched(ops: Sequence[SpmmOp]) -> None:
+def spmm_batched(ops: Sequence[SpmmOp]):
     if not 1 <= len(ops) <= L.SPMM_MAX_BATCH:
         raise ValueError("1..4 problems per launch")
     D = ops[0].D
     arr = (L.SpmmProblem * len(ops))(*[o.p for o in ops])
-    L.check(L.lib().dmm_spmm_csr_f32(arr, len(ops), D, L.stream()), "dmm_spmm_csr_f32")
+    L.call("dmm_spmm_csr_f32", arr, len(ops), D, L.stream())
+    return arr  # the launch's argument block (plans patch the Philox offsets in place)
 
 
 def spmm(adj: Adjacency, x: Tensor, y: Optional[Tensor] = None, **kw) -> Tensor:
@@ -121,8 +124,53 @@ def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = 
     g.M, g.N, g.K = m, n, k
     g.alpha, g.e1, g.e2, g.act = alpha, e1, e2, act
     g.split_k, g.precision, g.accumulate = split_k, precision, int(accumulate)
-    L.check(L.lib().dmm_gemm(C.byref(g), L.stream()), "dmm_gemm")
+    L.call("dmm_gemm", C.byref(g), L.stream())
     return out
+
+
+def gemm_bf16_nt(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, *, bias: Optional[Tensor] = None,
+                 act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
+                 N: Optional[int] = None, K: Optional[int] = None) -> None:
+    """out[M,N] (fp32) and/or out_bf16 = post(act(alpha * A B^T + bias)); A [M,K], B [N,K] bf16, row-strided views allowed."""
+    for nm, t in (("A", A), ("B", B)):
+        if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm_bf16_nt {nm}: need a 2-D bfloat16 tensor with unit inner stride")
+    m, k = A.shape[0], (A.shape[1] if K is None else K)
+    n = B.shape[0] if N is None else N
+    if k > A.shape[1] or k > B.shape[1] or n > B.shape[0]:
+        raise ValueError("gemm_bf16_nt: shape mismatch")
+    g = L.GemmBf16Args()
+    g.A, g.lda, g.B, g.ldb = L.ptr(A), A.stride(0), L.ptr(B), B.stride(0)
+    if out is not None:
+        if out.dtype != torch.float32 or out.stride(1) != 1 or out.shape[0] < m or out.shape[1] < n:
+            raise ValueError("gemm_bf16_nt out: bad shape / dtype / stride")
+        g.C, g.ldc = L.ptr(out), out.stride(0)
+    if out_bf16 is not None:
+        if out_bf16.dtype != torch.bfloat16 or out_bf16.stride(1) != 1 or out_bf16.shape[0] < m or out_bf16.shape[1] < n:
+            raise ValueError("gemm_bf16_nt out_bf16: bad shape / dtype / stride")
+        g.Cb, g.ldcb = L.ptr(out_bf16), out_bf16.stride(0)
+    if bias is not None:
+        if bias.numel() < n:
+            raise ValueError("gemm_bf16_nt bias too short")
+        g.bias = L.ptr(_f32c(bias, "bias"))
+    if residual is not None:
+        if residual.dtype != torch.float32 or residual.stride(1) != 1 or residual.shape[0] < m or residual.shape[1] < n:
+            raise ValueError("gemm_bf16_nt residual: bad shape / dtype / stride")
+        g.R, g.ldr = L.ptr(residual), residual.stride(0)
+    g.M, g.N, g.K, g.alpha, g.e1, g.e2, g.act = m, n, k, alpha, e1, e2, act
+    L.call("dmm_gemm_bf16_nt", C.byref(g), L.stream())
+
+
+def cast_bf16(src: Tensor, dst: Tensor, cols: Optional[int] = None, cols_pad: Optional[int] = None) -> None:
+    cols = src.shape[1] if cols is None else cols
+    cols_pad = cols if cols_pad is None else cols_pad
+    if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] < src.shape[0]:
+        raise ValueError("cast_bf16: bad operands")
+    L.call("dmm_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), src.shape[0], cols, cols_pad, L.stream())
+
+
+def temb_bf16(t: int, w_emb: Tensor, b_emb: Tensor, xb: Tensor, I: int) -> None:
+    L.call("dmm_temb_bf16", int(t), L.ptr(w_emb), L.ptr(b_emb), w_emb.shape[0], L.ptr(xb), xb.stride(0), xb.shape[0], I, L.stream())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -132,14 +180,14 @@ def rownorm_fwd(x: Tensor, y: Optional[Tensor] = None, norm: Optional[Tensor] = 
     _f32c(x, "x")
     y = torch.empty_like(x) if y is None else _f32c(y, "y")
     norm = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if norm is None else norm
-    L.check(L.lib().dmm_rownorm_fwd(L.ptr(x), L.ptr(y), L.ptr(norm), x.shape[0], x.shape[1], L.stream()), "dmm_rownorm_fwd")
+    L.call("dmm_rownorm_fwd", L.ptr(x), L.ptr(y), L.ptr(norm), x.shape[0], x.shape[1], L.stream())
     return y, norm
 
 
 def rownorm_bwd(dy: Tensor, y: Tensor, norm: Tensor, dx: Optional[Tensor] = None) -> Tensor:
     dx = torch.empty_like(dy) if dx is None else dx
-    L.check(L.lib().dmm_rownorm_bwd(L.ptr(_f32c(dy, "dy")), L.ptr(_f32c(y, "y")), L.ptr(norm), L.ptr(_f32c(dx, "dx")), dy.shape[0], dy.shape[1],
-                                    L.stream()), "dmm_rownorm_bwd")
+    L.call("dmm_rownorm_bwd", L.ptr(_f32c(dy, "dy")), L.ptr(_f32c(y, "y")), L.ptr(norm), L.ptr(_f32c(dx, "dx")), dy.shape[0], dy.shape[1],
+                                    L.stream())
     return dx
 
 
@@ -149,8 +197,7 @@ def _ptr_array(ts: Sequence[Tensor]):
 
 def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, mx: Optional[Tensor] = None) -> Tensor:
     mx = torch.empty_like(bx) if mx is None else mx
-    L.check(L.lib().dmm_gcn_mix_fwd(L.ptr(_f32c(bx, "bx")), _ptr_array(z), L.ptr(w_logits), len(z), maw, L.ptr(mx), bx.numel(), L.stream()),
-            "dmm_gcn_mix_fwd")
+    L.call("dmm_gcn_mix_fwd", L.ptr(_f32c(bx, "bx")), _ptr_array(z), L.ptr(w_logits), len(z), maw, L.ptr(mx), bx.numel(), L.stream())
     return mx
 
 
@@ -161,8 +208,8 @@ def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tenso
     dw = torch.empty(len(z), dtype=torch.float32, device=dmx.device) if dw is None else dw
     if partials is None:
         partials = torch.empty(int(L.lib().dmm_gcn_mix_partials(n)), dtype=torch.float32, device=dmx.device)
-    L.check(L.lib().dmm_gcn_mix_bwd(L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
-                                    L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, L.stream()), "dmm_gcn_mix_bwd")
+    L.call("dmm_gcn_mix_bwd", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
+                                    L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, L.stream())
     return dbx, dw
 
 
@@ -194,41 +241,38 @@ def infonce_pack(n_slots: int, B: int, D: int, device) -> Tensor:
 
 
 def gather_normalize(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, pack: Optional[Tensor] = None) -> None:
-    L.check(L.lib().dmm_gather_normalize(slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(pack), L.stream()), "dmm_gather_normalize")
+    L.call("dmm_gather_normalize", slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(pack), L.stream())
 
 
 def infonce_fwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, row_loss: Tensor, pack: Optional[Tensor] = None,
                 n_slots: int = 0, precision: int = 0) -> None:
-    L.check(L.lib().dmm_infonce_fwd(L.ptr(zhat), L.ptr(pack), n_slots, precision, terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.stream()),
-            "dmm_infonce_fwd")
+    L.call("dmm_infonce_fwd", L.ptr(zhat), L.ptr(pack), n_slots, precision, terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.stream())
 
 
 def infonce_bwd(zhat: Tensor, lse: Tensor, terms, n_terms: int, B: int, D: int, dzhat: Tensor, pack: Optional[Tensor] = None,
                 n_slots: int = 0, precision: int = 0) -> None:
-    L.check(L.lib().dmm_infonce_bwd(L.ptr(zhat), L.ptr(pack), n_slots, precision, L.ptr(lse), terms, n_terms, B, D, L.ptr(dzhat), L.stream()),
-            "dmm_infonce_bwd")
+    L.call("dmm_infonce_bwd", L.ptr(zhat), L.ptr(pack), n_slots, precision, L.ptr(lse), terms, n_terms, B, D, L.ptr(dzhat), L.stream())
 
 
 def scatter_normalize_bwd(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, dzhat: Tensor) -> None:
-    L.check(L.lib().dmm_scatter_normalize_bwd(slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(dzhat), L.stream()),
-            "dmm_scatter_normalize_bwd")
+    L.call("dmm_scatter_normalize_bwd", slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(dzhat), L.stream())
 
 
 def bpr_fwd_bwd(fin: Tensor, users: Tensor, pos: Tensor, neg: Tensor, U: int, row_loss: Tensor, dfin: Optional[Tensor]) -> None:
     B, D = users.shape[0], fin.shape[1]
-    L.check(L.lib().dmm_bpr_fwd_bwd(L.ptr(_f32c(fin, "fin")), L.ptr(_i32c(users, "users")), L.ptr(_i32c(pos, "pos")), L.ptr(_i32c(neg, "neg")),
-                                    B, D, U, L.ptr(row_loss), L.ptr(dfin), L.stream()), "dmm_bpr_fwd_bwd")
+    L.call("dmm_bpr_fwd_bwd", L.ptr(_f32c(fin, "fin")), L.ptr(_i32c(users, "users")), L.ptr(_i32c(pos, "pos")), L.ptr(_i32c(neg, "neg")),
+                                    B, D, U, L.ptr(row_loss), L.ptr(dfin), L.stream())
 
 
 def segment_sum(x: Tensor, n_seg: int, seg_len: int, scale: float, out: Tensor) -> None:
-    L.check(L.lib().dmm_segment_sum(L.ptr(x), n_seg, seg_len, scale, L.ptr(out), L.stream()), "dmm_segment_sum")
+    L.call("dmm_segment_sum", L.ptr(x), n_seg, seg_len, scale, L.ptr(out), L.stream())
 
 
 def sumsq(x: Tensor, scale: float, out: Tensor, scratch: Optional[Tensor] = None) -> None:
     n = x.numel()
     if scratch is None:
         scratch = torch.empty(int(L.lib().dmm_sumsq_scratch(n)), dtype=torch.float32, device=x.device)
-    L.check(L.lib().dmm_sumsq(L.ptr(x), n, scale, L.ptr(scratch), L.ptr(out), L.stream()), "dmm_sumsq")
+    L.call("dmm_sumsq", L.ptr(x), n, scale, L.ptr(scratch), L.ptr(out), L.stream())
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, extra: Sequence[Tensor] = (), extra_n: Sequence[int] = (),
@@ -238,8 +282,7 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, 
         raise ValueError("adam: size mismatch")
     ex = (C.c_void_p * max(1, len(extra)))(*[L.ptr(t) for t in extra]) if extra else (C.c_void_p * 1)()
     en = (C.c_int64 * max(1, len(extra)))(*extra_n) if extra else (C.c_int64 * 1)()
-    L.check(L.lib().dmm_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream()),
-            "dmm_adam_step")
+    L.call("dmm_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -249,33 +292,40 @@ def qsample_temb(x0: Optional[Tensor], noise: Optional[Tensor], t: Tensor, sqrt_
                  w_emb: Tensor, b_emb: Tensor, xcat: Tensor, I: int, draw_noise: bool = False, seed: int = 0, offset: int = 0,
                  eps_out: Optional[Tensor] = None) -> None:
     B, te = t.shape[0], w_emb.shape[0]
-    L.check(L.lib().dmm_qsample_temb(L.ptr(x0), x0.stride(0) if x0 is not None else 0, L.ptr(noise), L.ptr(_i32c(t, "t")), L.ptr(sqrt_ac),
+    L.call("dmm_qsample_temb", L.ptr(x0), x0.stride(0) if x0 is not None else 0, L.ptr(noise), L.ptr(_i32c(t, "t")), L.ptr(sqrt_ac),
                                      L.ptr(sqrt_1mac), L.ptr(w_emb), L.ptr(b_emb), te, L.ptr(xcat), xcat.stride(0), B, I, int(draw_noise), seed,
-                                     offset, L.ptr(eps_out), L.stream()), "dmm_qsample_temb")
+                                     offset, L.ptr(eps_out), L.stream())
 
 
 def temb_bwd(t: Tensor, dxcat: Tensor, I: int, te: int, dw: Tensor, db: Tensor) -> None:
-    L.check(L.lib().dmm_temb_bwd(L.ptr(t), L.ptr(dxcat), dxcat.stride(0), I, te, t.shape[0], L.ptr(dw), L.ptr(db), L.stream()), "dmm_temb_bwd")
+    L.call("dmm_temb_bwd", L.ptr(t), L.ptr(dxcat), dxcat.stride(0), I, te, t.shape[0], L.ptr(dw), L.ptr(db), L.stream())
 
 
 def mul(a: Tensor, b: Tensor, out: Tensor) -> None:
-    L.check(L.lib().dmm_mul_sigmoid_fwd(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream()), "dmm_mul_sigmoid_fwd")
+    L.call("dmm_mul_sigmoid_fwd", L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream())
 
 
 def gate_bwd(dout: Tensor, proj: Tensor, gate: Tensor, dproj: Tensor, dpre: Tensor) -> None:
-    L.check(L.lib().dmm_gate_bwd(L.ptr(dout), L.ptr(proj), L.ptr(gate), L.ptr(dproj), L.ptr(dpre), dout.numel(), L.stream()), "dmm_gate_bwd")
+    L.call("dmm_gate_bwd", L.ptr(dout), L.ptr(proj), L.ptr(gate), L.ptr(dproj), L.ptr(dpre), dout.numel(), L.stream())
+
+
+def zero_(t: Tensor) -> None:
+    """hipMemsetAsync on the current stream (recordable, unlike Tensor.zero_())."""
+    if not t.is_contiguous():
+        raise ValueError("zero_: contiguous tensors only")
+    L.call("dmm_fill_zero", L.ptr(t), t.numel() * t.element_size(), L.stream())
 
 
 def tanh_bwd(dh: Tensor, h: Tensor, dpre: Tensor) -> None:
-    L.check(L.lib().dmm_tanh_bwd(L.ptr(dh), L.ptr(h), L.ptr(dpre), dh.numel(), L.stream()), "dmm_tanh_bwd")
+    L.call("dmm_tanh_bwd", L.ptr(dh), L.ptr(h), L.ptr(dpre), dh.numel(), L.stream())
 
 
 def add_inplace(y: Tensor, x: Tensor, alpha: float = 1.0) -> None:
-    L.check(L.lib().dmm_add_inplace(L.ptr(y), L.ptr(x), alpha, y.numel(), L.stream()), "dmm_add_inplace")
+    L.call("dmm_add_inplace", L.ptr(y), L.ptr(x), alpha, y.numel(), L.stream())
 
 
 def colsum(x: Tensor, rows: int, cols: int, out: Tensor) -> None:
-    L.check(L.lib().dmm_colsum(L.ptr(x), x.stride(0), rows, cols, L.ptr(out), L.stream()), "dmm_colsum")
+    L.call("dmm_colsum", L.ptr(x), x.stride(0), rows, cols, L.ptr(out), L.stream())
 
 
 def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, gscale: float,
@@ -285,10 +335,10 @@ def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int
         raise ValueError("diff_loss: out, x0 and dout must share one leading dimension")
     if w.dtype != torch.float64 or loss.dtype != torch.float64:
         raise ValueError("diff_loss: w and loss are float64")
-    L.check(L.lib().dmm_diff_loss(L.ptr(out), L.ptr(x0), out.stride(0), L.ptr(w), L.ptr(um), L.ptr(ui), B, I, d, sim_weight, reg_term, gscale,
-                                  L.ptr(loss), L.ptr(dout), L.ptr(dum), L.stream()), "dmm_diff_loss")
+    L.call("dmm_diff_loss", L.ptr(out), L.ptr(x0), out.stride(0), L.ptr(w), L.ptr(um), L.ptr(ui), B, I, d, sim_weight, reg_term, gscale,
+                                  L.ptr(loss), L.ptr(dout), L.ptr(dum), L.stream())
 
 
 def topk_rows(x: Tensor, row_ids: Tensor, out_ptr: Tensor, out_idx: Tensor, cols: int) -> None:
-    L.check(L.lib().dmm_topk_rows(L.ptr(x), x.stride(0), L.ptr(_i32c(row_ids, "row_ids")), L.ptr(_i32c(out_ptr, "out_ptr")), L.ptr(out_idx),
-                                  row_ids.shape[0], cols, L.stream()), "dmm_topk_rows")
+    L.call("dmm_topk_rows", L.ptr(x), x.stride(0), L.ptr(_i32c(row_ids, "row_ids")), L.ptr(_i32c(out_ptr, "out_ptr")), L.ptr(out_idx),
+                                  row_ids.shape[0], cols, L.stream())

@@ -37,7 +37,9 @@ const char* dmm_last_error_string(void);
  *   y_mean = (y_pert + m1[row] + m2[row]) / 3
  * X row r is read from x_lo[r] when r < split, else x_hi[r - split] (lets [u_embs ; feats] stay two tensors).
  * `tasks` is the int4 work list {row, nz_begin, nz_end, run_pos<<16 | run_len} produced by the planner
- * (diffmm_amd/graph.py: plan_tasks); n_tasks must be a multiple of dmm_spmm_tasks_per_block(D).
+ * (diffmm_amd/graph.py: plan_tasks); n_tasks must be a multiple of dmm_spmm_tasks_per_block(D).  The planner puts the
+ * tasks of split (heavy) rows first: those n_head_tasks keep the hardware's round-robin workgroup->XCD dispatch (they hold
+ * most of the non-zeros and must be spread), the single-task tail is remapped so each XCD walks a contiguous row range.
  * noise == NULL with y_pert != NULL draws uniform noise in-kernel: Philox4x32-10(seed, offset + row*D/4 + lane). */
 typedef struct dmm_spmm_problem {
   const void* tasks;
@@ -55,7 +57,9 @@ typedef struct dmm_spmm_problem {
   const float* m2;
   uint64_t seed;
   uint64_t offset;
+  int32_t n_rows;  /* rows of the adjacency (sizes the XCD-placement heuristic) */
   int32_t n_tasks;
+  int32_t n_head_tasks; /* leading tasks (split heavy rows, multiple of tasks_per_block) dispatched round-robin over the XCDs */
   int32_t split;
   float alpha, beta, gamma;
   float noise_degree;
@@ -89,6 +93,25 @@ typedef struct dmm_gemm_args {
   int32_t accumulate; /* 1: C += result (plain read-modify-write, split_k == 1) */
 } dmm_gemm_args;
 int dmm_gemm(const dmm_gemm_args* a /*host*/, void* stream);
+
+/* bf16 NT GEMM of the reverse diffusion chain (GaussianDiffusion.generate_view, Model.py:300-322: T x Denoise.forward +
+ * posterior mean): A [M,K] and B [N,K] are bf16 row-major with K % 8 == 0; outputs fp32 (C) and/or bf16 (Cb); same epilogue
+ * as dmm_gemm.  dmm_cast_bf16 makes the bf16 copies (weights once per epoch, x_0 once per chain); dmm_temb_bf16 writes the
+ * time embedding of one timestep (all rows of a chain step share it) into columns I.. of the bf16 operand. */
+typedef struct dmm_gemm_bf16_args {
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  float* C; int64_t ldc;
+  void* Cb; int64_t ldcb;
+  const float* bias;
+  const float* R; int64_t ldr;
+  int32_t M, N, K;
+  float alpha, e1, e2;
+  int32_t act;
+} dmm_gemm_bf16_args;
+int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a /*host*/, void* stream);
+int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
+int dmm_temb_bf16(int t, const float* w_emb, const float* b_emb, int te, void* xb, int64_t ldx, int B, int I, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Row L2 normalisation, F.normalize(x, p=2, dim=1, eps=1e-12): Model.py:89,92,104; Utils.py:72.
@@ -177,6 +200,7 @@ int dmm_gate_bwd(const float* dout, const float* proj, const float* gate, float*
                  float* dgate_pre /*out: dout*proj*gate*(1-gate)*/, int64_t n, void* stream);
 int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* stream); /* dpre = dh * (1 - h^2) */
 int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n, void* stream);   /* y += alpha * x */
+int dmm_fill_zero(void* p, int64_t bytes, void* stream);                                /* hipMemsetAsync(p, 0, bytes) */
 int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out /*[cols], overwritten*/, void* stream);
 /* Diffusion loss, Model.py:407-425.  per row b: mse_b = mean_j (out - x0)^2; cos_b = cosine(um_b, ui_b);
  * loss_b = w_b * mse_b + sim_weight * (1 - cos_b) + reg_term  (float64 out, like the reference).

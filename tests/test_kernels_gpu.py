@@ -150,6 +150,28 @@ def test_gemm_layouts(dev, M, N, K, prec):
     close(acc, ref + R.double(), what="accumulate", **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 200, 328), (384, 1024, 704), (130, 70, 64), (1024, 6710, 1024), (512, 1024, 6720)])
+def test_gemm_bf16_nt(dev, M, N, K):
+    """Dedicated bf16 NT kernel (reverse chain): operands exactly representable in bf16, so only fp32 summation order differs."""
+    from diffmm_amd import ops, _lib as L
+    rng = np.random.default_rng(M * 7 + N)
+    A = T(rng.standard_normal((M, K)).astype(np.float32)).bfloat16(); Bw = T(rng.standard_normal((N, K)).astype(np.float32)).bfloat16()
+    bias = T(rng.standard_normal(N).astype(np.float32)); R = T(rng.standard_normal((M, N)).astype(np.float32))
+    ref = A.double() @ Bw.double().t()
+    ld = (N + 7) & ~7
+    out, out16 = torch.zeros(M, ld, device=dev), torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16_nt(A.to(dev), Bw.to(dev), out=out, out_bf16=out16, N=N)
+    close(out[:, :N], ref, rtol=1e-5, atol=1e-4 * np.sqrt(K / 64), what="plain")
+    close(out16[:, :N].float(), ref, rtol=1e-2, atol=1e-2 * np.sqrt(K), what="bf16 copy")
+    assert float(out[:, N:].abs().max() if ld > N else 0.0) == 0.0, "columns beyond N must stay untouched"
+    ops.gemm_bf16_nt(A.to(dev), Bw.to(dev), out=out, bias=bias.to(dev), act=L.ACT_TANH, alpha=0.05, residual=R.to(dev), e1=0.3, e2=0.9, N=N)
+    close(out[:, :N], 0.3 * torch.tanh(0.05 * ref + bias.double()) + 0.9 * R.double(), rtol=1e-5, atol=2e-5, what="epilogue")
+    # asymmetric integer data: catches any transposed / permuted fragment or swizzle mistake exactly
+    Ai = (torch.arange(M * K).view(M, K) % 13 - 6).float().bfloat16(); Bi = (torch.arange(N * K).view(N, K) % 7 - 3).float().bfloat16()
+    ops.gemm_bf16_nt(Ai.to(dev), Bi.to(dev), out=out, N=N)
+    assert torch.equal(out[:, :N].cpu().double(), Ai.double() @ Bi.double().t()), "integer GEMM must be exact"
+
+
 def test_gemm_asymmetric_identity_and_strided_views(dev):
     from diffmm_amd import ops
     n = 96
@@ -352,6 +374,9 @@ def test_denoise_and_diffusion_loss_vs_reference(dev, name):
     scale = float(np.abs(z["nogate/out"]).max())
     assert float((got.cpu() - T(z["nogate/out"])).abs().max()) < 3e-2 * scale, "bf16 single-product mode within 3 % of the output scale"
     close(E.generate_view(0, x0, precision=3), z["genview/out"], rtol=2e-4, atol=5e-5, what="generate_view")
+    gv = E.generate_view(0, x0, precision=1).cpu()  # dedicated bf16 chain
+    gscale = float(np.abs(z["genview/out"]).max())
+    assert float((gv - T(z["genview/out"])).abs().max()) < 3e-2 * gscale, "bf16 reverse chain within 3 % of the output scale"
     # training_losses with the recorded draws: value and every gradient
     means = E.train_step(x0, [feat], ie, t=[t], noise=[noise], precision=3, update=False)
     close(E.act[0]["loss"][:B], z["tl/loss"], rtol=1e-4, atol=1e-7, what="training_losses")
