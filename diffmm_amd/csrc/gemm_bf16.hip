@@ -178,6 +178,26 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+// fp32 [R, C] (ld lds) -> bf16 [C, Rp] (ld ldd): tiled transpose through LDS; destination columns R..Rp are zero-filled so the
+// result can be the K-contiguous operand of the NT GEMM with K = Rp (a multiple of 8)
+__global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ src, long long lds, __bf16* __restrict__ dst,
+                                                                   long long ldd, int R, int C, int Rp) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < R && c < C) ? src[(long long)r * lds + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < C && r < Rp) dst[(long long)c * ldd + r] = (__bf16)tile[tx][ty + 4 * i];
+  }
+}
+
 // time embedding of a single timestep (every row of the reverse chain shares it) -> bf16 columns I.. of xb, zero padded to ldx
 __global__ __launch_bounds__(256) void temb_bf16_kernel(int t, const float* __restrict__ w_emb, const float* __restrict__ b_emb, int te,
                                                          __bf16* __restrict__ xb, long long ldx, int B, int I) {
@@ -237,6 +257,14 @@ extern "C" int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t l
   const unsigned grid = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)lds, (__bf16*)dst, (long long)ldd, rows, cols, cols_pad);
   DMM_LAUNCH_CHECK("dmm_cast_bf16");
+  return 0;
+}
+
+extern "C" int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream) {
+  DMM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows_pad >= rows && ldd >= rows_pad, "dmm_transpose_cast_bf16: bad arguments");
+  hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3(cdiv(cols, 64), cdiv(rows_pad, 64)), dim3(256), 0, (hipStream_t)stream, src, (long long)lds,
+                     (__bf16*)dst, (long long)ldd, rows, cols, rows_pad);
+  DMM_LAUNCH_CHECK("dmm_transpose_cast_bf16");
   return 0;
 }
 

@@ -25,8 +25,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// bf16 operand packs for the MFMA InfoNCE kernels, all [n_slots][...] with Bp = B rounded up to 32 (pad rows zero):
-//   hi [s][Bp][D], lo [s][Bp][D] (lo = bf16(x - hi)), hiT [s][D][Bp], loT [s][D][Bp]
+// bf16 operand packs for the MFMA InfoNCE kernels (Bp = B rounded up to 32, pad rows zero, lo = bf16(x - hi)).  Both are stored
+// in MFMA-fragment order so that every operand load of a wave is ONE contiguous 512-byte access (32 lanes x 16 bytes per half):
+//   hi/lo  [slot][row tile = b/32][ks = c/16][h][r = b%32][8]   element e <-> column 16 ks + 8 h + e      (A/B operand, k = column)
+//   hiT/loT[slot][row tile = b/32][s][h][c][8]                  element e <-> row 32 tile + 16 s + 8 (e>>2) + 4 h + (e&3)
+//                                                               (B operand of the X^T B product, k = batch row in accumulator order)
 struct Bf16Pack {
   __bf16 *hi, *lo, *hiT, *loT;
   int Bp;
@@ -59,12 +62,16 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(SlotTable S, int 
         h[j] = (__bf16)f[j];
         lo[j] = (__bf16)(f[j] - (float)h[j]);
       }
-      const size_t o = ((size_t)s * pk.Bp + b) * D + 4 * l;
+      const int tile = b >> 5, r = b & 31, c0 = 4 * l;
+      // row-fragment order: columns c0..c0+3 share (ks, h) and are 4 consecutive elements
+      const size_t o = ((((size_t)s * (pk.Bp >> 5) + tile) * (D / 16) + (c0 >> 4)) * 2 + ((c0 >> 3) & 1)) * 32 * 8 + (size_t)r * 8 + (c0 & 7);
       *reinterpret_cast<bf16x4*>(pk.hi + o) = bf16x4{h[0], h[1], h[2], h[3]};
       *reinterpret_cast<bf16x4*>(pk.lo + o) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+      // k-packed transposed order
+      const int r4 = r & 15, ss = r >> 4, hh = (r4 >> 2) & 1, e = ((r4 >> 3) << 2) | (r4 & 3);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const size_t ot = ((size_t)s * D + 4 * l + j) * pk.Bp + b;
+        const size_t ot = (((((size_t)s * (pk.Bp >> 5) + tile) * 2 + ss) * 2 + hh) * D + c0 + j) * 8 + e;
         pk.hiT[ot] = h[j];
         pk.loT[ot] = lo[j];
       }
@@ -195,17 +202,24 @@ __global__ void infonce_bwd_kernel(const float* __restrict__ zhat, const float* 
 // place, is directly the A operand (X^T B form) of the MFMA that accumulates d(own) = sum_k P[k][own] * other[k][:] --
 // no LDS, no cross-lane traffic.  PREC = 3 adds the hi*lo + lo*hi products (operands split as hi + lo bf16).
 // ---------------------------------------------------------------------------------------------
+// fragment (ks, h) of row r of a 32-row tile in the row-fragment order
+template <int D>
+__device__ __forceinline__ size_t frag_off(int slot, int tiles, int tile, int ks, int h, int r) {
+  return ((((size_t)slot * tiles + tile) * (D / 16) + ks) * 2 + h) * 256 + (size_t)r * 8;
+}
+
 template <int D, int PREC>
-__device__ __forceinline__ f32x16 logits_tile(const __bf16* __restrict__ oth_hi, const __bf16* __restrict__ oth_lo, const bf16x8 (&own_h)[D / 16],
-                                              const bf16x8 (&own_l)[D / 16], int fh) {
+__device__ __forceinline__ f32x16 logits_tile(const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, int slot, int tiles, int tile,
+                                              const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16], int fr, int fh) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < D / 16; ++ks) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(oth_hi + ks * 16 + fh * 8);
+    const size_t o = frag_off<D>(slot, tiles, tile, ks, fh, fr);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(hi + o);
     if (PREC == 3) {
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(oth_lo + ks * 16 + fh * 8);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(lo + o);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, own_h[ks], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, own_l[ks], acc, 0, 0, 0);
     }
@@ -223,21 +237,49 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
   if (i0 >= B) return;  // wave-uniform; the kernel has no workgroup barrier
   const dmm_infonce_term term = T.t[t];
   const int Bp = pk.Bp;
+  const int tiles = Bp >> 5;
   bf16x8 own_h[D / 16], own_l[D / 16];
-  {
-    const size_t o = ((size_t)term.a * Bp + i0 + fr) * D;
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-      own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o + ks * 16 + fh * 8);
-      own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o + ks * 16 + fh * 8);
-    }
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const size_t o = frag_off<D>(term.a, tiles, i0 >> 5, ks, fh, fr);
+    own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+    own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
   }
   const float inv_t = 1.0f / term.temp;
   const int i = i0 + fr;
   float m = -INFINITY, ssum = 0.f, diag = 0.f;
+  bf16x8 ca[D / 16], cl[D / 16], na[D / 16], nl[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const size_t o = frag_off<D>(term.b, tiles, 0, ks, fh, fr);
+    ca[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+    if (PREC == 3) cl[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
+  }
   for (int j0 = 0; j0 < B; j0 += 32) {
-    const size_t o = ((size_t)term.b * Bp + j0 + fr) * D;
-    const f32x16 acc = logits_tile<D, PREC>(pk.hi + o, pk.lo + o, own_h, own_l, fh);
+    if (j0 + 32 < B) {  // next tile's operand: in flight under this tile's math
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const size_t o = frag_off<D>(term.b, tiles, (j0 >> 5) + 1, ks, fh, fr);
+        na[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+        if (PREC == 3) nl[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      if (PREC == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[ks], own_h[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[ks], own_l[ks], acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[ks], own_h[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      ca[ks] = na[ks];
+      if (PREC == 3) cl[ks] = nl[ks];
+    }
     float v[16], tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -266,25 +308,55 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
   }
 }
 
-// blockIdx.z = 0: own = anchor view a (lse indexed by the own row); 1: own = view b (lse indexed by the other row)
+// blockIdx.z = 2 * slice + pass.  pass 0: own = anchor view a (lse indexed by the own row); pass 1: own = view b (lse indexed by
+// the other row).  The walk over the other view is cut into KSPLIT slices handled by different waves (the probabilities only
+// need the precomputed lse, and the output is accumulated with atomics anyway): 4x more waves in flight hides the L2 latency of
+// the per-tile operand loads, which are also issued one tile ahead.
+constexpr int INFONCE_KSPLIT = 4;
+
+template <int D, int PREC>
+struct OthFrags {
+  bf16x8 a_h[D / 16], a_l[D / 16];        // logit-tile A operand (row-fragment order)
+  bf16x8 t_h[2][D / 32], t_l[2][D / 32];  // output-product B operand (k-packed transposed order)
+};
+
+template <int D, int PREC>
+__device__ __forceinline__ void load_oth(OthFrags<D, PREC>& f, const Bf16Pack& pk, int slot, int tiles, int tile, int fr, int fh) {
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const size_t o = frag_off<D>(slot, tiles, tile, ks, fh, fr);
+    f.a_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+    if (PREC == 3) f.a_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb) {
+      const size_t ot = (((((size_t)slot * tiles + tile) * 2 + s) * 2 + fh) * D + cb * 32 + fr) * 8;
+      f.t_h[s][cb] = *reinterpret_cast<const bf16x8*>(pk.hiT + ot);
+      if (PREC == 3) f.t_l[s][cb] = *reinterpret_cast<const bf16x8*>(pk.loT + ot);
+    }
+}
+
 template <int D, int PREC>
 __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
                                                                 float* __restrict__ dzhat) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
-  const int t = blockIdx.y, pass = blockIdx.z;
+  const int t = blockIdx.y, pass = blockIdx.z & 1, slice = blockIdx.z >> 1;
   const int o0 = (blockIdx.x * 4 + wave) * 32;
   if (o0 >= B) return;
   const dmm_infonce_term term = T.t[t];
   const int own_slot = pass == 0 ? term.a : term.b, oth_slot = pass == 0 ? term.b : term.a;
-  const int Bp = pk.Bp;
+  const int tiles = pk.Bp >> 5;
+  const int per = (tiles + INFONCE_KSPLIT - 1) / INFONCE_KSPLIT;
+  const int kt0 = slice * per, kt1 = min(tiles, kt0 + per);
+  if (kt0 >= kt1) return;
   bf16x8 own_h[D / 16], own_l[D / 16];
-  {
-    const size_t o = ((size_t)own_slot * Bp + o0 + fr) * D;
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-      own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o + ks * 16 + fh * 8);
-      own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o + ks * 16 + fh * 8);
-    }
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const size_t o = frag_off<D>(own_slot, tiles, o0 >> 5, ks, fh, fr);
+    own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+    own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
   }
   f32x16 out[D / 32];
 #pragma unroll
@@ -295,9 +367,22 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
   const float* __restrict__ ls = lse + (size_t)t * B;
   const int oidx = o0 + fr;
   const float lse_own = ls[oidx < B ? oidx : B - 1];
-  for (int k0 = 0; k0 < B; k0 += 32) {
-    const size_t o = ((size_t)oth_slot * Bp + k0 + fr) * D;
-    const f32x16 acc = logits_tile<D, PREC>(pk.hi + o, pk.lo + o, own_h, own_l, fh);
+  OthFrags<D, PREC> cur, nxt;
+  load_oth<D, PREC>(cur, pk, oth_slot, tiles, kt0, fr, fh);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (kt + 1 < kt1) load_oth<D, PREC>(nxt, pk, oth_slot, tiles, kt + 1, fr, fh);  // in flight under this tile's math
+    const int k0 = kt * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      if (PREC == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a_l[ks], own_h[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a_h[ks], own_l[ks], acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a_h[ks], own_h[ks], acc, 0, 0, 0);
+    }
     float p[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -306,7 +391,7 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
       p[r] = kidx < B ? __expf(acc[r] * inv_t - l) - (kidx == oidx ? 1.f : 0.f) : 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {  // k-step s of the output MFMA covers tile rows 16s .. 16s+15 (permuted, see header comment)
+    for (int s = 0; s < 2; ++s) {  // k-step s of the output MFMA covers tile rows 16s .. 16s+15 in accumulator order
       bf16x8 ph, pl;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -315,18 +400,14 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
       }
 #pragma unroll
       for (int cb = 0; cb < D / 32; ++cb) {
-        const size_t ot = ((size_t)oth_slot * D + cb * 32 + fr) * Bp + k0 + 16 * s + 4 * fh;
-        const bf16x4 x0 = *reinterpret_cast<const bf16x4*>(pk.hiT + ot), x1 = *reinterpret_cast<const bf16x4*>(pk.hiT + ot + 8);
-        const bf16x8 bh = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         if (PREC == 3) {
-          const bf16x4 y0 = *reinterpret_cast<const bf16x4*>(pk.loT + ot), y1 = *reinterpret_cast<const bf16x4*>(pk.loT + ot + 8);
-          const bf16x8 bl = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, bh, out[cb], 0, 0, 0);
-          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bl, out[cb], 0, 0, 0);
+          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, cur.t_h[s][cb], out[cb], 0, 0, 0);
+          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, cur.t_l[s][cb], out[cb], 0, 0, 0);
         }
-        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, bh, out[cb], 0, 0, 0);
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, cur.t_h[s][cb], out[cb], 0, 0, 0);
       }
     }
+    if (kt + 1 < kt1) cur = nxt;
   }
   const float coef = term.weight * inv_t / (float)B;
 #pragma unroll
@@ -501,7 +582,7 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
   if (bf16_pack && precision != 0 && mfma_ok(D)) {
     DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_bwd: precision must be 0 (fp32 VALU), 1 or 3");
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
-    DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
+    DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2 * INFONCE_KSPLIT), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
     DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma)");
     return 0;
   }

@@ -393,6 +393,10 @@ class DiffusionEngine:
         self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
         self.w16_step = [-1] * M  # Adam step the bf16 weight copies were taken at
         self._chain_plans: Dict[tuple, list] = {}
+        Bp8 = (B_max + 7) & ~7
+        # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
+        self.dpre16, self.doutT16, self.hT16, self.dpreT16 = zb(B_max, H), zb(items, Bp8), zb(H, Bp8), zb(H, Bp8)
+        self.xcatT16, self.w1T16, self.w2T16 = zb(Kp, Bp8), zb(Kp, H), zb(H, Kp)
         self.rng_step = 0
         self.world, self.rank = 1, 0
 
@@ -415,6 +419,16 @@ class DiffusionEngine:
         return x0p
 
     # -- Denoise.forward on an operand buffer that already holds [x_t | temb | 0] ---------------------
+    def _mlp_train_bf16(self, m: int, xcat: Tensor, h: Tensor, out: Tensor):
+        """Training-time Denoise MLP on the bf16 NT kernel: operands are cast once, h is also kept in bf16 for the backward."""
+        P, B = self.P[m], xcat.shape[0]
+        ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
+        ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+        self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
+        ops.cast_bf16(xcat, self.xa16[:B])
+        ops.gemm_bf16_nt(self.xa16[:B], self.w1_16[m], out=h, out_bf16=self.h16[:B], bias=P.view("in_layers.0.bias"), act=L.ACT_TANH)
+        ops.gemm_bf16_nt(self.h16[:B], self.w2_16[m], out=out, bias=P.view("out_layers.0.bias"), N=self.I)
+
     def _mlp(self, m: int, xcat: Tensor, h: Tensor, out: Tensor, precision: int, post: Optional[Tuple[float, float, Tensor]] = None):
         P = self.P[m]
         B = xcat.shape[0]
@@ -440,7 +454,9 @@ class DiffusionEngine:
 
     def _gate_fwd(self, m: int, xcat: Tensor, feat: Tensor, precision: int):
         a, P, B, I = self.act[m], self.P[m], xcat.shape[0], self.I
-        ops.gemm(xcat, feat, out=a["proj"][:B], precision=precision, K=I)
+        if precision == 1:
+            ops.zero_(a["proj"][:B])
+        ops.gemm(xcat, feat, out=a["proj"][:B], precision=precision, K=I, split_k=8 if precision == 1 else 1)
         ops.gemm(a["proj"][:B], P.view("gate_layer.weight"), out=a["gate"][:B], trans_b=True, bias=P.view("gate_layer.bias"), act=L.ACT_SIGMOID,
                  precision=precision)
         ops.mul(a["proj"][:B], a["gate"][:B], a["pg"][:B])
@@ -455,10 +471,18 @@ class DiffusionEngine:
         ops.qsample_temb(x0p, noise, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, P.view("emb_layer.weight"), P.view("emb_layer.bias"), xcat, I,
                          draw_noise=noise is None, seed=self.hp.get("seed", 1818), offset=(self.rng_step * self.M + m) * self.B_max * ((I + 3) // 4))
         self._gate_fwd(m, xcat, feat, precision)
-        self._mlp(m, xcat, a["h"][:B], a["out"][:B], precision)
-        ops.gemm(a["out"][:B], feat, out=a["um"][:B], precision=precision, K=I)
+        if precision == 1:
+            self._mlp_train_bf16(m, xcat, a["h"][:B], a["out"][:B])
+        else:
+            self._mlp(m, xcat, a["h"][:B], a["out"][:B], precision)
+        sk = 8 if precision == 1 else 1  # skinny (N = d) products: split K so more than B/128 workgroups run
+        if sk > 1:
+            ops.zero_(a["um"][:B])
+        ops.gemm(a["out"][:B], feat, out=a["um"][:B], precision=precision, K=I, split_k=sk)
         if not ui_ready:
-            ops.gemm(x0p, i_embs, out=self.ui[:B], precision=precision, K=I)
+            if sk > 1:
+                ops.zero_(self.ui[:B])
+            ops.gemm(x0p, i_embs, out=self.ui[:B], precision=precision, K=I, split_k=sk)
         w = self.w_table[a["t"][:B].long()]
         a["w"] = w
         ops.diff_loss(a["out"][:B], x0p, w, a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
@@ -466,18 +490,39 @@ class DiffusionEngine:
     def loss_backward(self, m: int, x0p: Tensor, feat: Tensor, reg_term: float, gscale: float, precision: int):
         a, P, B, I, H, D, Kp = self.act[m], self.P[m], x0p.shape[0], self.I, self.H, self.D, self.Kp
         dout, dum = self.dout[:B], self.dum[:B]
-        P.grad.zero_()
+        ops.zero_(P.grad)
         ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], dout, dum)
         ops.gemm(dum, feat, out=dout, trans_b=True, precision=precision, N=I, accumulate=True)  # d(out F) -> dout += dum F^T
-        ops.gemm(dout, a["h"][:B], out=P.g("out_layers.0.weight"), trans_a=True, precision=precision, M=I)  # dW2 = dout^T h
-        ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
-        ops.gemm(dout, P.view("out_layers.0.weight"), out=self.dh[:B], precision=precision, K=I)  # dh = dout W2
-        ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
-        ops.gemm(self.dpre[:B], a["xcat"][:B], out=P.g("in_layers.0.weight"), trans_a=True, precision=precision)  # dW1 = dpre^T [x|temb]
-        ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
-        ops.gemm(self.dpre[:B], P.view("in_layers.0.weight"), out=self.dxcat[:B], precision=precision)  # d[x'|temb] = dpre W1
+        if precision == 1:
+            # every large product in NT form on the bf16 kernel; K-contiguous operands come from cast / transpose-cast passes
+            Bp8 = (B + 7) & ~7
+            ops.transpose_cast_bf16(dout, self.doutT16, rows=B, cols=I)            # dout^T  [I, B]
+            ops.transpose_cast_bf16(a["h"][:B], self.hT16, rows=B, cols=H)          # h^T     [H, B]
+            ops.gemm_bf16_nt(self.doutT16[:, :Bp8], self.hT16[:, :Bp8], out=P.g("out_layers.0.weight"), N=H, K=Bp8)  # dW2 = dout^T h
+            ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
+            ops.cast_bf16(dout, self.xb16[:B])                                       # dout (pad columns are zero)
+            ops.transpose_cast_bf16(P.view("out_layers.0.weight"), self.w2T16, rows=I, cols=H)  # W2^T [H, I -> Kp]
+            ops.gemm_bf16_nt(self.xb16[:B], self.w2T16, out=self.dh[:B], K=Kp)     # dh = dout W2
+            ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
+            ops.transpose_cast_bf16(self.dpre[:B], self.dpreT16, rows=B, cols=H)    # dpre^T  [H, B]
+            ops.transpose_cast_bf16(a["xcat"][:B], self.xcatT16, rows=B, cols=Kp)   # xcat^T  [Kp, B]
+            ops.gemm_bf16_nt(self.dpreT16[:, :Bp8], self.xcatT16[:, :Bp8], out=P.g("in_layers.0.weight"), K=Bp8)  # dW1 = dpre^T [x|temb]
+            ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
+            ops.cast_bf16(self.dpre[:B], self.dpre16[:B])
+            ops.transpose_cast_bf16(P.view("in_layers.0.weight"), self.w1T16, rows=H, cols=Kp)  # W1^T [Kp, H]
+            ops.gemm_bf16_nt(self.dpre16[:B], self.w1T16, out=self.dxcat[:B])       # d[x'|temb] = dpre W1
+        else:
+            ops.gemm(dout, a["h"][:B], out=P.g("out_layers.0.weight"), trans_a=True, precision=precision, M=I)  # dW2 = dout^T h
+            ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
+            ops.gemm(dout, P.view("out_layers.0.weight"), out=self.dh[:B], precision=precision, K=I)  # dh = dout W2
+            ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
+            ops.gemm(self.dpre[:B], a["xcat"][:B], out=P.g("in_layers.0.weight"), trans_a=True, precision=precision)  # dW1 = dpre^T [x|temb]
+            ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
+            ops.gemm(self.dpre[:B], P.view("in_layers.0.weight"), out=self.dxcat[:B], precision=precision)  # d[x'|temb] = dpre W1
         ops.temb_bwd(a["t"][:B], self.dxcat[:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
-        ops.gemm(self.dxcat[:B], feat, out=self.dpg[:B], precision=precision, K=I)  # d(proj*gate) = dx' F
+        if precision == 1:
+            ops.zero_(self.dpg[:B])
+        ops.gemm(self.dxcat[:B], feat, out=self.dpg[:B], precision=precision, K=I, split_k=8 if precision == 1 else 1)  # d(proj*gate) = dx' F
         ops.gate_bwd(self.dpg[:B], a["proj"][:B], a["gate"][:B], self.dproj[:B], self.dgate[:B])
         ops.gemm(self.dgate[:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=precision)  # dWg = dgate_pre^T proj
         ops.colsum(self.dgate[:B], B, D, P.g("gate_layer.bias"))

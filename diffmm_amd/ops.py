@@ -169,6 +169,16 @@ def cast_bf16(src: Tensor, dst: Tensor, cols: Optional[int] = None, cols_pad: Op
     L.call("dmm_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), src.shape[0], cols, cols_pad, L.stream())
 
 
+def transpose_cast_bf16(src: Tensor, dst: Tensor, rows: Optional[int] = None, cols: Optional[int] = None) -> None:
+    """dst[c, r] = bf16(src[r, c]); dst is [cols, ld >= round_up(rows, 8)] and its columns rows..round_up(rows, 8) are zeroed."""
+    rows = src.shape[0] if rows is None else rows
+    cols = src.shape[1] if cols is None else cols
+    rp = (rows + 7) & ~7
+    if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] < cols or dst.stride(0) < rp:
+        raise ValueError("transpose_cast_bf16: bad operands")
+    L.call("dmm_transpose_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), rows, cols, rp, L.stream())
+
+
 def temb_bf16(t: int, w_emb: Tensor, b_emb: Tensor, xb: Tensor, I: int) -> None:
     L.call("dmm_temb_bf16", int(t), L.ptr(w_emb), L.ptr(b_emb), w_emb.shape[0], L.ptr(xb), xb.stride(0), xb.shape[0], I, L.stream())
 

@@ -388,3 +388,21 @@ def test_denoise_and_diffusion_loss_vs_reference(dev, name):
         close(E.P[0].g(k) * total, ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, what="grad " + k)
     ref = z["tl/grad/in_layers.0.weight"]
     close(E.P[0].g("in_layers.0.weight")[:, : I + 10] * total, ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()), what="grad W1")
+    # the benchmark's mode: the same step with single-product bf16 GEMMs (fast NT kernel + transpose-cast operands)
+    means1 = E.train_step(x0, [feat], ie, t=[t], noise=[noise], precision=1, update=False)
+    close(means1[0], float(z["tl/loss"].mean()), rtol=2e-2, what="loss (bf16 path)")
+    for k in ("emb_layer.weight", "in_layers.0.bias", "out_layers.0.weight", "out_layers.0.bias", "gate_layer.weight", "gate_layer.bias", "in_layers.0.weight"):
+        ref = z[f"tl/grad/{k}"]
+        got = E.P[0].g(k) * means1[0]
+        if k == "in_layers.0.weight":
+            got = got[:, : I + 10]
+        err = float((got.cpu() - T(ref)).abs().max()) / float(np.abs(ref).max())
+        assert err < 6e-2, f"bf16-path grad {k}: max err {err:.3e} of the gradient scale"
+
+
+def test_transpose_cast(dev):
+    from diffmm_amd import ops
+    x = torch.randn(1116, 6710, device=dev)
+    dst = torch.full((6710, 1120), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.transpose_cast_bf16(x, dst)
+    assert torch.equal(dst[:, :1116], x.t().bfloat16()) and float(dst[:, 1116:1120].abs().max()) == 0.0
