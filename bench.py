@@ -92,6 +92,14 @@ def roofline(coach, args):
             "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6}
     spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sb / ts / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": ts * 1e6, "algorithmic_bytes": sb}
+    try:  # HBM-side traffic per launch from the committed PMC passes (profiles/README.md); bench.py itself cannot run rocprofv3
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")))
+        if args.precision == 1 and args.batch == 4096 and args.workload == "tiktok":
+            gemm["traffic"] = pmc["gemm_bf16_nt_layer1"]["traffic_bytes"]
+            gemm["traffic_note"] = "bytes/launch, fabric side (Infinity-Cache hits included), profiles/r1_pmc_traffic.json"
+            spmm["traffic"] = pmc["spmm_kernel_64"]["traffic_bytes"]
+    except Exception:
+        pass
     return gemm, spmm
 
 

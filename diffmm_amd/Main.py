@@ -129,22 +129,21 @@ class Coach:
         J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
         feats = [J.feat[m] for m in range(M)]
         dl = [0.0] * M
-        diff_batches = []
+        from . import dist as D_
         batches = list(h.diffusionLoader)
-        for gs in range(0, len(batches), W):  # one global step = up to W minibatches, one per replica
-            group = batches[gs:gs + W]
-            diff_batches += [idx for _, idx in group]
-            if R >= len(group):
-                DE.idle_step(len(group))
+        diff_batches = [idx for _, idx in batches]
+        for n_contrib, mine in D_.deal(batches, W, R):  # one global step = up to W minibatches, one per replica
+            if mine is None:
+                DE.idle_step(n_contrib)
                 continue
-            x0, idx = group[R]
+            x0, idx = mine
             t = noise = None
             if draws is not None:
                 t, noise = [], []
                 for m in range(M):
                     t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
                     noise.append(draws.randn(tuple(x0.shape)).to(dev))
-            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, n_contrib=len(group))
+            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, n_contrib=n_contrib)
             tot = sum(means)
             for m in range(M):  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
                 dl[m] += means[m]
@@ -170,16 +169,14 @@ class Coach:
 
         # ---- phase 3: joint training (Main.py:292-377) ----
         acc = torch.zeros(J.n_terms + 2, dtype=torch.float64, device=dev)
-        batches = list(h.trainLoader)
-        for gs in range(0, len(batches), W):
-            group = batches[gs:gs + W]
-            if R >= len(group):
-                J.allreduce_grads(contributing=False, n_contrib=len(group))
+        for n_contrib, mine in D_.deal(list(h.trainLoader), W, R):
+            if mine is None:
+                J.allreduce_grads(contributing=False, n_contrib=n_contrib)
                 J.apply_adam(fold_extras=False)
                 continue
-            users, pos, neg = group[R]
+            users, pos, neg = mine
             noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
-            acc += J.step(users, pos, neg, noise=noise, precision=prec, n_contrib=len(group))
+            acc += J.step(users, pos, neg, noise=noise, precision=prec, n_contrib=n_contrib)
         if W > 1:
             import torch.distributed as dist
             dist.all_reduce(acc)

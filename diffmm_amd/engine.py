@@ -301,15 +301,12 @@ class JointEngine:
     def allreduce_grads(self, contributing: bool, n_contrib: Optional[int] = None):
         """Data-parallel step: average the local gradients of the replicas that hold a minibatch (RCCL all-reduce on the
         flat gradient buffer).  A replica without a minibatch in this global step contributes zeros."""
-        import torch.distributed as dist
+        from . import dist as D_
         ne = self.U * self.D
         if contributing:
             for t in self.T:  # fold the user-row parts of the modal SpMM backward into the flat buffer first
                 ops.add_inplace(self.P.grad[:ne], t.view(-1)[:ne], 1.0)
-        else:
-            self.P.grad.zero_()
-        dist.all_reduce(self.P.grad)
-        self.P.grad.mul_(1.0 / float(n_contrib or self.world))
+        D_.allreduce_mean_(self.P.grad, contributing, n_contrib or self.world)
 
     def apply_adam(self, fold_extras: bool = True):
         P, U, D = self.P, self.U, self.D
@@ -549,11 +546,8 @@ class DiffusionEngine:
     def reduce_and_step(self, m: int, contributing: bool, n_contrib: Optional[int] = None):
         P = self.P[m]
         if self.world > 1:
-            import torch.distributed as dist
-            if not contributing:
-                P.grad.zero_()
-            dist.all_reduce(P.grad)
-            P.grad.mul_(1.0 / float(n_contrib or self.world))
+            from . import dist as D_
+            D_.allreduce_mean_(P.grad, contributing, n_contrib or self.world)
         P.step += 1
         ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step)
 
@@ -612,14 +606,14 @@ class DiffusionEngine:
         int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]])."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
         for i, ub in enumerate(user_batches):
-            if i % self.world != self.rank:  # user batches are sharded over the replicas
+            if i % self.world != self.rank:  # user batches are sharded over the replicas (dist.shard_owner)
                 continue
             x0 = dense_rows(ub)
             for m in range(self.M):
                 den = self.generate_view(m, x0, precision)
                 ops.topk_rows(den, ub.to(torch.int32), deg_ptr, out[m], self.I)
         if self.world > 1:  # every edge slot is written by exactly one replica: a sum all-reduce is an all-gather
-            import torch.distributed as dist
+            from . import dist as D_
             for o in out:
-                dist.all_reduce(o)
+                D_.allgather_disjoint_(o)
         return out
