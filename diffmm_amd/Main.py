@@ -158,8 +158,9 @@ class Coach:
             if int(cfg.hyper.sampling_step) != 0:
                 raise NotImplementedError("sampling_step > 0 (noised start of the reverse chain) is not on the HIP path yet")
             edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, n_edges, precision=prec)
-            u_list = np.repeat(np.arange(dd.users), np.diff(dd.ptr.cpu().numpy()))
-            adjs = [self.makeTorchAdj(u_list, e[:n_edges].cpu().numpy()) for e in edges]
+            if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
+                self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim))
+            adjs = [self.graph_builder.build(e) for e in edges]
         else:
             adjs = list(modal_adj_override)
         self.image_adj, self.text_adj = adjs[0], adjs[1]

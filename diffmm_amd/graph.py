@@ -164,3 +164,99 @@ def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, kee
                      rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
                      val=torch.from_numpy(val).to(dev), tasks=torch.from_numpy(tasks).to(dev), n_head_tasks=head,
                      host=(rowptr, col, val) if keep_host else None)
+
+
+# ======================================================================================================
+# Device-side construction (no host round trip): used for the modality graphs rebuilt every epoch.
+# Index arithmetic runs as torch ops on the device the edge list already lives on (plumbing: sort / cumsum / scatter of
+# ~1e5 integers); the values follow the same float64 formula as normalized_bipartite_csr.
+# ======================================================================================================
+def plan_tasks_torch(rowptr: torch.Tensor, D: int, task_len: int = 32):
+    """torch port of plan_tasks (same task list, bit for bit; checked against the numpy planner in tests/test_host_logic.py)."""
+    G = 1024 // D
+    if G * D != 1024 or D % 4:
+        raise ValueError(f"D={D} unsupported")
+    dev = rowptr.device
+    rp = rowptr.long()
+    length = rp[1:] - rp[:-1]
+    k = torch.clamp((length + task_len - 1) // task_len, min=1, max=G)
+    multi = torch.nonzero(k > 1).flatten()
+    single = torch.nonzero(k == 1).flatten()
+    pad_row = torch.tensor([[-1, 0, 0, 1]], dtype=torch.long, device=dev)
+    parts = []
+    head = 0
+    if multi.numel():
+        km = k[multi]
+        kp = torch.ones_like(km)
+        while bool((kp < km).any()):  # next power of two, <= log2(G) rounds
+            kp = torch.where(kp < km, kp * 2, kp)
+        order = torch.sort(-kp, stable=True).indices
+        multi, kp = multi[order], kp[order]
+        kmm = torch.clamp(kp, max=G)
+        total = int(kmm.sum())
+        start = torch.cumsum(kmm, 0) - kmm
+        run_of = torch.repeat_interleave(torch.arange(multi.numel(), device=dev), kmm, output_size=total)
+        j = torch.arange(total, device=dev) - start[run_of]
+        chunk = (length[multi] + kmm - 1) // kmm
+        beg = rp[multi][run_of] + j * chunk[run_of]
+        end = torch.minimum(beg + chunk[run_of], rp[multi + 1][run_of])
+        live = beg < end
+        nlive = torch.bincount(run_of[live], minlength=multi.numel())
+        t = torch.full((total, 4), -1, dtype=torch.long, device=dev)
+        t[:, 1:] = 0
+        t[live, 0] = multi[run_of[live]]
+        t[live, 1] = beg[live]
+        t[live, 2] = end[live]
+        t[live, 3] = (j[live] << 16) | nlive[run_of[live]]
+        t[~live, 3] = 1
+        pad = (-total) % G
+        if pad:
+            t = torch.cat([t, pad_row.expand(pad, 4)])
+        head = int(t.shape[0])
+        parts.append(t)
+    if single.numel():
+        t = torch.stack([single, rp[single], rp[single + 1], torch.ones_like(single)], dim=1)
+        pad = (-int(t.shape[0])) % G
+        if pad:
+            t = torch.cat([t, pad_row.expand(pad, 4)])
+        parts.append(t)
+    out = torch.cat(parts) if parts else pad_row.expand(G, 4)
+    return out.to(torch.int32).contiguous(), head
+
+
+class DeviceGraphBuilder:
+    """Builds D^-1/2 (A + I) D^-1/2 CSR + task list on the device for edge lists that share the base graph's user degrees
+    (the rebuild keeps k_u = deg_u, Main.py:215-230): `item_idx[user_ptr[u] : user_ptr[u+1]]` are user u's items, distinct."""
+
+    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = 32):
+        self.U, self.I, self.N, self.D, self.task_len = users, items, users + items, D, task_len
+        self.dev = user_ptr.device
+        up = user_ptr.long()
+        self.deg_u = up[1:] - up[:-1]
+        self.E = int(up[-1])
+        self.edge_user = torch.repeat_interleave(torch.arange(users, device=self.dev), self.deg_u, output_size=self.E)
+        self.pos_user_edge = torch.arange(self.E, device=self.dev) + self.edge_user + 1  # slot of edge j inside its user row
+
+    def build(self, item_idx: torch.Tensor, validate: bool = False) -> Adjacency:
+        U, I, N, E, dev = self.U, self.I, self.N, self.E, self.dev
+        item = item_idx[:E].long()
+        cnt_i = torch.bincount(item, minlength=I)
+        deg_n = torch.cat([self.deg_u, cnt_i]) + 1
+        rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
+        torch.cumsum(deg_n, 0, out=rowptr[1:])
+        nnz = 2 * E + N
+        col = torch.empty(nnz, dtype=torch.long, device=dev)
+        ar_u, ar_i = torch.arange(U, device=dev), torch.arange(I, device=dev)
+        col[rowptr[:U]] = ar_u                                  # user self loops come first in their rows (u < U <= U + item)
+        col[self.pos_user_edge] = U + item                      # a user's items keep the (ascending) top-k order
+        skey = torch.sort(item * U + self.edge_user).values    # item rows: users ascending
+        it_s = skey // U
+        col[(E + U) + torch.arange(E, device=dev) + it_s] = skey - it_s * U
+        col[rowptr[U + 1:] - 1] = U + ar_i                      # item self loops come last (users < U <= U + i)
+        dinv = deg_n.double() ** -0.5
+        row = torch.repeat_interleave(torch.arange(N, device=dev), deg_n, output_size=nnz)
+        val = ((dinv[row] * 1.0) * dinv[col]).float()
+        tasks, head = plan_tasks_torch(rowptr, self.D, self.task_len)
+        if validate:
+            check_plan(rowptr.cpu().numpy(), tasks.cpu().numpy(), self.D)
+        return Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr.to(torch.int32), col=col.to(torch.int32), val=val, tasks=tasks, n_head_tasks=head)
