@@ -67,7 +67,8 @@ class Coach:
         self.diffusion_model = GaussianDiffusion(cfg)
         in_dims, out_dims = denoise_dims(cfg)
         self.diff_engine = DiffusionEngine(int(cfg.data.item_num), int(cfg.base.latdim), int(in_dims[1]), int(cfg.base.d_emb_size), M,
-                                           int(cfg.hyper.steps), hyper_dict(cfg), self.device, int(cfg.train.batch))
+                                           int(cfg.hyper.steps), hyper_dict(cfg), self.device, int(cfg.train.batch),
+                                           chain_rows=min(int(cfg.data.user_num), 16384))
         dens = [Denoise(in_dims, out_dims, cfg, _engine=self.diff_engine, _slot=m, precision=self.precision) for m in range(M)]
         self.image_denoise_model, self.text_denoise_model = dens[0], dens[1]
         if M == 3:

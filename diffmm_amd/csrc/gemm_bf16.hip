@@ -249,8 +249,47 @@ __global__ __launch_bounds__(256) void temb_bf16_kernel(int t, const float* __re
   }
 }
 
+// Per-timestep layer-1 bias of the reverse chain: every row of a chain step shares the timestep, so the time embedding's
+// contribution W1[:, I:I+te] . emb_layer(features(t)) is a vector; table[t][h] = b1[h] + that, for all T steps at once (fp32).
+__global__ __launch_bounds__(256) void temb_bias_table_kernel(const float* __restrict__ w_emb, const float* __restrict__ b_emb, int te,
+                                                               const float* __restrict__ w1, long long ldw1, int I, const float* __restrict__ b1,
+                                                               int H, float* __restrict__ table) {
+  __shared__ float e[32], o[32];
+  const int t = blockIdx.x;
+  if (threadIdx.x < te) {
+    const int k = threadIdx.x, half = te / 2;
+    float v = 0.f;
+    if (!((te & 1) && k == te - 1)) {
+      const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
+      const float ang = (float)t * f;
+      v = k < half ? cosf(ang) : sinf(ang);
+    }
+    e[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < te) {
+    float v = b_emb[threadIdx.x];
+    for (int k = 0; k < te; ++k) v = fmaf(w_emb[threadIdx.x * te + k], e[k], v);
+    o[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += 256) {
+    float v = b1[h];
+    for (int c = 0; c < te; ++c) v = fmaf(w1[(long long)h * ldw1 + I + c], o[c], v);
+    table[(long long)t * H + h] = v;
+  }
+}
+
 }  // namespace dmm
 using namespace dmm;
+
+extern "C" int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int te, const float* w1, int64_t ldw1, int I, const float* b1, int H,
+                                   int T, float* table, void* stream) {
+  DMM_CHECK_ARG(w_emb && b_emb && w1 && b1 && table && te >= 2 && te <= 32 && H > 0 && T > 0 && ldw1 >= I + te, "dmm_temb_bias_table: bad arguments");
+  hipLaunchKernelGGL(temb_bias_table_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, w_emb, b_emb, te, w1, (long long)ldw1, I, b1, H, table);
+  DMM_LAUNCH_CHECK("dmm_temb_bias_table");
+  return 0;
+}
 
 extern "C" int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a, void* stream) {
   DMM_CHECK_ARG(a && a->A && a->B && (a->C || a->Cb), "dmm_gemm_bf16_nt: null operand");

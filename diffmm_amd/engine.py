@@ -356,8 +356,11 @@ def schedule_tables(T: int, noise_scale: float, noise_min: float, noise_max: flo
 class DiffusionEngine:
     """Denoise MLPs of all modalities + GaussianDiffusion arithmetic."""
 
-    def __init__(self, items: int, D: int, H: int, te: int, M: int, T: int, hp: dict, device, B_max: int):
+    def __init__(self, items: int, D: int, H: int, te: int, M: int, T: int, hp: dict, device, B_max: int, chain_rows: Optional[int] = None):
+        """chain_rows: rows the reverse chain processes per launch sequence (>= B_max).  The chain's rows are independent, so the
+        rebuild is free to use far larger GEMMs than the training batch: more 128x128 tiles per launch, no ragged tail batch."""
         self.I, self.D, self.H, self.te, self.M, self.T = items, D, H, te, M, T
+        self.chain_rows = max(int(chain_rows or B_max), B_max)
         self.hp = dict(hp)
         self.dev = torch.device(device)
         self.Kp = (items + te + 7) & ~7  # leading dimension of [x_t | temb | 0-pad]; also of out / dout
@@ -383,12 +386,15 @@ class DiffusionEngine:
         self.ui = z(B_max, D)
         self.dout, self.dxcat = z(B_max, Kp), z(B_max, Kp)
         self.dum, self.dpg, self.dgate, self.dproj = z(B_max, D), z(B_max, D), z(B_max, D), z(B_max, D)
-        self.dh, self.dpre = z(B_max, H), z(B_max, H)
-        self.xa, self.xb = z(B_max, Kp), z(B_max, Kp)  # ping-pong buffers of the reverse chain
+        self.dh, self.dpre = z(self.chain_rows, H), z(B_max, H)
+        R = self.chain_rows
+        self.xa, self.xb = z(R, Kp), z(R, Kp)  # ping-pong buffers of the reverse chain
         zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
-        self.xa16, self.xb16, self.h16 = zb(B_max, Kp), zb(B_max, Kp), zb(B_max, H)  # bf16 operands of the chain's GEMMs
+        self.xa16, self.xb16, self.h16 = zb(R, Kp), zb(R, Kp), zb(R, H)  # bf16 operands of the chain's GEMMs
         self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
         self.w16_step = [-1] * M  # Adam step the bf16 weight copies were taken at
+        self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
+        self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
         Bp8 = (B_max + 7) & ~7
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
@@ -562,6 +568,8 @@ class DiffusionEngine:
         if self.w16_step[m] != P.step or P.step == 0:
             ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
             ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+            ops.temb_bias_table(P.view("emb_layer.weight"), P.view("emb_layer.bias"), P.view("in_layers.0.weight"), self.I, P.view("in_layers.0.bias"),
+                                self.bias_t[m])
             self.w16_step[m] = P.step
 
     def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
@@ -571,14 +579,15 @@ class DiffusionEngine:
         self._refresh_bf16_weights(m)
         self.xa[:B, :I].copy_(x0)
         plan = self._chain_plans.get((m, B))
-        if plan is None:  # 3 T + 1 launches on static buffers: record once, replay for every user batch and epoch
+        if plan is None:  # 2 T + 2 launches on static buffers: record once, replay for every user batch and epoch
             with L.Recorder() as plan:
                 cur, nxt, cur16, nxt16, h16 = self.xa[:B], self.xb[:B], self.xa16[:B], self.xb16[:B], self.h16[:B]
-                ops.cast_bf16(cur, cur16, cols=I, cols_pad=I)
-                w_emb, b_emb, b1, b2 = P.view("emb_layer.weight"), P.view("emb_layer.bias"), P.view("in_layers.0.bias"), P.view("out_layers.0.bias")
+                I8 = self.I8  # K of layer 1: the item columns only (rounded up to 8, pad columns zero); temb enters through the bias table
+                ops.zero_(nxt16)
+                ops.cast_bf16(cur, cur16, cols=I, cols_pad=I8)
+                b2 = P.view("out_layers.0.bias")
                 for i in range(self.T - 1, -1, -1):
-                    ops.temb_bf16(i, w_emb, b_emb, cur16, I)
-                    ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=b1, act=L.ACT_TANH)
+                    ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH, K=I8)
                     ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
             self._chain_plans[(m, B)] = plan
@@ -605,8 +614,14 @@ class DiffusionEngine:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
         int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]])."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
+        if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow, evenly over the replicas
+            all_users = torch.cat([b.reshape(-1) for b in user_batches])
+            n = int(all_users.numel())
+            n_chunks = self.world * max(1, -(-n // (self.world * self.chain_rows)))
+            per = -(-n // n_chunks)
+            user_batches = [all_users[s:s + per] for s in range(0, n, per)]
         for i, ub in enumerate(user_batches):
-            if i % self.world != self.rank:  # user batches are sharded over the replicas (dist.shard_owner)
+            if i % self.world != self.rank:  # user chunks are sharded over the replicas (dist.shard_owner)
                 continue
             x0 = dense_rows(ub)
             for m in range(self.M):

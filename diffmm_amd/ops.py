@@ -179,6 +179,12 @@ def transpose_cast_bf16(src: Tensor, dst: Tensor, rows: Optional[int] = None, co
     L.call("dmm_transpose_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), rows, cols, rp, L.stream())
 
 
+def temb_bias_table(w_emb: Tensor, b_emb: Tensor, w1: Tensor, I: int, b1: Tensor, table: Tensor) -> None:
+    T, H = table.shape
+    L.call("dmm_temb_bias_table", L.ptr(w_emb), L.ptr(b_emb), w_emb.shape[0], L.ptr(w1), w1.stride(0), I, L.ptr(b1), H, T, L.ptr(_f32c(table, "table")),
+           L.stream())
+
+
 def temb_bf16(t: int, w_emb: Tensor, b_emb: Tensor, xb: Tensor, I: int) -> None:
     L.call("dmm_temb_bf16", int(t), L.ptr(w_emb), L.ptr(b_emb), w_emb.shape[0], L.ptr(xb), xb.stride(0), xb.shape[0], I, L.stream())
 

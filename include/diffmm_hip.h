@@ -113,6 +113,9 @@ int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a /*host*/, void* stream);
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
 int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream);
+/* table[t][h] = b1[h] + sum_c W1[h][I+c] * emb_layer(features(t))[c]: the layer-1 bias of chain step t (all rows share t), T x H */
+int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int te, const float* w1, int64_t ldw1, int I, const float* b1, int H,
+                        int T, float* table, void* stream);
 int dmm_temb_bf16(int t, const float* w_emb, const float* b_emb, int te, void* xb, int64_t ldx, int B, int I, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
