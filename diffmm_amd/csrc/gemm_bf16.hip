@@ -33,37 +33,63 @@ struct GemmBf16P {
   int part;    // XCD placement: 0 = grid order, 1 = each XCD owns a range of m tiles, 2 = a range of n tiles
 };
 
-constexpr int GB_BM = 128, GB_BK = 64;
+constexpr int GB_BK = 64;
+constexpr int GB_MAX_BATCH = 4;
+
+struct GemmBf16Batch {
+  GemmBf16P p[GB_MAX_BATCH];  // same shape / scalars, different pointers (one per modality); blockIdx.y picks one
+  int n;
+};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int ROWS>
-__device__ __forceinline__ void g_load(uint4 (&v)[ROWS / 32], const __bf16* __restrict__ base, long long ld, int row0, int rows, int k0, int K) {
+// ROWS x 64 bf16 tile, NTHR threads: thread t moves the 16-byte chunk (t & 7) of rows (t >> 3) + (NTHR / 8) * i
+// `edge` is workgroup-uniform: true when the tile can reach past M / N / K.  Interior workgroups (almost all) move raw registers
+// from the load to the LDS write -- nothing consumes the loaded values early, so they stay in flight until that write.  Edge
+// workgroups read clamped (valid) addresses and zero the out-of-range chunks with an AND mask (no branch around any load).
+template <int ROWS, int NTHR>
+__device__ __forceinline__ void g_load(uint4 (&v)[ROWS * 8 / NTHR], const __bf16* __restrict__ base, long long ld, int row0, int rows, int k0, int K,
+                                       bool edge) {
   const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int k = k0 + c * 8;
+  if (!edge) {
+    const int kc = k < K ? k : 0;  // only prefetches past the last tile take the clamp; their data is never used
 #pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) {
-    const int r = row0 + r0 + 32 * i, k = k0 + c * 8;
-    uint4 x = make_uint4(0u, 0u, 0u, 0u);
-    if (r < rows && k < K) x = *reinterpret_cast<const uint4*>(base + (long long)r * ld + k);
-    v[i] = x;
+    for (int i = 0; i < ROWS * 8 / NTHR; ++i) v[i] = *reinterpret_cast<const uint4*>(base + (long long)(row0 + r0 + (NTHR / 8) * i) * ld + kc);
+    return;
+  }
+  const bool kok = k < K;
+  const int kc = kok ? k : 0;
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / NTHR; ++i) {
+    const int r = row0 + r0 + (NTHR / 8) * i;
+    const uint4 x = *reinterpret_cast<const uint4*>(base + (long long)(r < rows ? r : rows - 1) * ld + kc);
+    const unsigned msk = (kok && r < rows) ? 0xffffffffu : 0u;
+    v[i] = make_uint4(x.x & msk, x.y & msk, x.z & msk, x.w & msk);
   }
 }
-template <int ROWS>
-__device__ __forceinline__ void s_store(const uint4 (&v)[ROWS / 32], char* tile) {
+template <int ROWS, int NTHR>
+__device__ __forceinline__ void s_store(const uint4 (&v)[ROWS * 8 / NTHR], char* tile) {
   const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) *reinterpret_cast<uint4*>(tile + swz(r0 + 32 * i, c)) = v[i];
+  for (int i = 0; i < ROWS * 8 / NTHR; ++i) *reinterpret_cast<uint4*>(tile + swz(r0 + (NTHR / 8) * i, c)) = v[i];
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmBf16P P) {
+// BM x BN output tile; waves are arranged (BM / 64) x 2, every wave owns 64 x (BN / 2) outputs (2 x NT MFMA tiles of 32 x 32).
+//   <128, 64>  256 threads, 48 KiB LDS: small problems (most workgroups)
+//   <128, 128> 256 threads, 64 KiB LDS
+//   <256, 128> 512 threads, 96 KiB LDS, 85 flop per staged byte: keeps a CU's vector-memory path (the limiter of the small
+//              tiles: 43 flop/B needs ~95 B/clk/CU) under the MFMA time; one workgroup per CU, two waves per SIMD
+template <int BM, int BN>
+__global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_kernel(const GemmBf16Batch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = GB_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NTHR = BM * 2;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int WN = BN / 2;        // columns per wave
   constexpr int NT = WN / 32;       // 32x32 tiles per wave along n (2 or 1)
-  // Workgroups are dealt round-robin over the 8 XCDs (id % 8 names the XCD group; speed only).  Each XCD works through a
-  // contiguous range of tiles along the dimension of the LARGER operand, so that operand crosses the fabric once instead of
-  // once per XCD (measured on the layer-1 shape: FETCH_SIZE 6.4x the operand bytes with grid-order placement).
+  const GemmBf16P& P = batch.p[blockIdx.y];
+  // Workgroups are dealt round-robin over the 8 XCDs (id % 8 names the XCD group; speed only).  With part != 0 each XCD works
+  // through a contiguous range of tiles along the dimension of the LARGER operand, so that operand crosses the fabric once.
   int mtile, ntile;
   {
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
@@ -82,10 +108,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmBf16P P)
       ntile = id % P.nt;
     }
   }
-  const int m0 = mtile * GB_BM, n0 = ntile * BN;
+  const int m0 = mtile * BM, n0 = ntile * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
   const int nk = (P.K + GB_BK - 1) / GB_BK;
+  const bool edge_a = m0 + BM > P.M || P.K % GB_BK != 0, edge_b = n0 + BN > P.N || P.K % GB_BK != 0;
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -95,20 +122,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmBf16P P)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[GB_BM / 32], rb[BN / 32];
-  g_load<GB_BM>(ra, P.A, P.lda, m0, P.M, 0, P.K);
-  g_load<BN>(rb, P.B, P.ldb, n0, P.N, 0, P.K);
-  s_store<GB_BM>(ra, smem);
-  s_store<BN>(rb, smem + A_BYTES);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    char* a_t = smem + cur * STAGE;
-    char* b_t = a_t + A_BYTES;
-    if (kt + 1 < nk) {  // next tile: global -> registers, in flight while this tile's MFMAs run
-      g_load<GB_BM>(ra, P.A, P.lda, m0, P.M, (kt + 1) * GB_BK, P.K);
-      g_load<BN>(rb, P.B, P.ldb, n0, P.N, (kt + 1) * GB_BK, P.K);
-    }
+  // Software pipeline: LDS holds tile kt (two buffers), register set 0 / 1 hold tiles kt+1 / kt+2 while their global loads are
+  // in flight -- a load has two tiles of MFMA work (~1000+ cycles) to land before it is written to LDS.  The loop is unrolled by
+  // two so that both register sets keep static names (runtime-indexed register arrays would go to scratch).
+  uint4 ra0[BM * 8 / NTHR], rb0[BN * 8 / NTHR], ra1[BM * 8 / NTHR], rb1[BN * 8 / NTHR];
+  auto compute = [&](const char* a_t, const char* b_t) {
 #pragma unroll
     for (int ks = 0; ks < GB_BK / 16; ++ks) {
       const int chunk = ks * 2 + fh;
@@ -122,73 +140,105 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmBf16P P)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {  // the other buffer was last read before the previous barrier: safe to overwrite now
-      s_store<GB_BM>(ra, smem + (cur ^ 1) * STAGE);
-      s_store<BN>(rb, smem + (cur ^ 1) * STAGE + A_BYTES);
-    }
+  };
+  char* const buf0 = smem;
+  char* const buf1 = smem + STAGE;
+  g_load<BM, NTHR>(ra0, P.A, P.lda, m0, P.M, 0, P.K, edge_a);
+  g_load<BN, NTHR>(rb0, P.B, P.ldb, n0, P.N, 0, P.K, edge_b);
+  s_store<BM, NTHR>(ra0, buf0);
+  s_store<BN, NTHR>(rb0, buf0 + A_BYTES);
+  g_load<BM, NTHR>(ra0, P.A, P.lda, m0, P.M, GB_BK, P.K, edge_a);       // tile 1 -> set 0
+  g_load<BN, NTHR>(rb0, P.B, P.ldb, n0, P.N, GB_BK, P.K, edge_b);
+  g_load<BM, NTHR>(ra1, P.A, P.lda, m0, P.M, 2 * GB_BK, P.K, edge_a);   // tile 2 -> set 1
+  g_load<BN, NTHR>(rb1, P.B, P.ldb, n0, P.N, 2 * GB_BK, P.K, edge_b);
+  __syncthreads();
+  // Straight-line body (no conditional loads: tiles past K read clamped addresses and are zero-filled), so the compiler's
+  // s_waitcnt insertion can count the loads of the OTHER register set that stay in flight across the LDS write.
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    // even half: LDS buffer 0 = tile kt; set 0 = tile kt+1, set 1 = tile kt+2 (both may still be in flight)
+    compute(buf0, buf0 + A_BYTES);
+    s_store<BM, NTHR>(ra0, buf1);               // buffer 1 was last read two barriers ago
+    s_store<BN, NTHR>(rb0, buf1 + A_BYTES);
+    g_load<BM, NTHR>(ra0, P.A, P.lda, m0, P.M, (kt + 3) * GB_BK, P.K, edge_a);
+    g_load<BN, NTHR>(rb0, P.B, P.ldb, n0, P.N, (kt + 3) * GB_BK, P.K, edge_b);
     __syncthreads();
-    cur ^= 1;
+    // odd half: LDS buffer 1 = tile kt+1; set 1 = tile kt+2, set 0 = tile kt+3
+    compute(buf1, buf1 + A_BYTES);
+    s_store<BM, NTHR>(ra1, buf0);
+    s_store<BN, NTHR>(rb1, buf0 + A_BYTES);
+    g_load<BM, NTHR>(ra1, P.A, P.lda, m0, P.M, (kt + 4) * GB_BK, P.K, edge_a);
+    g_load<BN, NTHR>(rb1, P.B, P.ldb, n0, P.N, (kt + 4) * GB_BK, P.K, edge_b);
+    __syncthreads();
   }
+  if (kt < nk) compute(buf0, buf0 + A_BYTES);  // odd tile count: the last tile sits in buffer 0
+  __syncthreads();  // every wave is done with the staging buffers before the epilogue reuses them
 
-  // ---- epilogue: transpose the wave's 64 x WN accumulator tile through LDS (the staging buffers are free after the last
-  // barrier) so that every lane then handles 4 consecutive columns: 16-byte residual loads and fp32 stores, 8-byte bf16 stores.
-  float* tile = reinterpret_cast<float*>(smem) + wave * 64 * WN;
-  constexpr int C4 = WN / 4;  // float4 chunks per tile row
+  // ---- epilogue: every wave transposes its accumulators through its OWN LDS slab (the staging buffers are free after the last
+  // barrier; 32 rows x WN floats per pass, so no workgroup barrier is needed) and then each lane handles 4 consecutive columns:
+  // 16-byte residual loads and fp32 stores, 8-byte bf16 stores.
+  float* tile = reinterpret_cast<float*>(smem) + wave * 32 * WN;
+  constexpr int C4 = WN / 4;       // float4 chunks per tile row
+  constexpr int ITER = 32 * C4 / 64;  // chunks per lane per 32-row pass
   const bool vec_ok = (!P.C || (P.ldc % 4 == 0 && ((uintptr_t)P.C & 15) == 0)) &&
                       (!P.R || (P.ldr % 4 == 0 && ((uintptr_t)P.R & 15) == 0)) && (!P.Cb || (P.ldcb % 4 == 0 && ((uintptr_t)P.Cb & 7) == 0));
-  // residual rows are requested first so their HBM latency overlaps the LDS transpose below
-  float4 rr[C4];
-  if (P.R && vec_ok) {
 #pragma unroll
-    for (int it = 0; it < C4; ++it) {
-      const int idx = it * 64 + lane;
-      const int m = m0 + wm * 64 + idx / C4, n = n0 + wn * WN + (idx % C4) * 4;
-      rr[it] = (m < P.M && n + 3 < P.N) ? *reinterpret_cast<const float4*>(P.R + (long long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 2; ++i) {
+    // residual rows are requested first so their latency overlaps the LDS transpose below
+    float4 rr[ITER];
+    if (P.R && vec_ok) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = it * 64 + lane;
+        const int m = m0 + wm * 64 + i * 32 + idx / C4, n = n0 + wn * WN + (idx % C4) * 4;
+        rr[it] = (m < P.M && n + 3 < P.N) ? *reinterpret_cast<const float4*>(P.R + (long long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tile[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][r];
-  __syncthreads();
+      for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (DS ops of a wave complete in order)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int it = 0; it < C4; ++it) {
-    const int idx = it * 64 + lane;
-    const int row = idx / C4, c4 = idx % C4;
-    const int m = m0 + wm * 64 + row, n = n0 + wn * WN + c4 * 4;
-    if (m >= P.M || n >= P.N) continue;
-    const float4 a4 = *reinterpret_cast<const float4*>(tile + row * WN + c4 * 4);
-    float v[4] = {a4.x, a4.y, a4.z, a4.w};
-    const int nv = min(4, P.N - n);
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / C4, c4 = idx % C4;
+      const int m = m0 + wm * 64 + i * 32 + row, n = n0 + wn * WN + c4 * 4;
+      if (m >= P.M || n >= P.N) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(tile + row * WN + c4 * 4);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      const int nv = min(4, P.N - n);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (u < nv) {
-        float x = P.alpha * v[u] + (P.bias ? P.bias[n + u] : 0.f);
-        if (P.act == DMM_ACT_TANH) x = tanhf(x);
-        else if (P.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
-        v[u] = x;
+      for (int u = 0; u < 4; ++u) {
+        if (u < nv) {
+          float x = P.alpha * v[u] + (P.bias ? P.bias[n + u] : 0.f);
+          if (P.act == DMM_ACT_TANH) x = tanhf(x);
+          else if (P.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+          v[u] = x;
+        }
+      }
+      if (nv == 4 && vec_ok) {
+        if (P.R) {
+          const float4 r4 = rr[it];
+          v[0] = P.e1 * v[0] + P.e2 * r4.x; v[1] = P.e1 * v[1] + P.e2 * r4.y; v[2] = P.e1 * v[2] + P.e2 * r4.z; v[3] = P.e1 * v[3] + P.e2 * r4.w;
+        }
+        if (P.C) *reinterpret_cast<float4*>(P.C + (long long)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (P.Cb) {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<bf16x4*>(P.Cb + (long long)m * P.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+      } else {
+        for (int u = 0; u < nv; ++u) {
+          float x = v[u];
+          if (P.R) x = P.e1 * x + P.e2 * P.R[(long long)m * P.ldr + n + u];
+          if (P.C) P.C[(long long)m * P.ldc + n + u] = x;
+          if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)x;
+        }
       }
     }
-    if (nv == 4 && vec_ok) {
-      if (P.R) {
-        const float4 r4 = rr[it];
-        v[0] = P.e1 * v[0] + P.e2 * r4.x; v[1] = P.e1 * v[1] + P.e2 * r4.y; v[2] = P.e1 * v[2] + P.e2 * r4.z; v[3] = P.e1 * v[3] + P.e2 * r4.w;
-      }
-      if (P.C) *reinterpret_cast<float4*>(P.C + (long long)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-      if (P.Cb) {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<bf16x4*>(P.Cb + (long long)m * P.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-      }
-    } else {
-      for (int u = 0; u < nv; ++u) {
-        float x = v[u];
-        if (P.R) x = P.e1 * x + P.e2 * P.R[(long long)m * P.ldr + n + u];
-        if (P.C) P.C[(long long)m * P.ldc + n + u] = x;
-        if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)x;
-      }
-    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // the pass's LDS reads are done before the next pass overwrites the slab
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -291,44 +341,71 @@ extern "C" int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int t
   return 0;
 }
 
-extern "C" int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a, void* stream) {
-  DMM_CHECK_ARG(a && a->A && a->B && (a->C || a->Cb), "dmm_gemm_bf16_nt: null operand");
-  DMM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0, "dmm_gemm_bf16_nt: K=%d must be a positive multiple of 8", a->K);
-  DMM_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0,
-                "dmm_gemm_bf16_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
-  GemmBf16P P;
-  P.A = (const __bf16*)a->A; P.lda = a->lda; P.B = (const __bf16*)a->B; P.ldb = a->ldb;
-  P.C = a->C; P.ldc = a->ldc; P.Cb = (__bf16*)a->Cb; P.ldcb = a->ldcb;
-  P.bias = a->bias; P.R = a->R; P.ldr = a->ldr; P.M = a->M; P.N = a->N; P.K = a->K;
-  P.alpha = a->alpha; P.e1 = a->e1; P.e2 = a->e2; P.act = a->act;
-  const long long tiles128 = (long long)cdiv(a->M, GB_BM) * cdiv(a->N, 128);
-  hipStream_t s = (hipStream_t)stream;
-  static const int force_bn = [] { const char* e = getenv("DMM_GEMM_BN"); return e ? atoi(e) : 0; }();      // tuning knobs
+template <int BM, int BN>
+static void launch_tile(const GemmBf16Batch& b, int blocks, hipStream_t s) {
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool once = [] {  // > 64 KiB of dynamic LDS must be opted into
+    if (LDS > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(blocks, b.n), dim3(BM * 2), LDS, s, b);
+}
+
+extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_batch, void* stream) {
+  DMM_CHECK_ARG(args && n_batch >= 1 && n_batch <= GB_MAX_BATCH, "dmm_gemm_bf16_nt: 1..%d problems per launch", GB_MAX_BATCH);
+  GemmBf16Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n_batch;
+  const dmm_gemm_bf16_args* a0 = args;
+  for (int i = 0; i < n_batch; ++i) {
+    const dmm_gemm_bf16_args* a = args + i;
+    DMM_CHECK_ARG(a->A && a->B && (a->C || a->Cb), "dmm_gemm_bf16_nt: null operand (problem %d)", i);
+    DMM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0, "dmm_gemm_bf16_nt: K=%d must be a positive multiple of 8", a->K);
+    DMM_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0,
+                  "dmm_gemm_bf16_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+    DMM_CHECK_ARG(a->M == a0->M && a->N == a0->N && a->K == a0->K, "dmm_gemm_bf16_nt: batched problems must share one shape");
+    GemmBf16P& P = b.p[i];
+    P.A = (const __bf16*)a->A; P.lda = a->lda; P.B = (const __bf16*)a->B; P.ldb = a->ldb;
+    P.C = a->C; P.ldc = a->ldc; P.Cb = (__bf16*)a->Cb; P.ldcb = a->ldcb;
+    P.bias = a->bias; P.R = a->R; P.ldr = a->ldr; P.M = a->M; P.N = a->N; P.K = a->K;
+    P.alpha = a->alpha; P.e1 = a->e1; P.e2 = a->e2; P.act = a->act;
+  }
+  static const int force_tile = [] { const char* e = getenv("DMM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning knobs: 64 / 128 / 256
   static const int force_part = [] { const char* e = getenv("DMM_GEMM_PART"); return e ? atoi(e) : -1; }();
-  const bool big = (tiles128 >= 512 && force_bn != 64) || force_bn == 128;  // enough 128x128 tiles for two workgroups per CU
-  const int bn = big ? 128 : 64;
-  P.mt = cdiv(a->M, GB_BM);
-  P.nt = cdiv(a->N, bn);
+  const int M = a0->M, N = a0->N;
+  const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * n_batch, t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * n_batch;
+  int tile = t256 >= 768 ? 256 : (t128 >= 512 ? 128 : 64);  // big tiles only when they still fill the 256 CUs several times over
+  if (force_tile) tile = force_tile;
+  const int bm = tile == 256 ? 256 : 128, bn = tile == 64 ? 64 : 128;
+  const int mt = cdiv(M, bm), nt = cdiv(N, bn);
   // XCD-contiguous placement pays only when the operands overflow the 256 MiB Infinity Cache (measured: +-3 % on the 70 MB
   // chain shapes, where grid order is kept); then the XCDs split the dimension of the larger operand.
-  P.part = 0;
-  if (((long long)a->M + a->N) * a->K * 2 > (192ll << 20)) P.part = (long long)a->M >= (long long)a->N ? (P.mt >= 8 ? 1 : 0) : (P.nt >= 8 ? 2 : 0);
-  if (force_part >= 0) P.part = force_part;
-  int blocks = P.mt * P.nt;
-  if (P.part == 1) {
+  int part = 0;
+  if (((long long)M + N) * a0->K * 2 > (192ll << 20)) part = M >= N ? (mt >= 8 ? 1 : 0) : (nt >= 8 ? 2 : 0);
+  if (force_part >= 0) part = force_part;
+  int blocks = mt * nt;
+  if (part == 1) {
     int mx = 0;
-    for (int x = 0; x < 8; ++x) mx = max(mx, (x + 1) * P.mt / 8 - x * P.mt / 8);
-    blocks = 8 * mx * P.nt;
-  } else if (P.part == 2) {
+    for (int x = 0; x < 8; ++x) mx = max(mx, (x + 1) * mt / 8 - x * mt / 8);
+    blocks = 8 * mx * nt;
+  } else if (part == 2) {
     int mx = 0;
-    for (int x = 0; x < 8; ++x) mx = max(mx, (x + 1) * P.nt / 8 - x * P.nt / 8);
-    blocks = 8 * mx * P.mt;
+    for (int x = 0; x < 8; ++x) mx = max(mx, (x + 1) * nt / 8 - x * nt / 8);
+    blocks = 8 * mx * mt;
   }
-  if (big) hipLaunchKernelGGL(gemm_bf16_nt_kernel<128>, dim3(blocks), dim3(256), 2 * (GB_BM + 128) * 128, s, P);
-  else hipLaunchKernelGGL(gemm_bf16_nt_kernel<64>, dim3(blocks), dim3(256), 2 * (GB_BM + 64) * 128, s, P);
+  for (int i = 0; i < n_batch; ++i) {
+    b.p[i].mt = mt; b.p[i].nt = nt; b.p[i].part = part;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (tile == 256) launch_tile<256, 128>(b, blocks, s);
+  else if (tile == 128) launch_tile<128, 128>(b, blocks, s);
+  else launch_tile<128, 64>(b, blocks, s);
   DMM_LAUNCH_CHECK("dmm_gemm_bf16_nt");
   return 0;
 }
+
+extern "C" int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a, void* stream) { return dmm_gemm_bf16_nt_batched(a, 1, stream); }
 
 extern "C" int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream) {
   DMM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols_pad >= cols && ldd >= cols_pad, "dmm_cast_bf16: bad arguments");

@@ -388,9 +388,11 @@ class DiffusionEngine:
         self.dum, self.dpg, self.dgate, self.dproj = z(B_max, D), z(B_max, D), z(B_max, D), z(B_max, D)
         self.dh, self.dpre = z(self.chain_rows, H), z(B_max, H)
         R = self.chain_rows
-        self.xa, self.xb = z(R, Kp), z(R, Kp)  # ping-pong buffers of the reverse chain
         zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
-        self.xa16, self.xb16, self.h16 = zb(R, Kp), zb(R, Kp), zb(R, H)  # bf16 operands of the chain's GEMMs
+        # ping-pong buffers of the reverse chain, one set per modality (the modalities' chains advance together, batched launches)
+        self.cxa, self.cxb = [z(R, Kp) for _ in range(M)], [z(R, Kp) for _ in range(M)]
+        self.cxa16, self.cxb16, self.ch16 = [zb(R, Kp) for _ in range(M)], [zb(R, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
+        self.xa, self.xb, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxb[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
         self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
         self.w16_step = [-1] * M  # Adam step the bf16 weight copies were taken at
         self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
@@ -582,17 +584,41 @@ class DiffusionEngine:
         if plan is None:  # 2 T + 2 launches on static buffers: record once, replay for every user batch and epoch
             with L.Recorder() as plan:
                 cur, nxt, cur16, nxt16, h16 = self.xa[:B], self.xb[:B], self.xa16[:B], self.xb16[:B], self.h16[:B]
-                I8 = self.I8  # K of layer 1: the item columns only (rounded up to 8, pad columns zero); temb enters through the bias table
-                ops.zero_(nxt16)
-                ops.cast_bf16(cur, cur16, cols=I, cols_pad=I8)
+                ops.zero_(nxt16)  # temb / pad columns of both ping-pong operands stay zero: temb enters through the bias table
+                ops.cast_bf16(cur, cur16, cols=I, cols_pad=self.Kp)
                 b2 = P.view("out_layers.0.bias")
                 for i in range(self.T - 1, -1, -1):
-                    ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH, K=I8)
+                    ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
                     ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
             self._chain_plans[(m, B)] = plan
         L.replay(plan)
         return (self.xa if self.T % 2 == 0 else self.xb)[:B, :I]
+
+    def generate_views_bf16(self, x0: Tensor) -> List[Tensor]:
+        """All modalities' reverse chains advanced together: per timestep two batched launches (M problems each)."""
+        B, I, M = x0.shape[0], self.I, self.M
+        for m in range(M):
+            self._refresh_bf16_weights(m)
+            self.cxa[m][:B, :I].copy_(x0)
+        plan = self._chain_plans.get(("all", B))
+        if plan is None:
+            with L.Recorder() as plan:
+                cur, nxt = [t[:B] for t in self.cxa], [t[:B] for t in self.cxb]
+                cur16, nxt16, h16 = [t[:B] for t in self.cxa16], [t[:B] for t in self.cxb16], [t[:B] for t in self.ch16]
+                for m in range(M):
+                    ops.zero_(nxt16[m])
+                    ops.cast_bf16(cur[m], cur16[m], cols=I, cols_pad=self.Kp)  # item columns; the temb / pad columns are zero (bias table)
+                for i in range(self.T - 1, -1, -1):
+                    ops.gemm_bf16_nt_batched([dict(A=cur16[m], B=self.w1_16[m], out_bf16=h16[m], bias=self.bias_t[m][i], act=L.ACT_TANH)
+                                              for m in range(M)])
+                    ops.gemm_bf16_nt_batched([dict(A=h16[m], B=self.w2_16[m], out=nxt[m], out_bf16=nxt16[m], bias=self.P[m].view("out_layers.0.bias"),
+                                                   residual=cur[m], e1=float(self.c1[i]), e2=float(self.c2[i]), N=I) for m in range(M)])
+                    cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
+            self._chain_plans[("all", B)] = plan
+        L.replay(plan)
+        fin = self.cxa if self.T % 2 == 0 else self.cxb
+        return [fin[m][:B, :I] for m in range(M)]
 
     def generate_view(self, m: int, x0: Tensor, precision: int = 1) -> Tensor:
         """sampling_step == 0 path: x_T = x0, then T deterministic posterior-mean steps.  Returns a [B, I] view (ld = Kp)."""
@@ -624,6 +650,11 @@ class DiffusionEngine:
             if i % self.world != self.rank:  # user chunks are sharded over the replicas (dist.shard_owner)
                 continue
             x0 = dense_rows(ub)
+            if precision == 1:
+                views = self.generate_views_bf16(x0)
+                for m in range(self.M):
+                    ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
+                continue
             for m in range(self.M):
                 den = self.generate_view(m, x0, precision)
                 ops.topk_rows(den, ub.to(torch.int32), deg_ptr, out[m], self.I)

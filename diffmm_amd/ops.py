@@ -128,10 +128,9 @@ def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = 
     return out
 
 
-def gemm_bf16_nt(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, *, bias: Optional[Tensor] = None,
-                 act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
-                 N: Optional[int] = None, K: Optional[int] = None) -> None:
-    """out[M,N] (fp32) and/or out_bf16 = post(act(alpha * A B^T + bias)); A [M,K], B [N,K] bf16, row-strided views allowed."""
+def _bf16_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, *, bias: Optional[Tensor] = None,
+               act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
+               N: Optional[int] = None, K: Optional[int] = None) -> "L.GemmBf16Args":
     for nm, t in (("A", A), ("B", B)):
         if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
             raise ValueError(f"gemm_bf16_nt {nm}: need a 2-D bfloat16 tensor with unit inner stride")
@@ -158,7 +157,19 @@ def gemm_bf16_nt(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: O
             raise ValueError("gemm_bf16_nt residual: bad shape / dtype / stride")
         g.R, g.ldr = L.ptr(residual), residual.stride(0)
     g.M, g.N, g.K, g.alpha, g.e1, g.e2, g.act = m, n, k, alpha, e1, e2, act
+    return g
+
+
+def gemm_bf16_nt(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, **kw) -> None:
+    """out[M,N] (fp32) and/or out_bf16 = post(act(alpha * A B^T + bias)); A [M,K], B [N,K] bf16, row-strided views allowed."""
+    g = _bf16_args(A, B, out, out_bf16, **kw)
     L.call("dmm_gemm_bf16_nt", C.byref(g), L.stream())
+
+
+def gemm_bf16_nt_batched(problems: Sequence[dict]) -> None:
+    """Up to 4 same-shape problems (dicts of gemm_bf16_nt keyword arguments incl. A, B) in one launch."""
+    arr = (L.GemmBf16Args * len(problems))(*[_bf16_args(**p) for p in problems])
+    L.call("dmm_gemm_bf16_nt_batched", arr, len(problems), L.stream())
 
 
 def cast_bf16(src: Tensor, dst: Tensor, cols: Optional[int] = None, cols_pad: Optional[int] = None) -> None:

@@ -110,6 +110,8 @@ typedef struct dmm_gemm_bf16_args {
   int32_t act;
 } dmm_gemm_bf16_args;
 int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a /*host*/, void* stream);
+/* up to 4 problems of one shape in one launch (the modalities' chains advance together: enough tiles for 256 x 128 workgroup tiles) */
+int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* a /*host array*/, int n_batch, void* stream);
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
 int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream);

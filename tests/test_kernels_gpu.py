@@ -172,6 +172,31 @@ def test_gemm_bf16_nt(dev, M, N, K):
     assert torch.equal(out[:, :N].cpu().double(), Ai.double() @ Bi.double().t()), "integer GEMM must be exact"
 
 
+def test_gemm_bf16_big_tile_and_batched(dev):
+    """Shapes that select the 256 x 128 / 8-wave tile (>= 768 tiles), ragged in M and N, and 3 problems in one launch."""
+    from diffmm_amd import ops, _lib as L
+    rng = np.random.default_rng(5)
+    M, N, K = 2500, 1030, 520
+    probs, refs = [], []
+    for z in range(3):
+        A = (torch.arange(M * K).view(M, K) % (11 + z) - 5).float().bfloat16()
+        Bw = (torch.arange(N * K).view(N, K) % (5 + z) - 2).float().bfloat16()
+        bias = T(rng.standard_normal(N).astype(np.float32)); R = T(rng.standard_normal((M, N + 2)).astype(np.float32))
+        out = torch.zeros(M, N + 2, device=dev); out16 = torch.zeros(M, N + 2, dtype=torch.bfloat16, device=dev)
+        probs.append(dict(A=A.to(dev), B=Bw.to(dev), out=out, out_bf16=out16, bias=bias.to(dev), residual=R.to(dev), e1=0.25, e2=2.0, N=N))
+        refs.append(0.25 * (A.double() @ Bw.double().t() + bias.double()) + 2.0 * R[:, :N].double())
+    ops.gemm_bf16_nt_batched(probs)   # 3 x 10 x 9 tiles of 256x128 = 270 -> 128x128 kernel; force the big tile through a larger batch below
+    for p, r in zip(probs, refs):
+        close(p["out"][:, :N], r, rtol=1e-6, atol=1e-3, what="batched")
+    M2, N2 = 9308, 1024
+    A = (torch.randn(M2, 128)).bfloat16(); Bw = (torch.randn(N2, 128)).bfloat16()
+    outs = [torch.zeros(M2, N2, device=dev) for _ in range(3)]
+    ops.gemm_bf16_nt_batched([dict(A=A.to(dev), B=Bw.to(dev), out=o) for o in outs])  # 3 * 37 * 8 = 888 tiles: the 256x128 kernel
+    ref = A.double() @ Bw.double().t()
+    for o in outs:
+        close(o, ref, rtol=1e-5, atol=1e-3, what="big tile")
+
+
 def test_gemm_asymmetric_identity_and_strided_views(dev):
     from diffmm_amd import ops
     n = 96
