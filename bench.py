@@ -36,7 +36,7 @@ def make_coach(args, rank: int, world: int):
     from diffmm_amd.DataHandler import DataHandler
     from diffmm_amd.Main import Coach, seed_it
     cfg = load_config(os.path.join(REPO, "conf", "tiktok.toml"))
-    cfg.base.gpu = str(int(os.environ.get("LOCAL_RANK", 0)))
+    cfg.base.gpu = str(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
     cfg.base.latdim, cfg.hyper.steps, cfg.train.batch = args.latdim, args.T, args.batch
     cfg.data.name = args.workload
     seed_it(cfg.base.seed)
@@ -69,25 +69,31 @@ def roofline(coach, args):
     P = DE.P[0]
     x, h = DE.xa[:B], DE.dh[:B]
     x.normal_()
-    if args.precision == 1:  # the reverse chain's dedicated bf16 kernel, random operands
-        DE._refresh_bf16_weights(0)
-        x16, h16 = DE.xa16[:B], DE.h16[:B]
-        ops.cast_bf16(x, x16)
-        t1 = timed_launches(lambda: ops.gemm_bf16_nt(x16, DE.w1_16[0], out_bf16=h16, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH), 20)
-        t2 = timed_launches(lambda: ops.gemm_bf16_nt(h16, DE.w2_16[0], out=DE.xb[:B], out_bf16=DE.xb16[:B], bias=P.view("out_layers.0.bias"),
-                                                     residual=x, e1=0.5, e2=0.5, N=I), 20)
+    rows, nb = B, 1
+    if args.precision == 1:  # the launches the reverse chain really issues: all modalities batched, all users (chain_rows), random operands
+        M = DE.M
+        rows, nb = min(DE.chain_rows, coach.handler.graph.users), M
+        for m in range(M):
+            DE._refresh_bf16_weights(m)
+            DE.cxa[m][:rows].normal_()
+            ops.cast_bf16(DE.cxa[m][:rows], DE.cxa16[m][:rows])
+        t1 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.cxa16[m][:rows], B=DE.w1_16[m], out_bf16=DE.ch16[m][:rows], bias=DE.bias_t[m][0],
+                                                                   act=L.ACT_TANH) for m in range(M)]), 10)
+        t2 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.ch16[m][:rows], B=DE.w2_16[m], out=DE.cxb[m][:rows], out_bf16=DE.cxb16[m][:rows],
+                                                                   bias=DE.P[m].view("out_layers.0.bias"), residual=DE.cxa[m][:rows], e1=0.5, e2=0.5, N=I)
+                                                              for m in range(M)]), 10)
     else:
         t1 = timed_launches(lambda: ops.gemm(x, P.view("in_layers.0.weight"), out=h, trans_b=True, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH,
                                              precision=args.precision), 20)
         t2 = timed_launches(lambda: ops.gemm(h, P.view("out_layers.0.weight"), out=DE.xb[:B], trans_b=True, bias=P.view("out_layers.0.bias"),
                                              precision=args.precision, N=I, residual=x, e1=0.5, e2=0.5), 20)
-    flops1 = 2.0 * B * Kp * H * (3 if args.precision == 3 else 1)
-    flops2 = 2.0 * B * H * I * (3 if args.precision == 3 else 1)
+    flops1 = 2.0 * rows * nb * Kp * H * (3 if args.precision == 3 else 1)
+    flops2 = 2.0 * rows * nb * H * I * (3 if args.precision == 3 else 1)
     A = J.adj
     emb = J.P.view("emb")
     ts = timed_launches(lambda: ops.spmm_batched([ops.SpmmOp(A, emb, y=J.Bx)]), 50)
     sb = A.algorithmic_bytes(4)
-    gemm = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel: Denoise layer 1 of the reverse chain (B x (I+te) x H)", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
+    gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_kernel: Denoise layer 1 of the reverse chain, {nb} modalities x ({rows} x {Kp}) x ({H} x {Kp})^T per launch", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
             "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6,
             "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6}
     spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -95,9 +101,9 @@ def roofline(coach, args):
     try:  # HBM-side traffic per launch from the committed PMC passes (profiles/README.md); bench.py itself cannot run rocprofv3
         pmc = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")))
         if args.precision == 1 and args.batch == 4096 and args.workload == "tiktok":
-            gemm["traffic"] = pmc["gemm_bf16_nt_layer1"]["traffic_bytes"]
-            gemm["traffic_note"] = "bytes/launch, fabric side (Infinity-Cache hits included), profiles/r1_pmc_traffic.json"
             spmm["traffic"] = pmc["spmm_kernel_64"]["traffic_bytes"]
+            gemm["traffic_note"] = ("PMC passes were taken on the single-problem 4096-row launch (463 MB fabric-side per launch vs 77 MB algorithmic, "
+                                    "L2 hit rate 33 % on the batched launch): profiles/r1_pmc_traffic.json, profiles/README.md")
     except Exception:
         pass
     return gemm, spmm
@@ -156,14 +162,15 @@ def main():
     ap.add_argument("--workload", default="tiktok"); ap.add_argument("--T", type=int, default=40); ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--latdim", type=int, default=64); ap.add_argument("--precision", type=int, default=1, choices=(1, 3))
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
+        dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
     coach, h, cfg = make_coach(args, rank, world)
     n_diff, n_joint = len(h.diffusionLoader), len(h.trainLoader)
     iters_per_epoch = n_diff + n_joint
@@ -190,6 +197,13 @@ def main():
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    replicas_identical = None
+    if world > 1:  # data-parallel replicas must hold bit-identical weights after the same sequence of averaged updates
+        import torch.distributed as dist
+        flat = torch.cat([coach.model.engine.P.data] + [p.data for p in coach.diff_engine.P])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
     if rank != 0:
         return
     out = {"metric": "BPR+diffusion train iters/sec on TikTok d=64 T=40", "value": iters_per_epoch * args.steps / dt, "unit": "iters/s",
@@ -200,6 +214,8 @@ def main():
                                   f"d={args.latdim}, T={args.T}, batch={args.batch}; step = 1 epoch = {n_diff} diffusion iters + rebuild + {n_joint} joint iters",
                       "parallelism": f"dp{world}", "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
                       "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3}}}
+    if replicas_identical is not None:
+        out["replicas_identical"] = replicas_identical
     if not args.no_roofline:
         g, s = roofline(coach, args)
         out["roofline"], out["roofline_spmm"] = g, s

@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
 
 class GemmBf16Args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
-                ("Cb", C.c_void_p), ("ldcb", C.c_int64), ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64),
+                ("Cb", C.c_void_p), ("ldcb", C.c_int64), ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64), ("Rb", C.c_void_p), ("ldrb", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("alpha", C.c_float), ("e1", C.c_float), ("e2", C.c_float),
                 ("act", C.c_int32)]
 

@@ -26,6 +26,7 @@ struct GemmBf16P {
   __bf16* Cb; long long ldcb;
   const float* bias;
   const float* R; long long ldr;
+  const __bf16* Rb; long long ldrb;  // residual given in bf16 (alternative to R)
   int M, N, K;
   float alpha, e1, e2;
   int act;
@@ -73,6 +74,119 @@ __device__ __forceinline__ void s_store(const uint4 (&v)[ROWS * 8 / NTHR], char*
   const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 #pragma unroll
   for (int i = 0; i < ROWS * 8 / NTHR; ++i) *reinterpret_cast<uint4*>(tile + swz(r0 + (NTHR / 8) * i, c)) = v[i];
+}
+
+// One K tile (BK = 64 = 4 MFMA k-steps) of a wave's 64 x (32 NT) output: the fragments of k-step ks+1 are read from LDS while
+// the MFMAs of k-step ks run (two fragment register sets), and the interleave is pinned for the scheduler: without it the
+// compiler reuses one register set and parks the wave on lgkmcnt(0) in front of every MFMA group.
+template <int NT>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][NT], const char* a_t, const char* b_t, int arow, int brow, int fh) {
+  bf16x8 fa[2][2], fb[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(a_t + swz(arow + i * 32, fh));
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(b_t + swz(brow + j * 32, fh));
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // k-step 0's reads
+#pragma unroll
+  for (int ks = 0; ks < GB_BK / 16; ++ks) {
+    const int cb = ks & 1, nb = cb ^ 1;
+    if (ks + 1 < GB_BK / 16) {
+      const int chunk = (ks + 1) * 2 + fh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[nb][i] = *reinterpret_cast<const bf16x8*>(a_t + swz(arow + i * 32, chunk));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[nb][j] = *reinterpret_cast<const bf16x8*>(b_t + swz(brow + j * 32, chunk));
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // the next step's DS reads first ...
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][i], fb[cb][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 2 * NT, 0);        // ... then this step's MFMAs
+  }
+}
+
+template <int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmBf16P& P, f32x16 (&acc)[2][BN / 64], char* smem, int m0, int n0, int wave, int lane) {
+  constexpr int WN = BN / 2, NT = WN / 32;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  // ---- epilogue: every wave transposes its accumulators through its OWN LDS slab (the staging buffers are free after the last
+  // barrier; 32 rows x WN floats per pass, so no workgroup barrier is needed) and then each lane handles 4 consecutive columns:
+  // 16-byte residual loads and fp32 stores, 8-byte bf16 stores.
+  float* tile = reinterpret_cast<float*>(smem) + wave * 32 * WN;
+  constexpr int C4 = WN / 4;       // float4 chunks per tile row
+  constexpr int ITER = 32 * C4 / 64;  // chunks per lane per 32-row pass
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const bool vec_ok = (!P.C || (P.ldc % 4 == 0 && ((uintptr_t)P.C & 15) == 0)) &&
+                      (!P.R || (P.ldr % 4 == 0 && ((uintptr_t)P.R & 15) == 0)) && (!P.Cb || (P.ldcb % 4 == 0 && ((uintptr_t)P.Cb & 7) == 0)) &&
+                      (!P.Rb || (P.ldrb % 4 == 0 && ((uintptr_t)P.Rb & 7) == 0));
+  const bool has_r = P.R || P.Rb;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // residual rows are requested first so their latency overlaps the LDS transpose below
+    float4 rr[ITER];
+    if (has_r && vec_ok) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = it * 64 + lane;
+        const int m = m0 + wm * 64 + i * 32 + idx / C4, n = n0 + wn * WN + (idx % C4) * 4;
+        rr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < P.M && n + 3 < P.N) {
+          if (P.R) {
+            rr[it] = *reinterpret_cast<const float4*>(P.R + (long long)m * P.ldr + n);
+          } else {
+            const bf16x4 b = *reinterpret_cast<const bf16x4*>(P.Rb + (long long)m * P.ldrb + n);
+            rr[it] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (DS ops of a wave complete in order)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / C4, c4 = idx % C4;
+      const int m = m0 + wm * 64 + i * 32 + row, n = n0 + wn * WN + c4 * 4;
+      if (m >= P.M || n >= P.N) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(tile + row * WN + c4 * 4);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      const int nv = min(4, P.N - n);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < nv) {
+          float x = P.alpha * v[u] + (P.bias ? P.bias[n + u] : 0.f);
+          if (P.act == DMM_ACT_TANH) x = tanhf(x);
+          else if (P.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+          v[u] = x;
+        }
+      }
+      if (nv == 4 && vec_ok) {
+        if (has_r) {
+          const float4 r4 = rr[it];
+          v[0] = P.e1 * v[0] + P.e2 * r4.x; v[1] = P.e1 * v[1] + P.e2 * r4.y; v[2] = P.e1 * v[2] + P.e2 * r4.z; v[3] = P.e1 * v[3] + P.e2 * r4.w;
+        }
+        if (P.C) *reinterpret_cast<float4*>(P.C + (long long)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (P.Cb) {
+          *reinterpret_cast<bf16x4*>(P.Cb + (long long)m * P.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+      } else {
+        for (int u = 0; u < nv; ++u) {
+          float x = v[u];
+          if (P.R) x = P.e1 * x + P.e2 * P.R[(long long)m * P.ldr + n + u];
+          else if (P.Rb) x = P.e1 * x + P.e2 * (float)P.Rb[(long long)m * P.ldrb + n + u];
+          if (P.C) P.C[(long long)m * P.ldc + n + u] = x;
+          if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)x;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // the pass's LDS reads are done before the next pass overwrites the slab
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // BM x BN output tile; waves are arranged (BM / 64) x 2, every wave owns 64 x (BN / 2) outputs (2 x NT MFMA tiles of 32 x 32).
@@ -126,21 +240,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_kernel(const GemmBf16Batc
   // in flight -- a load has two tiles of MFMA work (~1000+ cycles) to land before it is written to LDS.  The loop is unrolled by
   // two so that both register sets keep static names (runtime-indexed register arrays would go to scratch).
   uint4 ra0[BM * 8 / NTHR], rb0[BN * 8 / NTHR], ra1[BM * 8 / NTHR], rb1[BN * 8 / NTHR];
-  auto compute = [&](const char* a_t, const char* b_t) {
-#pragma unroll
-    for (int ks = 0; ks < GB_BK / 16; ++ks) {
-      const int chunk = ks * 2 + fh;
-      bf16x8 fa[2], fb[NT];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a_t + swz(wm * 64 + i * 32 + fr, chunk));
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b_t + swz(wn * WN + j * 32 + fr, chunk));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  };
+  auto compute = [&](const char* a_t, const char* b_t) { mma_tile<NT>(acc, a_t, b_t, wm * 64 + fr, wn * WN + fr, fh); };
   char* const buf0 = smem;
   char* const buf1 = smem + STAGE;
   g_load<BM, NTHR>(ra0, P.A, P.lda, m0, P.M, 0, P.K, edge_a);
@@ -174,72 +274,118 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_kernel(const GemmBf16Batc
   if (kt < nk) compute(buf0, buf0 + A_BYTES);  // odd tile count: the last tile sits in buffer 0
   __syncthreads();  // every wave is done with the staging buffers before the epilogue reuses them
 
-  // ---- epilogue: every wave transposes its accumulators through its OWN LDS slab (the staging buffers are free after the last
-  // barrier; 32 rows x WN floats per pass, so no workgroup barrier is needed) and then each lane handles 4 consecutive columns:
-  // 16-byte residual loads and fp32 stores, 8-byte bf16 stores.
-  float* tile = reinterpret_cast<float*>(smem) + wave * 32 * WN;
-  constexpr int C4 = WN / 4;       // float4 chunks per tile row
-  constexpr int ITER = 32 * C4 / 64;  // chunks per lane per 32-row pass
-  const bool vec_ok = (!P.C || (P.ldc % 4 == 0 && ((uintptr_t)P.C & 15) == 0)) &&
-                      (!P.R || (P.ldr % 4 == 0 && ((uintptr_t)P.R & 15) == 0)) && (!P.Cb || (P.ldcb % 4 == 0 && ((uintptr_t)P.Cb & 7) == 0));
+  gemm_epilogue<BN>(P, acc, smem, m0, n0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Variant with direct global -> LDS staging (global_load_lds_dwordx4, "LDS-DMA"): no staging VGPRs and no ds_write instructions
+// (whose VGPR -> LDS transfer is ~13 cycles per wave-instruction and shares the LDS pipe with the fragment reads).
+// One wave-instruction fills 8 tile rows (1 KiB, lane-linear in LDS); the XOR swizzle is applied on the per-lane SOURCE address.
+// Requires K % 64 == 0 (out-of-range ROWS read clamped addresses; their outputs are discarded by the epilogue).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, long long ld, int row0, int rows, int k0, char* tile, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    // residual rows are requested first so their latency overlaps the LDS transpose below
-    float4 rr[ITER];
-    if (P.R && vec_ok) {
+  for (int g = wave; g < ROWS / 8; g += NWAVES) {
+    const int r = 8 * g + (lane >> 3);          // tile row this lane fills
+    const int c = (lane & 7) ^ ((r >> 1) & 7);  // source chunk that belongs at LDS chunk (lane & 7) of that row
+    const int gr = row0 + r < rows ? row0 + r : rows - 1;
+    const __bf16* src = base + (long long)gr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(tile + g * 1024), 16, 0, 0);
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_glds_kernel(const GemmBf16Batch batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = BM / 32;  // waves
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int WN = BN / 2, NT = WN / 32;
+  const GemmBf16P& P = batch.p[blockIdx.y];
+  const int mtile = blockIdx.x / P.nt, ntile = blockIdx.x % P.nt;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int nk = P.K / GB_BK;
+  f32x16 acc[2][NT];
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int idx = it * 64 + lane;
-        const int m = m0 + wm * 64 + i * 32 + idx / C4, n = n0 + wn * WN + (idx % C4) * 4;
-        rr[it] = (m < P.M && n + 3 < P.N) ? *reinterpret_cast<const float4*>(P.R + (long long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (DS ops of a wave complete in order)
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / C4, c4 = idx % C4;
-      const int m = m0 + wm * 64 + i * 32 + row, n = n0 + wn * WN + c4 * 4;
-      if (m >= P.M || n >= P.N) continue;
-      const float4 a4 = *reinterpret_cast<const float4*>(tile + row * WN + c4 * 4);
-      float v[4] = {a4.x, a4.y, a4.z, a4.w};
-      const int nv = min(4, P.N - n);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u < nv) {
-          float x = P.alpha * v[u] + (P.bias ? P.bias[n + u] : 0.f);
-          if (P.act == DMM_ACT_TANH) x = tanhf(x);
-          else if (P.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
-          v[u] = x;
-        }
-      }
-      if (nv == 4 && vec_ok) {
-        if (P.R) {
-          const float4 r4 = rr[it];
-          v[0] = P.e1 * v[0] + P.e2 * r4.x; v[1] = P.e1 * v[1] + P.e2 * r4.y; v[2] = P.e1 * v[2] + P.e2 * r4.z; v[3] = P.e1 * v[3] + P.e2 * r4.w;
-        }
-        if (P.C) *reinterpret_cast<float4*>(P.C + (long long)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (P.Cb) {
-          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-          *reinterpret_cast<bf16x4*>(P.Cb + (long long)m * P.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        }
-      } else {
-        for (int u = 0; u < nv; ++u) {
-          float x = v[u];
-          if (P.R) x = P.e1 * x + P.e2 * P.R[(long long)m * P.ldr + n + u];
-          if (P.C) P.C[(long long)m * P.ldc + n + u] = x;
-          if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)x;
-        }
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  glds_tile<BM, NW>(P.A, P.lda, m0, P.M, 0, smem, wave, lane);
+  glds_tile<BN, NW>(P.B, P.ldb, n0, P.N, 0, smem + A_BYTES, wave, lane);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* a_t = smem + cur * STAGE;
+    char* b_t = a_t + A_BYTES;
+    if (kt + 1 < nk) {
+      glds_tile<BM, NW>(P.A, P.lda, m0, P.M, (kt + 1) * GB_BK, smem + (cur ^ 1) * STAGE, wave, lane);
+      glds_tile<BN, NW>(P.B, P.ldb, n0, P.N, (kt + 1) * GB_BK, smem + (cur ^ 1) * STAGE + A_BYTES, wave, lane);
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // the pass's LDS reads are done before the next pass overwrites the slab
-    __builtin_amdgcn_wave_barrier();
+    mma_tile<NT>(acc, a_t, b_t, wm * 64 + fr, wn * WN + fr, fh);
+    __syncthreads();  // hipcc drains the pending LDS-DMA (vmcnt(0)) in front of this barrier
+    cur ^= 1;
   }
+  gemm_epilogue<BN>(P, acc, smem, m0, n0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LDS-ring variant: 256 x 128 tile, 8 waves (two per SIMD), BK = 64, THREE 48 KiB stages filled by LDS-DMA.  Two K tiles are in
+// flight while a third is being multiplied: a load has two full MFMA phases to land.  hipcc neither counts LDS-DMA completion at
+// a ds_read nor may a __syncthreads() be used (it would drain the ring), so ordering is explicit:
+//     s_waitcnt vmcnt(GL)   -- this wave's part of tile kt has landed (the GL loads of tile kt+1 may still be in flight)
+//     s_barrier             -- (RAW) every wave's part of tile kt has landed; (WAR) every wave finished reading tile kt-1
+//     issue tile kt+2 into the stage tile kt-1 occupied;  ds_read + MFMA on tile kt
+// Loads past the last tile are still issued (clamped addresses, a free stage) so the count GL per tile is a constant.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_ring_kernel(const GemmBf16Batch batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = BM / 32;  // 3 stages
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int GL = (BM / 8 + BN / 8) / NW;  // LDS-DMA instructions per wave per K tile
+  constexpr int WN = BN / 2, NT = WN / 32;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "row groups must divide evenly over the waves");
+  const GemmBf16P& P = batch.p[blockIdx.y];
+  const int mtile = blockIdx.x / P.nt, ntile = blockIdx.x % P.nt;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int nk = P.K / GB_BK;
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto issue = [&](int kt, int stage) {
+    const int k0 = (kt < nk ? kt : 0) * GB_BK;  // past the end: re-read tile 0 into a stage nobody reads any more
+    glds_tile<BM, NW>(P.A, P.lda, m0, P.M, k0, smem + stage * STAGE, wave, lane);
+    glds_tile<BN, NW>(P.B, P.ldb, n0, P.N, k0, smem + stage * STAGE + A_BYTES, wave, lane);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  int st = 0;  // stage of tile kt
+  for (int kt = 0; kt < nk; ++kt) {
+    if (GL == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if (GL == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nst = st == 0 ? 2 : st - 1;  // stage of tile kt-1 == stage of tile kt+2
+    issue(kt + 2, nst);
+    const char* a_t = smem + st * STAGE;
+    const char* b_t = a_t + A_BYTES;
+    mma_tile<NT>(acc, a_t, b_t, wm * 64 + fr, wn * WN + fr, fh);
+    st = st == 2 ? 0 : st + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ring drained, every wave done reading: LDS is free
+  gemm_epilogue<BN>(P, acc, smem, m0, n0, wave, lane);
 }
 
 // fp32 [rows, cols] (ld lds) -> bf16 (ld ldd); columns cols..cols_pad are zero-filled
@@ -349,6 +495,28 @@ static void launch_tile(const GemmBf16Batch& b, int blocks, hipStream_t s) {
     return true;
   }();
   (void)once;
+  static const int use_glds = [] { const char* e = getenv("DMM_GEMM_GLDS"); return e ? atoi(e) : 0; }();  // 1: 2-stage LDS-DMA, 2: 3-stage ring
+  if constexpr (BM == 256) {
+    if (use_glds == 2 && b.p[0].K % GB_BK == 0 && b.p[0].K >= 2 * GB_BK && b.p[0].part == 0) {
+      constexpr int RING = 3 * (BM + BN) * 128;
+      static bool once3 = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_ring_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, RING);
+        return true;
+      }();
+      (void)once3;
+      hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<BM, BN>), dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(BM * 2), RING, s, b);
+      return;
+    }
+  }
+  if (use_glds == 1 && b.p[0].K % GB_BK == 0 && b.p[0].part == 0) {
+    static bool once2 = [] {
+      if (LDS > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_glds_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      return true;
+    }();
+    (void)once2;
+    hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<BM, BN>), dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(BM * 2), LDS, s, b);
+    return;
+  }
   hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(blocks, b.n), dim3(BM * 2), LDS, s, b);
 }
 
@@ -368,7 +536,7 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
     GemmBf16P& P = b.p[i];
     P.A = (const __bf16*)a->A; P.lda = a->lda; P.B = (const __bf16*)a->B; P.ldb = a->ldb;
     P.C = a->C; P.ldc = a->ldc; P.Cb = (__bf16*)a->Cb; P.ldcb = a->ldcb;
-    P.bias = a->bias; P.R = a->R; P.ldr = a->ldr; P.M = a->M; P.N = a->N; P.K = a->K;
+    P.bias = a->bias; P.R = a->R; P.ldr = a->ldr; P.Rb = (const __bf16*)a->Rb; P.ldrb = a->ldrb; P.M = a->M; P.N = a->N; P.K = a->K;
     P.alpha = a->alpha; P.e1 = a->e1; P.e2 = a->e2; P.act = a->act;
   }
   static const int force_tile = [] { const char* e = getenv("DMM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning knobs: 64 / 128 / 256
@@ -382,7 +550,7 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   // XCD-contiguous placement pays only when the operands overflow the 256 MiB Infinity Cache (measured: +-3 % on the 70 MB
   // chain shapes, where grid order is kept); then the XCDs split the dimension of the larger operand.
   int part = 0;
-  if (((long long)M + N) * a0->K * 2 > (192ll << 20)) part = M >= N ? (mt >= 8 ? 1 : 0) : (nt >= 8 ? 2 : 0);
+  if (((long long)M + N) * a0->K * 2 * n_batch > (192ll << 20)) part = M >= N ? (mt >= 8 ? 1 : 0) : (nt >= 8 ? 2 : 0);
   if (force_part >= 0) part = force_part;
   int blocks = mt * nt;
   if (part == 1) {

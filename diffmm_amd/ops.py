@@ -130,7 +130,7 @@ def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = 
 
 def _bf16_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, *, bias: Optional[Tensor] = None,
                act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
-               N: Optional[int] = None, K: Optional[int] = None) -> "L.GemmBf16Args":
+               N: Optional[int] = None, K: Optional[int] = None, residual_bf16: Optional[Tensor] = None) -> "L.GemmBf16Args":
     for nm, t in (("A", A), ("B", B)):
         if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
             raise ValueError(f"gemm_bf16_nt {nm}: need a 2-D bfloat16 tensor with unit inner stride")
@@ -156,6 +156,10 @@ def _bf16_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Opt
         if residual.dtype != torch.float32 or residual.stride(1) != 1 or residual.shape[0] < m or residual.shape[1] < n:
             raise ValueError("gemm_bf16_nt residual: bad shape / dtype / stride")
         g.R, g.ldr = L.ptr(residual), residual.stride(0)
+    if residual_bf16 is not None:
+        if residual is not None or residual_bf16.dtype != torch.bfloat16 or residual_bf16.stride(1) != 1 or residual_bf16.shape[0] < m or residual_bf16.shape[1] < n:
+            raise ValueError("gemm_bf16_nt residual_bf16: bad shape / dtype / stride (and exclusive with residual)")
+        g.Rb, g.ldrb = L.ptr(residual_bf16), residual_bf16.stride(0)
     g.M, g.N, g.K, g.alpha, g.e1, g.e2, g.act = m, n, k, alpha, e1, e2, act
     return g
 

@@ -105,6 +105,7 @@ typedef struct dmm_gemm_bf16_args {
   void* Cb; int64_t ldcb;
   const float* bias;
   const float* R; int64_t ldr;
+  const void* Rb; int64_t ldrb; /* residual in bf16 (used when R is NULL) */
   int32_t M, N, K;
   float alpha, e1, e2;
   int32_t act;

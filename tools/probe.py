@@ -29,6 +29,15 @@ if "gemm" in sys.argv or len(sys.argv) == 1:
     for K in (2048, 4096):
         hk = torch.randn(B, K, device=dev).bfloat16(); wk = torch.randn(I, K, device=dev).bfloat16() * 0.02
         t = timed(lambda: ops.gemm_bf16_nt(hk, wk, out_bf16=c16, N=I)); out[f"L2-shape K={K} bf16-out"] = (t, 2.0 * B * K * I / t / 1e6)
+    Mc = 9308  # the reverse chain's real launches: 3 modalities batched, all users
+    xs = [torch.randn(Mc, Kp, device=dev).bfloat16() for _ in range(3)]; hs = [torch.randn(Mc, H, device=dev).bfloat16() for _ in range(3)]
+    hbs = [torch.zeros(Mc, H, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    cs = [torch.zeros(Mc, Kp, device=dev) for _ in range(3)]; rs = [torch.randn(Mc, Kp, device=dev) for _ in range(3)]
+    c16s = [torch.zeros(Mc, Kp, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    t = timed(lambda: ops.gemm_bf16_nt_batched([dict(A=xs[m], B=w1, out_bf16=hbs[m], bias=b1, act=L.ACT_TANH) for m in range(3)]), 10)
+    out["chain L1 x3 (M=9308)"] = (t, 3 * 2.0 * Mc * Kp * H / t / 1e6)
+    t = timed(lambda: ops.gemm_bf16_nt_batched([dict(A=hs[m], B=w2, out=cs[m], out_bf16=c16s[m], bias=b2, residual=rs[m], e1=.5, e2=.5, N=I) for m in range(3)]), 10)
+    out["chain L2 x3 (M=9308) full epilogue"] = (t, 3 * 2.0 * Mc * H * I / t / 1e6)
     a = torch.randn(4096, 4096, device=dev).bfloat16(); b = torch.randn(4096, 4096, device=dev).bfloat16(); cc = torch.zeros(4096, 4096, dtype=torch.bfloat16, device=dev)
     t = timed(lambda: ops.gemm_bf16_nt(a, b, out_bf16=cc)); out["4096^3"] = (t, 2.0 * 4096 ** 3 / t / 1e6)
 if "spmm" in sys.argv or len(sys.argv) == 1:
