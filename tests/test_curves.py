@@ -1,0 +1,33 @@
+"""Statistical end-to-end parity on committed measurements: the HIP path's training curves (recorded on an MI355X by
+tools/train_curve.py) against the reference's own run on the same synthetic TikTok-shape data (tests/golden/make_curve.py).
+RNG streams differ between torch-CPU and the GPU kernels, so epochs are compared as means over the plateau (epochs 10..29);
+north_star's bar: Recall@20 within +-0.002 of the reference."""
+import csv
+import os
+import statistics as st
+
+import pytest
+
+B = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "baselines")
+
+
+def _load(name):
+    return list(csv.DictReader(open(os.path.join(B, name))))
+
+
+def _mean(rows, key, a=10, b=30):
+    return st.mean(float(r[key]) for r in rows[a:b])
+
+
+@pytest.mark.parametrize("run", ["hip_synth_tiktok_T5_B1024_seed1818_prec1.csv", "hip_synth_tiktok_T5_B1024_seed1818_prec3.csv",
+                                 "hip_synth_tiktok_T5_B1024_seed7_prec1.csv"])
+def test_training_curve_matches_reference(run):
+    ref, hip = _load("ref_cpu_synth_tiktok_T5_B1024_seed1818.csv"), _load(run)
+    assert len(ref) == 30 and len(hip) == 30
+    assert abs(_mean(hip, "Recall") - _mean(ref, "Recall")) <= 0.002
+    assert abs(_mean(hip, "NDCG") - _mean(ref, "NDCG")) <= 0.002
+    for key in ("Loss", "BPR Loss", "CL loss", "reg loss"):
+        r, h = _mean(ref, key), _mean(hip, key)
+        assert abs(h - r) <= 0.01 * abs(r), f"{key}: reference {r:.5f} vs HIP {h:.5f}"
+    # the loss keeps decreasing like the reference's
+    assert float(hip[-1]["Loss"]) < float(hip[5]["Loss"]) < float(hip[0]["Loss"])
