@@ -22,7 +22,7 @@ class SpmmProblem(C.Structure):
     _fields_ = [("tasks", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("x_lo", C.c_void_p), ("x_hi", C.c_void_p),
                 ("y", C.c_void_p), ("c1", C.c_void_p), ("c2", C.c_void_p), ("y_pert", C.c_void_p), ("noise", C.c_void_p),
                 ("y_mean", C.c_void_p), ("m1", C.c_void_p), ("m2", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
-                ("n_rows", C.c_int32), ("n_tasks", C.c_int32), ("n_head_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
+                ("partial", C.c_void_p), ("fix", C.c_void_p), ("n_partial_blocks", C.c_int32), ("n_fix", C.c_int32), ("n_rows", C.c_int32), ("n_tasks", C.c_int32), ("n_head_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
                 ("noise_degree", C.c_float)]
 
 

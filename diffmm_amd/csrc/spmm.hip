@@ -34,6 +34,44 @@ struct SpmmBatch {
 };
 
 template <int D>
+__device__ __forceinline__ void spmm_epilogue(const dmm_spmm_problem& P, int row, int l, float4 acc) {
+  constexpr int LANES = D / 4;
+  const size_t off = (size_t)row * D + 4 * l;
+  float4 y = make_float4(P.alpha * acc.x, P.alpha * acc.y, P.alpha * acc.z, P.alpha * acc.w);
+  if (P.c1) {
+    const float4 c = *reinterpret_cast<const float4*>(P.c1 + off);
+    y.x = fmaf(P.beta, c.x, y.x); y.y = fmaf(P.beta, c.y, y.y); y.z = fmaf(P.beta, c.z, y.z); y.w = fmaf(P.beta, c.w, y.w);
+  }
+  if (P.c2) {
+    const float4 c = *reinterpret_cast<const float4*>(P.c2 + off);
+    y.x = fmaf(P.gamma, c.x, y.x); y.y = fmaf(P.gamma, c.y, y.y); y.z = fmaf(P.gamma, c.z, y.z); y.w = fmaf(P.gamma, c.w, y.w);
+  }
+  if (P.y) *reinterpret_cast<float4*>(P.y + off) = y;
+  if (P.y_pert) {
+    float4 n;
+    if (P.noise) {
+      n = *reinterpret_cast<const float4*>(P.noise + off);
+    } else {
+      const uint4 r = philox4(P.seed, P.offset + (unsigned long long)row * LANES + l, 0x5eedu);
+      n = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    }
+    float ss = n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w;
+    ss = group_sum<LANES>(ss);
+    const float sc = P.noise_degree / fmaxf(sqrtf(ss), 1e-12f);
+    float4 yp = make_float4(y.x + sgn(y.x) * (n.x * sc), y.y + sgn(y.y) * (n.y * sc), y.z + sgn(y.z) * (n.z * sc),
+                            y.w + sgn(y.w) * (n.w * sc));
+    *reinterpret_cast<float4*>(P.y_pert + off) = yp;
+    if (P.y_mean) {
+      const float4 a = *reinterpret_cast<const float4*>(P.m1 + off);
+      const float4 b = *reinterpret_cast<const float4*>(P.m2 + off);
+      const float t = 1.0f / 3.0f;
+      *reinterpret_cast<float4*>(P.y_mean + off) =
+          make_float4((yp.x + a.x + b.x) * t, (yp.y + a.y + b.y) * t, (yp.z + a.z + b.z) * t, (yp.w + a.w + b.w) * t);
+    }
+  }
+}
+
+template <int D>
 __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
   constexpr int LANES = D / 4;      // lanes per task group
   constexpr int G = 256 / LANES;    // task groups per workgroup
@@ -108,45 +146,36 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
     acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------
-  const size_t off = (size_t)row * D + 4 * l;
-  float4 y = make_float4(P.alpha * acc.x, P.alpha * acc.y, P.alpha * acc.z, P.alpha * acc.w);
-  if (P.c1) {
-    const float4 c = *reinterpret_cast<const float4*>(P.c1 + off);
-    y.x = fmaf(P.beta, c.x, y.x); y.y = fmaf(P.beta, c.y, y.y); y.z = fmaf(P.beta, c.z, y.z); y.w = fmaf(P.beta, c.w, y.w);
+  if (lb < P.n_partial_blocks) {  // segment of a giant row: park the raw partial row; spmm_fixup_kernel sums the segments in order
+    *reinterpret_cast<float4*>(P.partial + (size_t)lb * D + 4 * l) = acc;
+    return;
   }
-  if (P.c2) {
-    const float4 c = *reinterpret_cast<const float4*>(P.c2 + off);
-    y.x = fmaf(P.gamma, c.x, y.x); y.y = fmaf(P.gamma, c.y, y.y); y.z = fmaf(P.gamma, c.z, y.z); y.w = fmaf(P.gamma, c.w, y.w);
+  spmm_epilogue<D>(P, row, l, acc);
+}
+
+// Rows longer than one workgroup's worth of tasks are cut into segments (one workgroup each, planned first in the task list).
+// This pass adds a row's segment partials in segment order (deterministic) and applies the epilogue.
+template <int D>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) {
+  constexpr int LANES = D / 4, G = 256 / LANES;
+  const dmm_spmm_problem& P = batch.p[blockIdx.y];
+  const int i = blockIdx.x * G + threadIdx.x / LANES, l = threadIdx.x % LANES;
+  if (i >= P.n_fix) return;
+  const int4 f = reinterpret_cast<const int4*>(P.fix)[i];  // {row, first_slot, n_slots, -}
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sidx = 0; sidx < f.z; ++sidx) {
+    const float4 o = *reinterpret_cast<const float4*>(P.partial + (size_t)(f.y + sidx) * D + 4 * l);
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
   }
-  if (P.y) *reinterpret_cast<float4*>(P.y + off) = y;
-  if (P.y_pert) {
-    float4 n;
-    if (P.noise) {
-      n = *reinterpret_cast<const float4*>(P.noise + off);
-    } else {
-      const uint4 r = philox4(P.seed, P.offset + (unsigned long long)row * LANES + l, 0x5eedu);
-      n = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
-    }
-    float ss = n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w;
-    ss = group_sum<LANES>(ss);
-    const float sc = P.noise_degree / fmaxf(sqrtf(ss), 1e-12f);
-    float4 yp = make_float4(y.x + sgn(y.x) * (n.x * sc), y.y + sgn(y.y) * (n.y * sc), y.z + sgn(y.z) * (n.z * sc),
-                            y.w + sgn(y.w) * (n.w * sc));
-    *reinterpret_cast<float4*>(P.y_pert + off) = yp;
-    if (P.y_mean) {
-      const float4 a = *reinterpret_cast<const float4*>(P.m1 + off);
-      const float4 b = *reinterpret_cast<const float4*>(P.m2 + off);
-      const float t = 1.0f / 3.0f;
-      *reinterpret_cast<float4*>(P.y_mean + off) =
-          make_float4((yp.x + a.x + b.x) * t, (yp.y + a.y + b.y) * t, (yp.z + a.z + b.z) * t, (yp.w + a.w + b.w) * t);
-    }
-  }
+  spmm_epilogue<D>(P, f.x, l, acc);
 }
 
 template <int D>
 static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(spmm_kernel<D>, dim3(blocks), dim3(256), 0, s, b);
+  int max_fix = 0;
+  for (int i = 0; i < b.n; ++i) max_fix = max_fix > b.p[i].n_fix ? max_fix : b.p[i].n_fix;
+  if (max_fix > 0) hipLaunchKernelGGL(spmm_fixup_kernel<D>, dim3(cdiv(max_fix, 1024 / D), b.n), dim3(256), 0, s, b);
   DMM_LAUNCH_CHECK("dmm_spmm_csr_f32");
   return 0;
 }
@@ -178,6 +207,8 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
     DMM_CHECK_ARG(p.n_tasks > 0 && p.n_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: n_tasks=%d is not a multiple of %d", i, p.n_tasks, G);
     DMM_CHECK_ARG(p.n_head_tasks >= 0 && p.n_head_tasks <= p.n_tasks && p.n_head_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: bad n_head_tasks", i);
     DMM_CHECK_ARG(p.y || p.y_pert, "dmm_spmm_csr_f32: problem %d has no output", i);
+    DMM_CHECK_ARG(p.n_partial_blocks >= 0 && p.n_partial_blocks * G <= p.n_head_tasks && p.n_fix >= 0, "dmm_spmm_csr_f32: problem %d: bad giant-row fields", i);
+    DMM_CHECK_ARG(p.n_partial_blocks == 0 || (p.partial && p.fix && p.n_fix > 0), "dmm_spmm_csr_f32: problem %d: giant rows need partial + fix buffers", i);
     DMM_CHECK_ARG(!p.y_mean || (p.y_pert && p.m1 && p.m2), "dmm_spmm_csr_f32: problem %d: y_mean needs y_pert, m1, m2", i);
     DMM_CHECK_ARG(p.x_hi || p.split >= (1 << 30), "dmm_spmm_csr_f32: problem %d: x_hi missing", i);
     b.p[i] = p;

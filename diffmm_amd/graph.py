@@ -42,13 +42,25 @@ def normalized_bipartite_csr(rows: np.ndarray, cols: np.ndarray, users: int, ite
     return rowptr.astype(np.int32), dst.astype(np.int32), val
 
 
-def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False):
-    """Work list for dmm_spmm_csr_f32: int32 [T, 4] rows of (row, nz_begin, nz_end, run_pos << 16 | run_len).
+@dataclass
+class Plan:
+    """SpMM work list: int32 [T, 4] tasks (row, nz_begin, nz_end, run_pos << 16 | run_len); the first `n_partial_blocks` workgroups are
+    segments of giant rows (their partial rows are summed by the fix-up pass described by `fix`: int32 [n_giant, 4] =
+    row, first_slot, n_slots, 0); the first `head` tasks (segments + split rows) keep round-robin XCD dispatch."""
+    tasks: "np.ndarray"
+    head: int
+    n_partial_blocks: int
+    fix: "np.ndarray"
 
-    A workgroup of the kernel holds G = 1024 / D task groups.  Rows with at most `task_len` non-zeros are one
-    task.  Longer rows are cut into k <= G tasks that sit in consecutive groups of ONE workgroup (they are
-    combined through LDS in task order): k is rounded up to a power of two and runs are placed largest first,
-    so every run is aligned to its own size and never straddles a workgroup.  Padding tasks have row = -1.
+
+def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False, full: bool = False):
+    """Work list for dmm_spmm_csr_f32.
+
+    A workgroup of the kernel holds G = 1024 / D task groups.  Rows with at most `task_len` non-zeros are one task.  Longer
+    rows (up to 2 G task_len non-zeros) are cut into k <= G tasks that sit in consecutive groups of ONE workgroup (combined
+    through LDS in task order): k is rounded up to a power of two and runs are placed largest first, so every run is aligned to
+    its own size and never straddles a workgroup.  Still longer ("giant") rows are cut into segments of 2 G task_len non-zeros,
+    one full workgroup each; the segment partials are added in order by a second pass.  Padding tasks have row = -1.
     """
     G = 1024 // D
     if G * D != 1024 or D % 4:
@@ -56,11 +68,41 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
     rp = np.asarray(rowptr, dtype=np.int64)
     n = rp.shape[0] - 1
     length = rp[1:] - rp[:-1]
+    seg_len = 2 * G * task_len
     k = np.maximum(1, -(-length // task_len))
     k = np.minimum(k, G)
-    multi = np.flatnonzero(k > 1)
+    giant = np.flatnonzero(length > seg_len)
+    multi = np.flatnonzero((k > 1) & (length <= seg_len))
     single = np.flatnonzero(k == 1)
+    pad_row = np.array([[-1, 0, 0, 1]], dtype=np.int64)
     parts = []
+    n_partial_blocks = 0
+    fix = np.zeros((0, 4), dtype=np.int32)
+    if giant.size:
+        nseg = -(-length[giant] // seg_len)
+        first = np.cumsum(nseg) - nseg
+        total_seg = int(nseg.sum())
+        seg_owner = np.repeat(np.arange(giant.size), nseg)
+        seg_j = np.arange(total_seg) - first[seg_owner]
+        sbeg = rp[giant][seg_owner] + seg_j * seg_len
+        send = np.minimum(sbeg + seg_len, rp[giant + 1][seg_owner])
+        chunk = np.maximum(1, -(-(send - sbeg) // G))
+        sidx = np.repeat(np.arange(total_seg), G)
+        gidx = np.tile(np.arange(G), total_seg)
+        beg = sbeg[sidx] + gidx * chunk[sidx]
+        end = np.minimum(beg + chunk[sidx], send[sidx])
+        live = beg < end
+        nlive = np.bincount(sidx[live], minlength=total_seg)
+        t = np.full((total_seg * G, 4), -1, dtype=np.int64)
+        t[:, 1:] = 0
+        t[live, 0] = giant[seg_owner[sidx[live]]]
+        t[live, 1] = beg[live]
+        t[live, 2] = end[live]
+        t[live, 3] = (gidx[live] << 16) | nlive[sidx[live]]
+        t[~live, 3] = 1
+        parts.append(t)
+        n_partial_blocks = total_seg
+        fix = np.stack([giant, first, nseg, np.zeros_like(giant)], axis=1).astype(np.int32)
     if multi.size:
         kp = 1 << np.ceil(np.log2(k[multi])).astype(np.int64)  # slots reserved per run (power of two <= G)
         order = np.argsort(-kp, kind="stable")
@@ -70,16 +112,13 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
         total = int(km.sum())
         t = np.full((total, 4), -1, dtype=np.int64)
         t[:, 1:] = 0
-        # expand: task j of run i covers [beg + j*chunk, min(beg + (j+1)*chunk, end))
         run_of = np.repeat(np.arange(multi.size), km)
         j = np.arange(total) - np.repeat(start, km)
-        # use all reserved slots (km tasks) -> shorter tasks, still one run
-        chunk = -(-length[multi] // km)
+        chunk = -(-length[multi] // km)  # all reserved slots are used: shorter tasks, still one run
         beg = rp[multi][run_of] + j * chunk[run_of]
         end = np.minimum(beg + chunk[run_of], rp[multi + 1][run_of])
         live = beg < end
-        # number of live tasks per run (tasks are a prefix because chunks are equal)
-        nlive = np.bincount(run_of[live], minlength=multi.size)
+        nlive = np.bincount(run_of[live], minlength=multi.size)  # live tasks are a prefix of the run (equal chunks)
         t[live, 0] = multi[run_of[live]]
         t[live, 1] = beg[live]
         t[live, 2] = end[live]
@@ -87,19 +126,18 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
         t[~live, 3] = 1
         pad = (-total) % G
         if pad:
-            t = np.concatenate([t, np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int64), (pad, 1))])
+            t = np.concatenate([t, np.tile(pad_row, (pad, 1))])
         parts.append(t)
+    head = int(sum(p.shape[0] for p in parts))  # segments + split rows come first
     if single.size:
         t = np.stack([single, rp[single], rp[single + 1], np.ones_like(single)], axis=1)
         pad = (-t.shape[0]) % G
         if pad:
-            t = np.concatenate([t, np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int64), (pad, 1))])
+            t = np.concatenate([t, np.tile(pad_row, (pad, 1))])
         parts.append(t)
-    head = int(parts[0].shape[0]) if multi.size else 0  # tasks of the split (heavy) rows come first
-    if not parts:
-        out = np.tile(np.array([[-1, 0, 0, 1]], dtype=np.int32), (G, 1))
-    else:
-        out = np.ascontiguousarray(np.concatenate(parts).astype(np.int32))
+    out = np.ascontiguousarray(np.concatenate(parts).astype(np.int32)) if parts else np.tile(pad_row.astype(np.int32), (G, 1))
+    if full:
+        return Plan(out, head, n_partial_blocks, fix)
     return (out, head) if return_head else out
 
 
@@ -121,7 +159,10 @@ def check_plan(rowptr: np.ndarray, tasks: np.ndarray, D: int) -> None:
     assert (ln[live] >= 1).all() and (pos[live] < ln[live]).all(), "run fields"
     assert ((slot - pos + ln)[live] <= G).all(), "a run straddles a workgroup"
     heads = np.flatnonzero(live & (pos == 0))
-    assert np.array_equal(np.sort(t[heads, 0]), np.arange(n)), "every row needs exactly one run head"
+    assert np.array_equal(np.unique(t[heads, 0]), np.arange(n)), "every row needs a run head"
+    seg = 2 * G * 32
+    multi_head = np.bincount(t[heads, 0], minlength=n) > 1
+    assert not (multi_head & ((rp[1:] - rp[:-1]) <= G)).any(), "only giant rows may have several run heads (one per segment)"
     for h in heads[ln[heads] > 1][:64]:  # spot-check run contiguity
         m = ln[h]
         assert (t[h:h + m, 0] == t[h, 0]).all() and np.array_equal(pos[h:h + m], np.arange(m)), "run not contiguous"
@@ -137,12 +178,24 @@ class Adjacency:
     col: torch.Tensor  # int32 [nnz]
     val: torch.Tensor  # fp32 [nnz]
     tasks: torch.Tensor  # int32 [T, 4]
-    n_head_tasks: int = 0  # leading tasks that belong to split rows
+    n_head_tasks: int = 0  # leading tasks that belong to split rows / giant-row segments
+    n_partial_blocks: int = 0  # leading workgroups that are segments of giant rows
+    fix: Optional[torch.Tensor] = None  # int32 [n_giant, 4]: row, first_slot, n_slots, 0
     host: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
 
     @property
     def n_tasks(self) -> int:
         return int(self.tasks.shape[0])
+
+    def partial_buffer(self, i: int) -> Optional[torch.Tensor]:
+        """Scratch for the giant-row segments of the i-th concurrent use of this adjacency in one launch (owned here so that
+        recorded launch plans keep valid pointers)."""
+        if not self.n_partial_blocks:
+            return None
+        pool = self.__dict__.setdefault("_partial_pool", [])
+        while len(pool) <= i:
+            pool.append(torch.empty((self.n_partial_blocks, self.D), dtype=torch.float32, device=self.col.device))
+        return pool[i]
 
     def algorithmic_bytes(self, elem_bytes: int = 4) -> int:
         """Compulsory HBM traffic of one SpMM: indices + values + row pointers + X + Y."""
@@ -156,13 +209,15 @@ def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D
 
 
 def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, keep_host: bool = False) -> Adjacency:
-    tasks, head = plan_tasks(rowptr, D, task_len, return_head=True)
+    plan = plan_tasks(rowptr, D, task_len, full=True)
+    tasks, head = plan.tasks, plan.head
     check_plan(rowptr, tasks, D)
     assert col.size == 0 or (col.min() >= 0 and col.max() < rowptr.shape[0] - 1), "column id out of range"
     dev = torch.device(device)
     return Adjacency(n=int(rowptr.shape[0] - 1), nnz=int(col.shape[0]), D=D,
                      rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
                      val=torch.from_numpy(val).to(dev), tasks=torch.from_numpy(tasks).to(dev), n_head_tasks=head,
+                     n_partial_blocks=plan.n_partial_blocks, fix=torch.from_numpy(plan.fix).to(dev) if plan.n_partial_blocks else None,
                      host=(rowptr, col, val) if keep_host else None)
 
 
@@ -172,19 +227,47 @@ def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, kee
 # ~1e5 integers); the values follow the same float64 formula as normalized_bipartite_csr.
 # ======================================================================================================
 def plan_tasks_torch(rowptr: torch.Tensor, D: int, task_len: int = 32):
-    """torch port of plan_tasks (same task list, bit for bit; checked against the numpy planner in tests/test_host_logic.py)."""
+    """torch port of plan_tasks (same Plan, bit for bit; checked against the numpy planner in tests/test_host_logic.py)."""
     G = 1024 // D
     if G * D != 1024 or D % 4:
         raise ValueError(f"D={D} unsupported")
     dev = rowptr.device
     rp = rowptr.long()
     length = rp[1:] - rp[:-1]
+    seg_len = 2 * G * task_len
     k = torch.clamp((length + task_len - 1) // task_len, min=1, max=G)
-    multi = torch.nonzero(k > 1).flatten()
+    giant = torch.nonzero(length > seg_len).flatten()
+    multi = torch.nonzero((k > 1) & (length <= seg_len)).flatten()
     single = torch.nonzero(k == 1).flatten()
     pad_row = torch.tensor([[-1, 0, 0, 1]], dtype=torch.long, device=dev)
     parts = []
-    head = 0
+    n_partial_blocks = 0
+    fix = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    if giant.numel():
+        nseg = (length[giant] + seg_len - 1) // seg_len
+        first = torch.cumsum(nseg, 0) - nseg
+        total_seg = int(nseg.sum())
+        seg_owner = torch.repeat_interleave(torch.arange(giant.numel(), device=dev), nseg, output_size=total_seg)
+        seg_j = torch.arange(total_seg, device=dev) - first[seg_owner]
+        sbeg = rp[giant][seg_owner] + seg_j * seg_len
+        send = torch.minimum(sbeg + seg_len, rp[giant + 1][seg_owner])
+        chunk = torch.clamp((send - sbeg + G - 1) // G, min=1)
+        sidx = torch.arange(total_seg, device=dev).repeat_interleave(G)
+        gidx = torch.arange(G, device=dev).repeat(total_seg)
+        beg = sbeg[sidx] + gidx * chunk[sidx]
+        end = torch.minimum(beg + chunk[sidx], send[sidx])
+        live = beg < end
+        nlive = torch.bincount(sidx[live], minlength=total_seg)
+        t = torch.full((total_seg * G, 4), -1, dtype=torch.long, device=dev)
+        t[:, 1:] = 0
+        t[live, 0] = giant[seg_owner[sidx[live]]]
+        t[live, 1] = beg[live]
+        t[live, 2] = end[live]
+        t[live, 3] = (gidx[live] << 16) | nlive[sidx[live]]
+        t[~live, 3] = 1
+        parts.append(t)
+        n_partial_blocks = total_seg
+        fix = torch.stack([giant, first, nseg, torch.zeros_like(giant)], dim=1).to(torch.int32)
     if multi.numel():
         km = k[multi]
         kp = torch.ones_like(km)
@@ -212,8 +295,8 @@ def plan_tasks_torch(rowptr: torch.Tensor, D: int, task_len: int = 32):
         pad = (-total) % G
         if pad:
             t = torch.cat([t, pad_row.expand(pad, 4)])
-        head = int(t.shape[0])
         parts.append(t)
+    head = int(sum(p.shape[0] for p in parts))
     if single.numel():
         t = torch.stack([single, rp[single], rp[single + 1], torch.ones_like(single)], dim=1)
         pad = (-int(t.shape[0])) % G
@@ -221,7 +304,7 @@ def plan_tasks_torch(rowptr: torch.Tensor, D: int, task_len: int = 32):
             t = torch.cat([t, pad_row.expand(pad, 4)])
         parts.append(t)
     out = torch.cat(parts) if parts else pad_row.expand(G, 4)
-    return out.to(torch.int32).contiguous(), head
+    return Plan(out.to(torch.int32).contiguous(), head, n_partial_blocks, fix)
 
 
 class DeviceGraphBuilder:
@@ -256,7 +339,8 @@ class DeviceGraphBuilder:
         dinv = deg_n.double() ** -0.5
         row = torch.repeat_interleave(torch.arange(N, device=dev), deg_n, output_size=nnz)
         val = ((dinv[row] * 1.0) * dinv[col]).float()
-        tasks, head = plan_tasks_torch(rowptr, self.D, self.task_len)
+        plan = plan_tasks_torch(rowptr, self.D, self.task_len)
         if validate:
-            check_plan(rowptr.cpu().numpy(), tasks.cpu().numpy(), self.D)
-        return Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr.to(torch.int32), col=col.to(torch.int32), val=val, tasks=tasks, n_head_tasks=head)
+            check_plan(rowptr.cpu().numpy(), plan.tasks.cpu().numpy(), self.D)
+        return Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr.to(torch.int32), col=col.to(torch.int32), val=val, tasks=plan.tasks,
+                         n_head_tasks=plan.head, n_partial_blocks=plan.n_partial_blocks, fix=plan.fix if plan.n_partial_blocks else None)

@@ -37,7 +37,7 @@ class SpmmOp:
     def __init__(self, adj: Adjacency, x_lo: Tensor, y: Optional[Tensor] = None, x_hi: Optional[Tensor] = None, split: Optional[int] = None,
                  alpha: float = 1.0, c1: Optional[Tensor] = None, beta: float = 0.0, c2: Optional[Tensor] = None, gamma: float = 0.0,
                  y_pert: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_degree: float = 0.0, seed: int = 0, offset: int = 0,
-                 y_mean: Optional[Tensor] = None, m1: Optional[Tensor] = None, m2: Optional[Tensor] = None):
+                 y_mean: Optional[Tensor] = None, m1: Optional[Tensor] = None, m2: Optional[Tensor] = None, partial: Optional[Tensor] = None):
         D = adj.D
         n = adj.n
         if x_hi is None:
@@ -63,6 +63,10 @@ class SpmmOp:
         p.y_pert, p.noise, p.noise_degree, p.seed, p.offset = L.ptr(y_pert), L.ptr(noise), noise_degree, seed, offset
         p.y_mean, p.m1, p.m2 = L.ptr(y_mean), L.ptr(m1), L.ptr(m2)
         p.n_rows = adj.n
+        p.n_partial_blocks, p.n_fix = adj.n_partial_blocks, (int(adj.fix.shape[0]) if adj.fix is not None else 0)
+        p.fix = L.ptr(adj.fix) if adj.fix is not None else None
+        p.partial = L.ptr(partial) if partial is not None else None
+        self.adj = adj
         p.n_tasks = adj.n_tasks
         p.n_head_tasks = adj.n_head_tasks
         self.p, self.D = p, D
@@ -72,6 +76,12 @@ def spmm_batched(ops: Sequence[SpmmOp]):
     if not 1 <= len(ops) <= L.SPMM_MAX_BATCH:
         raise ValueError("1..4 problems per launch")
     D = ops[0].D
+    uses = {}
+    for o in ops:  # giant-row scratch: one buffer per concurrent use of an adjacency, owned by the adjacency
+        if o.adj.n_partial_blocks and not o.p.partial:
+            i = uses.get(id(o.adj), 0)
+            uses[id(o.adj)] = i + 1
+            o.p.partial = L.ptr(o.adj.partial_buffer(i))
     arr = (L.SpmmProblem * len(ops))(*[o.p for o in ops])
     L.call("dmm_spmm_csr_f32", arr, len(ops), D, L.stream())
     return arr  # the launch's argument block (plans patch the Philox offsets in place)

@@ -40,6 +40,9 @@ const char* dmm_last_error_string(void);
  * (diffmm_amd/graph.py: plan_tasks); n_tasks must be a multiple of dmm_spmm_tasks_per_block(D).  The planner puts the
  * tasks of split (heavy) rows first: those n_head_tasks keep the hardware's round-robin workgroup->XCD dispatch (they hold
  * most of the non-zeros and must be spread), the single-task tail is remapped so each XCD walks a contiguous row range.
+ * Rows beyond one workgroup's worth of tasks ("giant": a popular item of a rebuilt graph) are cut into segments, the first
+ * n_partial_blocks workgroups of the list; they park raw partial rows in `partial`, and a second tiny launch adds them in segment
+ * order and applies the epilogue (deterministic, no atomics).
  * noise == NULL with y_pert != NULL draws uniform noise in-kernel: Philox4x32-10(seed, offset + row*D/4 + lane). */
 typedef struct dmm_spmm_problem {
   const void* tasks;
@@ -57,6 +60,9 @@ typedef struct dmm_spmm_problem {
   const float* m2;
   uint64_t seed;
   uint64_t offset;
+  float* partial;       /* [n_partial_blocks, D] scratch for the segments of giant rows (NULL when there are none) */
+  const void* fix;      /* int4 {row, first_slot, n_slots, 0} per giant row */
+  int32_t n_partial_blocks, n_fix;
   int32_t n_rows;  /* rows of the adjacency (sizes the XCD-placement heuristic) */
   int32_t n_tasks;
   int32_t n_head_tasks; /* leading tasks (split heavy rows, multiple of tasks_per_block) dispatched round-robin over the XCDs */

@@ -41,11 +41,14 @@ def test_no_cpu_fallback():
         ops.spmm_batched([ops.SpmmOp(adj, torch.zeros(adj.n, 8), y=torch.zeros(adj.n, 8))])
 
 
-def _emulate(tasks, col, val, X, G):
-    """numpy model of spmm_kernel: per-task partial rows, runs combined in task order by the run head."""
+def _emulate(plan, col, val, X, G):
+    """numpy model of spmm_kernel + spmm_fixup_kernel: per-task partial rows, runs combined in task order by the run head;
+    the first n_partial_blocks workgroups park their sums, the fix list adds them per giant row."""
+    tasks = plan.tasks
     n, D = X.shape
     Y = np.full((n, D), np.nan, dtype=np.float64)
     part = np.zeros((tasks.shape[0], D))
+    slots = np.zeros((plan.n_partial_blocks, D))
     for i, (row, b, e, run) in enumerate(tasks):
         if row >= 0:
             part[i] = (val[b:e, None].astype(np.float64) * X[col[b:e]]).sum(0)
@@ -53,8 +56,15 @@ def _emulate(tasks, col, val, X, G):
         if row >= 0 and (run >> 16) == 0:
             ln = run & 0xFFFF
             assert (i % G) + ln <= G
+            if i // G < plan.n_partial_blocks:
+                assert i % G == 0
+                slots[i // G] = part[i:i + ln].sum(0)
+                continue
             assert np.isnan(Y[row]).all(), "row written twice"
             Y[row] = part[i:i + ln].sum(0)
+    for row, first, cnt, _ in plan.fix:
+        assert np.isnan(Y[row]).all()
+        Y[row] = slots[first:first + cnt].sum(0)
     return Y
 
 
@@ -62,15 +72,24 @@ def _emulate(tasks, col, val, X, G):
 def test_planner_tiles_every_row(name, D, task_len):
     from diffmm_amd import graph, synth
     g = synth.named(name)
-    rowptr, col, val = graph.normalized_bipartite_csr(g.trn_rows, g.trn_cols, g.users, g.items)
-    tasks = graph.plan_tasks(rowptr, D, task_len)
+    rows, cols = g.trn_rows, g.trn_cols
+    if name == "mid":  # one item every user interacted with: a giant row that must be cut into segments
+        rows, cols = np.concatenate([rows, np.arange(g.users)]), np.concatenate([cols, np.zeros(g.users, dtype=cols.dtype)])
+    rowptr, col, val = graph.normalized_bipartite_csr(rows, cols, g.users, g.items)
+    plan = graph.plan_tasks(rowptr, D, task_len, full=True)
+    tasks = plan.tasks
     graph.check_plan(rowptr, tasks, D)
+    n_giant = int((np.diff(rowptr) > 2 * (1024 // D) * task_len).sum())
+    assert len(plan.fix) == n_giant and (plan.n_partial_blocks >= 2 * n_giant)
+    if name == "mid" and D >= 64:
+        assert n_giant >= 1, "the all-users item must be a giant row at these task sizes"
     n = len(rowptr) - 1
     X = np.random.default_rng(0).standard_normal((n, 4))
-    Y = _emulate(tasks, col, val, X, 1024 // D)
+    Y = _emulate(plan, col, val, X, 1024 // D)
     dense = np.zeros((n, n)); dense[np.repeat(np.arange(n), np.diff(rowptr)), col] = val
     assert np.allclose(Y, dense @ X, rtol=1e-12, atol=1e-12)
     if name == "tiktok":
+        assert plan.n_partial_blocks == 0
         live = tasks[tasks[:, 0] >= 0]
         assert (live[:, 2] - live[:, 1]).max() <= 64, "no task longer than 2 x task_len on the TikTok degree law"
         assert tasks.shape[0] < 1.4 * n, "padding overhead stays small"
@@ -114,7 +133,9 @@ def test_device_graph_builder_equals_host_builder(name, D, task_len):
     items = np.concatenate([np.sort(rng.choice(g.items, size=d, replace=False, p=pop)) for d in deg if d])
     rows = np.repeat(np.arange(g.users), deg)
     rp, c, v = graph.normalized_bipartite_csr(rows, items, g.users, g.items)
-    tasks, head = graph.plan_tasks(rp, D, task_len, return_head=True)
+    plan = graph.plan_tasks(rp, D, task_len, full=True)
     adj = graph.DeviceGraphBuilder(torch.from_numpy(ptr), g.users, g.items, D, task_len).build(torch.from_numpy(items.astype(np.int32)), validate=True)
     assert np.array_equal(adj.rowptr.numpy(), rp) and np.array_equal(adj.col.numpy(), c) and np.array_equal(adj.val.numpy(), v)
-    assert np.array_equal(adj.tasks.numpy(), tasks) and adj.n_head_tasks == head
+    assert np.array_equal(adj.tasks.numpy(), plan.tasks) and adj.n_head_tasks == plan.head and adj.n_partial_blocks == plan.n_partial_blocks
+    if plan.n_partial_blocks:
+        assert np.array_equal(adj.fix.numpy(), plan.fix)

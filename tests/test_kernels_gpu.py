@@ -106,6 +106,35 @@ def test_spmm_perturb_mean_and_batch(dev, name, D):
         close(ys[i], (i + 1) * torch.sparse.mm(A, Xs[i]), atol=2e-5, what=f"batched {i}")
 
 
+@pytest.mark.parametrize("D", [16, 64, 256])
+def test_spmm_giant_rows(dev, D):
+    """An item every user interacted with (9k+ non-zeros) and a user with 3000 items: rows cut into multi-workgroup segments, summed
+    by the fix-up pass; all epilogues still apply; two uses of one adjacency in a launch get separate scratch."""
+    from diffmm_amd import ops, graph, synth
+    from oracle import diffmm_oracle as O
+    import torch.nn.functional as F
+    g = synth.named("tiktok")
+    rows = np.concatenate([g.trn_rows, np.arange(g.users), np.full(3000, 5)])
+    cols = np.concatenate([g.trn_cols, np.zeros(g.users, dtype=np.int32), np.arange(3000)])
+    adj = graph.make_adjacency(rows, cols, g.users, g.items, D, dev, keep_host=True)
+    assert adj.n_partial_blocks >= 2 and adj.fix is not None
+    A = O.csr_to_torch(*adj.host)
+    rng = np.random.default_rng(3)
+    X = T(rng.standard_normal((adj.n, D)).astype(np.float32)); C1 = T(rng.standard_normal((adj.n, D)).astype(np.float32))
+    noise = T(rng.random((adj.n, D)).astype(np.float32))
+    ref = torch.sparse.mm(A, X)
+    y, y2, yp = (torch.empty((adj.n, D), device=dev) for _ in range(3))
+    ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=y, alpha=2.0, c1=C1.to(dev), beta=0.5),
+                      ops.SpmmOp(adj, C1.to(dev), y=y2, y_pert=yp, noise=noise.to(dev), noise_degree=1.5)])
+    close(y, 2.0 * ref + 0.5 * C1, rtol=2e-5, atol=2e-5, what="giant rows, epilogue")
+    ref2 = torch.sparse.mm(A, C1)
+    close(y2, ref2, rtol=2e-5, atol=2e-5, what="second use of the adjacency")
+    close(yp, ref2 + torch.sign(ref2) * F.normalize(noise) * 1.5, rtol=2e-5, atol=2e-5, what="perturbed")
+    y3 = torch.empty_like(y)
+    ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=y3, alpha=2.0, c1=C1.to(dev), beta=0.5)])
+    assert torch.equal(y, y3), "segmented rows stay bitwise reproducible"
+
+
 def test_spmm_is_deterministic_and_symmetric_backward(dev):
     from diffmm_amd import ops
     g, adj, A = _adj("tiktok", 64, dev)
