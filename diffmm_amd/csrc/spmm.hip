@@ -11,9 +11,9 @@
 //     task order, so results are bitwise reproducible -- no atomics.  This is what balances the TikTok
 //     degree law (1 % of the rows hold 70 % of the non-zeros) across waves;
 //   * the host planner (diffmm_amd/graph.py: plan_tasks) emits the task list; padding tasks have row = -1.
-//   * blockIdx -> work is remapped so that each XCD (private 4 MiB L2) walks one contiguous slice of the task
-//     list: user-row tasks gather only item rows of X and vice versa, so a slice's gather set is about half
-//     of X and stays L2 resident.
+//   * workgroups keep the dispatcher's round-robin order over the 8 XCDs; an XCD-contiguous remap of the task list exists
+//     (DMM_SPMM_REMAP=1) but measured neutral at TikTok size and 20-30 % slower at 1M users (unequal work per XCD);
+//   * rows beyond one workgroup's worth of tasks are cut into segments (several workgroups) that a tiny second launch sums.
 //
 // Epilogues (all optional, selected per problem):
 //   y      = alpha*acc + beta*c1[row] + gamma*c2[row]
@@ -195,10 +195,11 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
   memset(&b, 0, sizeof(b));
   b.n = n_probs;
   {
-    // XCD-contiguous placement only pays when the gathered operand exceeds the on-die caches (measured: no effect on the
-    // 4 MB TikTok operand, where every XCD's L2 + the Infinity Cache hold all of X); DMM_SPMM_REMAP=0/1 overrides.
+    // XCD-contiguous placement of the single-task tail is opt-in (DMM_SPMM_REMAP=1): measured neutral on the 4 MB TikTok operand
+    // (X sits in every XCD's L2 + the Infinity Cache) and 20-30 % SLOWER on a 1M-user shard (contiguous slices of the row-sorted
+    // task list give the XCDs unequal work: user rows are short, item rows long), so the dispatcher's round-robin order is kept.
     const char* e = getenv("DMM_SPMM_REMAP");
-    b.remap = e ? (e[0] == '1') : -1;
+    b.remap = e ? (e[0] == '1') : 0;
   }
   int blocks = 0;
   for (int i = 0; i < n_probs; ++i) {
@@ -216,11 +217,7 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
     blocks += p.n_tasks / G;
   }
   for (int i = n_probs; i <= DMM_SPMM_MAX_BATCH; ++i) b.block_begin[i] = blocks;
-  if (b.remap < 0) {
-    long long max_rows = 0;
-    for (int i = 0; i < n_probs; ++i) max_rows = max_rows > probs[i].n_rows ? max_rows : probs[i].n_rows;
-    b.remap = max_rows * D * 4 > (256ll << 20);
-  }
+
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 8: return dmm::launch<8>(b, blocks, s);
