@@ -161,13 +161,35 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   if (k <= 0) return;  // uniform per block
   if (k > cols) k = cols;
   const float* __restrict__ r = x + (long long)blockIdx.x * ldx;
-  uint32_t T = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t cand = T | (1u << bit);
-    int c = 0;
-    for (int j = threadIdx.x; j < cols; j += 256) c += fkey(r[j]) >= cand;
-    if (block_sum_int(c, sm4) >= k) T = cand;
+  // k-th largest key by 8-bit radix select: 4 passes, each a 256-bin LDS histogram of the keys that match the prefix found so far
+  __shared__ int hist[256];
+  __shared__ uint32_t sel_prefix;
+  __shared__ int sel_k;
+  uint32_t prefix = 0, mask = 0;
+  int kk = k;  // rank still to find inside the current prefix bucket
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < cols; j += 256) {
+      const uint32_t key = fkey(r[j]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // walk the bins from the largest digit down until the bucket holding rank kk
+      int acc = 0, b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= kk) break;
+        acc += hist[b];
+      }
+      sel_prefix = prefix | ((uint32_t)b << shift);
+      sel_k = kk - acc;
+    }
+    __syncthreads();
+    prefix = sel_prefix;
+    kk = sel_k;
+    mask |= 255u << shift;
   }
+  const uint32_t T = prefix;  // the k-th largest key
   int c = 0;
   for (int j = threadIdx.x; j < cols; j += 256) c += fkey(r[j]) > T;
   const int n_gt = block_sum_int(c, sm4);
