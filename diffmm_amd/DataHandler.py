@@ -107,11 +107,14 @@ class TestData:
         self.test_users = np.unique(r)
         ptr = np.searchsorted(r, np.arange(users + 1))
         self.test_user_its: List[Optional[list]] = [list(c[ptr[u]:ptr[u + 1]]) if ptr[u + 1] > ptr[u] else None for u in range(users)]
+        self._tst_ptr = torch.from_numpy(ptr.astype(np.int64)).to(self.device)
+        self._tst_col = torch.from_numpy(c.astype(np.int64)).to(self.device)
         # train interactions as CSR over users, for the score mask
         o2 = np.argsort(trn_rows, kind="stable")
         self._trn_ptr = torch.from_numpy(np.searchsorted(np.asarray(trn_rows)[o2], np.arange(users + 1)).astype(np.int64)).to(self.device)
         self._trn_col = torch.from_numpy(np.asarray(trn_cols)[o2].astype(np.int64)).to(self.device)
         self._users_d = torch.from_numpy(self.test_users.astype(np.int64)).to(self.device)
+        self._users_i32 = self._users_d.to(torch.int32)
 
     def __len__(self) -> int:
         return len(self.test_users)

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import graph
+from . import graph, ops
 from .Conf import Config, load_config
 from .DataHandler import DataHandler
 from .Model import Denoise, GaussianDiffusion, Model, denoise_dims, hyper_dict
@@ -194,21 +194,27 @@ class Coach:
 
     # ---------------------------------------------------------------------------------------------
     def testEpoch(self) -> Dict[str, float]:
-        """Full-ranking evaluation (Main.py:390-420).  Scores and top-k use torch ops: evaluation is outside the timed hot path."""
+        """Full-ranking evaluation (Main.py:390-420): propagate once, then per user batch score = U_b I^T (dmm_gemm, split-bf16
+        ~fp32), train items masked to -1e8 and top-k selected in one launch (dmm_eval_topk); only the [batch, topk] ids leave the GPU."""
         h, J = self.handler, self.model.engine
         adjs = [self.image_adj, self.text_adj] + ([self.audio_adj] if self.M == 3 else [])
         J.set_adjacency(h.torchBiAdj, adjs)
         J.forward(with_cl=False, precision=self.precision)
         U = J.U
         uf, itf = J.Fin[:U], J.Fin[U:]
-        rec = ndcg = prec = 0.0
-        for usr, mask in h.testLoader:
-            score = (uf[usr] @ itf.t()) * (1 - mask) - mask * 1e8
-            top = torch.topk(score, int(self.config.base.topk)).indices
-            r, n, p = self.calcRes(top.cpu().numpy(), h.testData.test_user_its, usr)
-            rec, ndcg, prec = rec + r, ndcg + n, prec + p
-        n_u = len(h.testData)
-        return {"Recall": rec / n_u, "NDCG": ndcg / n_u, "Precision": prec / n_u}
+        td, k = h.testData, int(self.config.base.topk)
+        tb = int(self.config.train.test_batch)
+        score = torch.empty(min(tb, len(td)), J.I, dtype=torch.float32, device=uf.device)
+        total = torch.zeros(3, dtype=torch.float64, device=uf.device)
+        for lo in range(0, len(td), tb):
+            usr, u32 = td._users_d[lo:lo + tb], td._users_i32[lo:lo + tb]
+            ub = uf.index_select(0, usr)
+            sc = score[:usr.shape[0]]
+            ops.gemm(ub, itf, out=sc, trans_b=True, precision=3)
+            top = ops.eval_topk(sc, u32, td._trn_ptr, td._trn_col, k)
+            total += ops.eval_metrics(top, u32, td._tst_ptr, td._tst_col).sum(0)  # calcRes on the device; one host read at the end
+        rec, ndcg, prec = (total / len(td)).tolist()
+        return {"Recall": rec, "NDCG": ndcg, "Precision": prec}
 
     def calcRes(self, top_idxs: np.ndarray, test_u_its: list, users):
         """Sums of Recall / NDCG / Precision over the batch's users (Main.py:422-448)."""

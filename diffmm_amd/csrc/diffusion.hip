@@ -227,8 +227,130 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+// Evaluation (Coach.testEpoch, Main.py:403-411): scores of one user against all items with the user's TRAIN items pushed to
+// -1e8 (the reference multiplies by (1 - mask) and subtracts 1e8 * mask), then the k best columns in descending score order
+// (ties -> smaller column id).  One workgroup per user; k <= 64.  k selection rounds of a workgroup-wide arg-max would cost
+// k passes; instead: radix-select the k-th key, compact the <= k winners into LDS, sort them there (k is tiny).
+// The mask is applied to `score` in place (the caller's buffer is scratch for the next user batch anyway).
+__global__ __launch_bounds__(256) void eval_topk_kernel(float* __restrict__ score, long long ld, const int32_t* __restrict__ users,
+                                                         const int64_t* __restrict__ trn_ptr, const int64_t* __restrict__ trn_col, int cols, int k,
+                                                         int32_t* __restrict__ out) {
+  __shared__ int hist[256];
+  __shared__ uint32_t sel_prefix;
+  __shared__ int sel_k, n_out;
+  __shared__ float wv[64];
+  __shared__ int wi[64];
+  const int u = users[blockIdx.x];
+  float* __restrict__ r = score + (long long)blockIdx.x * ld;
+  for (long long p = trn_ptr[u] + threadIdx.x; p < trn_ptr[u + 1]; p += 256) r[trn_col[p]] = -1e8f;
+  __syncthreads();
+  uint32_t prefix = 0, mask = 0;
+  int kk = k < cols ? k : cols;
+  const int kq = kk;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < cols; j += 256) {
+      const uint32_t key = fkey(r[j]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= kk) break;
+        acc += hist[b];
+      }
+      sel_prefix = prefix | ((uint32_t)b << shift);
+      sel_k = kk - acc;
+      n_out = 0;
+    }
+    __syncthreads();
+    prefix = sel_prefix;
+    kk = sel_k;
+    mask |= 255u << shift;
+  }
+  const uint32_t T = prefix;
+  // winners: everything above the threshold, plus the first `kk` ties in column order (single thread resolves the few ties)
+  for (int j = threadIdx.x; j < cols; j += 256)
+    if (fkey(r[j]) > T) {
+      const int o = atomicAdd(&n_out, 1);
+      wv[o] = r[j];
+      wi[o] = j;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int o = n_out;
+    for (int j = 0; j < cols && o < kq; ++j)
+      if (fkey(r[j]) == T) {
+        wv[o] = r[j];
+        wi[o] = j;
+        ++o;
+      }
+    // insertion sort: descending score, ascending column on ties
+    for (int a = 1; a < kq; ++a) {
+      const float v = wv[a];
+      const int id = wi[a];
+      int b = a - 1;
+      while (b >= 0 && (wv[b] < v || (wv[b] == v && wi[b] > id))) {
+        wv[b + 1] = wv[b];
+        wi[b + 1] = wi[b];
+        --b;
+      }
+      wv[b + 1] = v;
+      wi[b + 1] = id;
+    }
+    for (int a = 0; a < kq; ++a) out[(long long)blockIdx.x * k + a] = wi[a];
+  }
+}
+
+// Coach.calcRes (Main.py:422-448) for one user per wave: lane j holds the j-th recommendation; recall = hits / |truth|,
+// ndcg = sum_hit 1/log2(j+2) / sum_{l < min(|truth|, k)} 1/log2(l+2), precision = hits / k.  fp64 like the reference's Python floats.
+__global__ __launch_bounds__(256) void eval_metrics_kernel(const int32_t* __restrict__ top, const int32_t* __restrict__ users,
+                                                            const int64_t* __restrict__ tst_ptr, const int64_t* __restrict__ tst_col, int rows, int k,
+                                                            double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;  // whole waves leave together; no workgroup barrier below
+  const int u = users[r];
+  const long long b = tst_ptr[u], e = tst_ptr[u + 1];
+  const int mine = lane < k ? top[(long long)r * k + lane] : -1;
+  bool hit = false;
+  for (long long p = b; p < e; ++p) hit |= (lane < k) && ((long long)mine == tst_col[p]);
+  double dcg = hit ? 1.0 / log2((double)lane + 2.0) : 0.0;
+  const long long nt = e - b;
+  double ideal = (lane < k && lane < nt) ? 1.0 / log2((double)lane + 2.0) : 0.0;
+  double nh = hit ? 1.0 : 0.0;
+  for (int o = 32; o > 0; o >>= 1) {
+    dcg += __shfl_xor(dcg, o);
+    ideal += __shfl_xor(ideal, o);
+    nh += __shfl_xor(nh, o);
+  }
+  if (lane == 0) {
+    out[(long long)r * 3 + 0] = nt > 0 ? nh / (double)nt : 0.0;
+    out[(long long)r * 3 + 1] = nt > 0 ? dcg / ideal : 0.0;
+    out[(long long)r * 3 + 2] = nh / (double)k;
+  }
+}
+
 }  // namespace dmm
 using namespace dmm;
+
+extern "C" int dmm_eval_metrics(const int32_t* top, const int32_t* users, const int64_t* tst_ptr, const int64_t* tst_col, int rows, int k, double* out,
+                                void* stream) {
+  DMM_CHECK_ARG(top && users && tst_ptr && tst_col && out && rows > 0 && k >= 1 && k <= 64, "dmm_eval_metrics: bad arguments (k <= 64)");
+  hipLaunchKernelGGL(eval_metrics_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, top, users, tst_ptr, tst_col, rows, k, out);
+  DMM_LAUNCH_CHECK("dmm_eval_metrics");
+  return 0;
+}
+
+extern "C" int dmm_eval_topk(float* score, int64_t ld, const int32_t* users, const int64_t* trn_ptr, const int64_t* trn_col, int rows, int cols,
+                             int k, int32_t* out, void* stream) {
+  DMM_CHECK_ARG(score && users && trn_ptr && trn_col && out && rows > 0 && cols > 0 && k >= 1 && k <= 64, "dmm_eval_topk: bad arguments (k <= 64)");
+  hipLaunchKernelGGL(eval_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
+  DMM_LAUNCH_CHECK("dmm_eval_topk");
+  return 0;
+}
 
 extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const int32_t* t, const float* sqrt_ac,
                                 const float* sqrt_1mac, const float* w_emb, const float* b_emb, int te, float* xcat, int64_t ldx, int B, int I,

@@ -383,3 +383,25 @@ def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int
 def topk_rows(x: Tensor, row_ids: Tensor, out_ptr: Tensor, out_idx: Tensor, cols: int) -> None:
     L.call("dmm_topk_rows", L.ptr(x), x.stride(0), L.ptr(_i32c(row_ids, "row_ids")), L.ptr(_i32c(out_ptr, "out_ptr")), L.ptr(out_idx),
                                   row_ids.shape[0], cols, L.stream())
+
+
+def eval_topk(score: Tensor, users: Tensor, trn_ptr: Tensor, trn_col: Tensor, k: int, cols: Optional[int] = None) -> Tensor:
+    """Mask the users' train items in `score` (in place) and return the k best columns per row, best first (Main.py:403-411)."""
+    if score.dtype != torch.float32 or score.stride(1) != 1:
+        raise ValueError("eval_topk: score must be fp32 with unit column stride")
+    if trn_ptr.dtype != torch.int64 or trn_col.dtype != torch.int64:
+        raise ValueError("eval_topk: trn_ptr / trn_col are int64")
+    cols = score.shape[1] if cols is None else cols
+    out = torch.empty(score.shape[0], k, dtype=torch.int32, device=score.device)
+    L.call("dmm_eval_topk", L.ptr(score), score.stride(0), L.ptr(_i32c(users, "users")), L.ptr(trn_ptr), L.ptr(trn_col), score.shape[0], cols, k,
+           L.ptr(out), L.stream())
+    return out
+
+
+def eval_metrics(top: Tensor, users: Tensor, tst_ptr: Tensor, tst_col: Tensor) -> Tensor:
+    """Per-row [recall, ndcg, precision] (fp64) of the recommendations `top` [rows, k] (Main.py:422-448)."""
+    if top.dtype != torch.int32 or not top.is_contiguous() or tst_ptr.dtype != torch.int64 or tst_col.dtype != torch.int64:
+        raise ValueError("eval_metrics: top is contiguous int32, tst_ptr / tst_col int64")
+    out = torch.empty(top.shape[0], 3, dtype=torch.float64, device=top.device)
+    L.call("dmm_eval_metrics", L.ptr(top), L.ptr(_i32c(users, "users")), L.ptr(tst_ptr), L.ptr(tst_col), top.shape[0], top.shape[1], L.ptr(out), L.stream())
+    return out

@@ -230,6 +230,20 @@ int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w
 int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids /*[rows] global user ids*/, const int32_t* out_ptr
                   /*[U+1] indexed by user id*/, int32_t* out_idx, int rows, int cols, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Evaluation: Coach.testEpoch (Main.py:403-411).  score [rows, cols] holds usrEmbeds[users] @ itmEmbeds^T (dmm_gemm); every
+ * train item of users[r] (CSR trn_ptr/trn_col over ALL users, int64) is set to -1e8 IN PLACE -- the reference's
+ * `allPreds * (1 - trnMask) - trnMask * 1e8` -- and the k best columns of the row are written to out[r*k .. r*k+k) in
+ * descending score order (equal scores: smaller column first).  k <= 64.  One workgroup per row. */
+int dmm_eval_topk(float* score, int64_t ld, const int32_t* users, const int64_t* trn_ptr, const int64_t* trn_col, int rows, int cols, int k,
+                  int32_t* out, void* stream);
+
+/* Coach.calcRes (Main.py:422-448) on the device: out[r*3 + {0,1,2}] = recall, ndcg, precision (fp64) of row r's k
+ * recommendations top[r*k ..] against the TEST items of users[r] (CSR tst_ptr/tst_col over all users, int64).  Users
+ * without test items get zeros.  The caller sums the rows (the reference sums them in Python). */
+int dmm_eval_metrics(const int32_t* top, const int32_t* users, const int64_t* tst_ptr, const int64_t* tst_col, int rows, int k, double* out,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -396,6 +396,64 @@ def test_topk_rows(dev, cols, kmax):
         assert (out[ptr[u]:ptr[u + 1]] == -1).all()
 
 
+@pytest.mark.parametrize("cols,k", [(9, 4), (200, 20), (6710, 20), (6710, 64)])
+def test_eval_topk(dev, cols, k):
+    """Masked top-k of Coach.testEpoch (Main.py:403-411): exact column ids in descending score order; ties -> smaller id."""
+    from diffmm_amd import ops
+    rng = np.random.default_rng(cols + k)
+    U, rows = 60, 41
+    deg = rng.integers(0, min(cols - k, 50) + 1, size=U); deg[3] = 0
+    ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate([rng.choice(cols, size=d, replace=False) for d in deg] + [np.zeros(0, np.int64)]).astype(np.int64)
+    users = rng.permutation(U)[:rows].astype(np.int32)
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    x[2, : cols // 2] = 0.75  # a run of equal scores straddling the threshold
+    x[5] = np.round(x[5] * 4) / 4  # many ties everywhere
+    ld = (cols + 7) & ~7
+    xp = torch.zeros(rows, ld); xp[:, :cols] = T(x)
+    xd = xp.to(dev)
+    out = ops.eval_topk(xd, T(users).to(dev), T(ptr).to(dev), T(col).to(dev), k, cols=cols).cpu().numpy()
+    masked = xd.cpu().numpy()[:, :cols]
+    for j, u in enumerate(users):
+        ref = x[j].copy(); ref[col[ptr[u]:ptr[u + 1]]] = -1e8
+        assert np.array_equal(masked[j], ref), "mask applied in place"
+        order = np.lexsort((np.arange(cols), -ref))[:k]  # descending score, ascending id on ties
+        assert np.array_equal(out[j], order), f"row {j}"
+
+
+def test_eval_metrics_golden(dev):
+    """dmm_eval_metrics against the reference's own calcRes outputs (tests/golden/calcres.npz)."""
+    from diffmm_amd import ops
+    z = load("calcres.npz")
+    top, users, lens, flat = z["top"], z["users"], z["its_len"], z["its_flat"]
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    out = ops.eval_metrics(T(top.astype(np.int32), dev), T(users.astype(np.int32), dev), T(ptr, dev), T(flat.astype(np.int64), dev)).sum(0).cpu().numpy()
+    close(out[0], z["recall"], rtol=1e-13, atol=0); close(out[1], z["ndcg"], rtol=1e-13, atol=0); close(out[2], z["precision"], rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("k", [1, 20, 64])
+def test_eval_metrics_random(dev, k):
+    import math
+    from diffmm_amd import ops
+    rng = np.random.default_rng(k)
+    U, I, rows = 300, 500, 257
+    lens = rng.integers(0, 40, size=U); lens[7] = 0
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([rng.choice(I, size=n, replace=False) for n in lens]).astype(np.int64)
+    users = rng.permutation(U)[:rows].astype(np.int32)
+    top = np.stack([rng.choice(I, size=k, replace=False) for _ in range(rows)]).astype(np.int32)
+    out = ops.eval_metrics(T(top, dev), T(users, dev), T(ptr, dev), T(col, dev)).cpu().numpy()
+    for j, u in enumerate(users):
+        truth = col[ptr[u]:ptr[u + 1]]
+        if len(truth) == 0:
+            assert (out[j] == 0).all()
+            continue
+        pos = [int(np.flatnonzero(top[j] == it)[0]) for it in truth if it in top[j]]
+        ideal = sum(1.0 / math.log2(l + 2) for l in range(min(len(truth), k)))
+        ref = [len(pos) / len(truth), sum(1.0 / math.log2(p + 2) for p in pos) / ideal, len(pos) / k]
+        assert np.allclose(out[j], ref, rtol=1e-13, atol=0), (j, out[j], ref)
+
+
 # ------------------------------------------------------------------------------------------------
 # diffusion pieces vs the reference's vectors
 # ------------------------------------------------------------------------------------------------
