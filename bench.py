@@ -93,7 +93,7 @@ def roofline(coach, args):
     emb = J.P.view("emb")
     ts = timed_launches(lambda: ops.spmm_batched([ops.SpmmOp(A, emb, y=J.Bx)]), 50)
     sb = A.algorithmic_bytes(4)
-    gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_kernel: Denoise layer 1 of the reverse chain, {nb} modalities x ({rows} x {Kp}) x ({H} x {Kp})^T per launch", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
+    gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_8ph_kernel (256x256 LDS-DMA tile): Denoise layer 1 of the reverse chain, {nb} modalities x ({rows} x {Kp}) x ({H} x {Kp})^T per launch", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
             "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6,
             "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6}
     spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

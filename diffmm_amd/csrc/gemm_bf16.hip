@@ -12,35 +12,9 @@
 // posterior mean c1*pred + c2*x_t (Model.py:375) and the next step's bf16 operand come out of the same pass.
 #include <stdlib.h>
 
-#include "common.h"
+#include "gemm_bf16.h"
 
 namespace dmm {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmBf16P {
-  const __bf16* A; long long lda;
-  const __bf16* B; long long ldb;
-  float* C; long long ldc;
-  __bf16* Cb; long long ldcb;
-  const float* bias;
-  const float* R; long long ldr;
-  const __bf16* Rb; long long ldrb;  // residual given in bf16 (alternative to R)
-  int M, N, K;
-  float alpha, e1, e2;
-  int act;
-  int mt, nt;  // tile counts
-  int part;    // XCD placement: 0 = grid order, 1 = each XCD owns a range of m tiles, 2 = a range of n tiles
-};
-
-constexpr int GB_BK = 64;
-constexpr int GB_MAX_BATCH = 4;
-
-struct GemmBf16Batch {
-  GemmBf16P p[GB_MAX_BATCH];  // same shape / scalars, different pointers (one per modality); blockIdx.y picks one
-  int n;
-};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -107,7 +81,12 @@ __device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][NT], const char* a_t, 
 }
 
 template <int BN>
-__device__ __forceinline__ void gemm_epilogue(const GemmBf16P& P, f32x16 (&acc)[2][BN / 64], char* smem, int m0, int n0, int wave, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmBf16P& Pk, f32x16 (&acc)[2][BN / 64], char* smem, int m0, int n0, int wave, int lane) {
+  // Every operand is copied out of the kernel-argument struct once: read through the reference, each use re-fetched its field
+  // (scalar load + full wait), which made the epilogue slower than a K = 1024 main loop.
+  struct { float* C; __bf16* Cb; const float* R; const __bf16* Rb; const float* bias; long long ldc, ldcb, ldr, ldrb; int M, N, act; float alpha, e1, e2; } P;
+  P.C = Pk.C; P.Cb = Pk.Cb; P.R = Pk.R; P.Rb = Pk.Rb; P.bias = Pk.bias; P.ldc = Pk.ldc; P.ldcb = Pk.ldcb; P.ldr = Pk.ldr; P.ldrb = Pk.ldrb;
+  P.M = Pk.M; P.N = Pk.N; P.act = Pk.act; P.alpha = Pk.alpha; P.e1 = Pk.e1; P.e2 = Pk.e2;
   constexpr int WN = BN / 2, NT = WN / 32;
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
   // ---- epilogue: every wave transposes its accumulators through its OWN LDS slab (the staging buffers are free after the last
@@ -283,9 +262,6 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_kernel(const GemmBf16Batc
 // One wave-instruction fills 8 tile rows (1 KiB, lane-linear in LDS); the XOR swizzle is applied on the per-lane SOURCE address.
 // Requires K % 64 == 0 (out-of-range ROWS read clamped addresses; their outputs are discarded by the epilogue).
 // ---------------------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
 template <int ROWS, int NWAVES>
 __device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, long long ld, int row0, int rows, int k0, char* tile, int wave, int lane) {
 #pragma unroll
@@ -542,6 +518,17 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   static const int force_tile = [] { const char* e = getenv("DMM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning knobs: 64 / 128 / 256
   static const int force_part = [] { const char* e = getenv("DMM_GEMM_PART"); return e ? atoi(e) : -1; }();
   const int M = a0->M, N = a0->N;
+  // 256 x 256 LDS-DMA tile (gemm_bf16_8ph.hip): K must be whole 64-wide tiles and the grid should fill the 256 CUs
+  static const int use_8ph = [] { const char* e = getenv("DMM_GEMM_8PH"); return e ? atoi(e) : 1; }();  // 0: register-staged tiles only
+  const long long t8 = (long long)cdiv(M, 256) * cdiv(N, 256) * n_batch;
+  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 192))) {
+    for (int i = 0; i < n_batch; ++i) {
+      b.p[i].mt = cdiv(M, 256); b.p[i].nt = cdiv(N, 256); b.p[i].part = force_part >= 0 ? force_part : 1;
+    }
+    launch_gemm_bf16_8ph(b, (hipStream_t)stream);
+    DMM_LAUNCH_CHECK("dmm_gemm_bf16_nt (256x256)");
+    return 0;
+  }
   const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * n_batch, t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * n_batch;
   int tile = t256 >= 768 ? 256 : (t128 >= 512 ? 128 : 64);  // big tiles only when they still fill the 256 CUs several times over
   if (force_tile) tile = force_tile;

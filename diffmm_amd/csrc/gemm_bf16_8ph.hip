@@ -1,0 +1,357 @@
+// 256 x 256 x 64 bf16 NT GEMM tile for the reverse diffusion chain (same contract and epilogue as gemm_bf16.hip), built around
+// LDS-DMA staging that stays in flight across barriers.  The register-staged tiles of gemm_bf16.hip top out where every K step
+// drains its loads in front of a workgroup barrier; here
+//   * 8 waves (2 along M x 4 along N, 128 x 64 outputs each = 32 MFMA 16x16x32 accumulators), one workgroup per CU, two waves per SIMD;
+//   * the two wave rows run ONE BARRIER APART: while the waves of row 0 issue the 16 MFMAs of a phase, the waves of row 1 (one per
+//     SIMD each) read their next fragments from LDS and issue the next LDS-DMA, and vice versa -- the matrix pipe of every SIMD
+//     always has a wave in its MFMA cluster;
+//   * a K tile is 4 phases (one 64 x 32 quadrant of the wave's outputs x K = 64 each); every phase reads at most one A unit and
+//     one B unit and refills exactly one 16 KiB unit of LDS with data that is needed 5-6 phases later;
+//   * completion is counted (s_waitcnt vmcnt(8): the four youngest units may still be in flight), never drained, and the
+//     barriers are raw s_barrier -- a __syncthreads() would wait for every outstanding LDS-DMA.
+//
+// LDS (128 KiB): 2 K-tile buffers x 4 units x 16 KiB.  A unit is 128 rows x 64 bf16 (128-byte rows, 16-byte chunk c of row r at
+// chunk c ^ ((r >> 1) & 7)); units are cut by WHEN they are read, not by where they sit in the tile:
+//   X0 / X1: rows {qa*64 .. qa*64+63} of both wave rows' 128-row halves of the A tile   (read in phase 0 / phase 2)
+//   Y0 / Y1: rows {qb*32 .. qb*32+31} of all four wave columns' 64-row quarters of B    (read in phase 0 / phase 1)
+// so a unit is dead right after the single phase that reads it and can be refilled two phases later.
+//
+// Per K tile t (buffer t & 1); issue order is one unit per phase, forever: ... Y1(t+1), X1(t+1), X0(t+2), Y0(t+2), Y1(t+2) ...
+//   phase 0: read Y0(t), X0(t)   issue Y1(t+1)   wait vmcnt(8)  -> Y1(t) has landed (needed in phase 1)     MFMA quadrant (0,0)
+//   phase 1: read Y1(t)          issue X1(t+1)   wait vmcnt(8)  -> X1(t) has landed (needed in phase 2)     MFMA quadrant (0,1)
+//   phase 2: read X1(t)          issue X0(t+2)   (nothing new is needed in phase 3)                          MFMA quadrant (1,1)
+//   phase 3:                     issue Y0(t+2)   wait vmcnt(8)  -> X0(t+1), Y0(t+1) have landed              MFMA quadrant (1,0)
+// Ordering rules (both follow from the wave rows being one barrier apart):
+//   RAW: a wave's wait for its part of a unit sits in front of the FIRST barrier of the phase before the one that reads it;
+//   WAR: a unit read in phase p is refilled in phase p+2 or later (the other row's reads of phase p retire one barrier later).
+// Loads past the last K tile are still issued (clamped to the last tile, into units nobody reads any more) so the counts stay
+// constant; everything is drained before the epilogue reuses LDS.
+#include "gemm_bf16.h"
+
+namespace dmm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int P8_UNIT = 128 * 128;  // bytes
+constexpr int P8_LDS = 8 * P8_UNIT;
+
+#define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define P8_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+struct P8Acc {
+  f32x4 v[2][2][4][2];  // [qa][qb][m tile][n tile]
+};
+
+template <int QA, int QB>
+__device__ __forceinline__ void p8_mma(P8Acc& acc, const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2]) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc.v[QA][QB][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][ks], b[nt][ks], acc.v[QA][QB][mt][nt], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void p8_read_a(bf16x8 (&a)[4][2], const char* unit, int wr, const int (&lo)[2]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[mt][ks] = *reinterpret_cast<const bf16x8*>(unit + (wr * 64 + mt * 16) * 128 + lo[ks]);
+}
+__device__ __forceinline__ void p8_read_b(bf16x8 (&b)[2][2], const char* unit, int wc, const int (&lo)[2]) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b[nt][ks] = *reinterpret_cast<const bf16x8*>(unit + (wc * 32 + nt * 16) * 128 + lo[ks]);
+}
+
+// ---- epilogue ---------------------------------------------------------------------------------------------------------------
+// 4 passes of 32 rows; every wave transposes its accumulators through its own LDS slab (row stride 68 floats: conflict-free for
+// the accumulator-layout writes, 16-byte aligned for the row reads), then each lane owns 4 consecutive columns of 8 rows per pass.
+// All operands of the epilogue are copied out of the kernel-argument struct ONCE (P8Epi, held in SGPRs): read through the struct
+// reference the compiler re-fetched every field at every use (scalar load + full wait, ~300 of them: 27-44 us per workgroup,
+// more than the K = 1024 main loop).
+struct P8Epi {
+  float* C; __bf16* Cb; const float* R; const __bf16* Rb; const float* bias;
+  long long ldc, ldcb, ldr, ldrb;
+  int M, N, act;
+  float alpha, e1, e2;
+};
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int P8_LDT = 68;
+
+template <int QA, int MP>
+__device__ __forceinline__ void p8_acc_to_lds(const P8Acc& acc, float* tile, int q, int fr) {
+#pragma unroll
+  for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(ml * 16 + q * 4 + r) * P8_LDT + qb * 32 + nt * 16 + fr] = acc.v[QA][qb][MP * 2 + ml][nt][r];
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+}
+
+// tanh for outputs that are rounded to bf16 anyway: 1 - 2 / (2^(2x log2 e) + 1), two transcendental instructions
+__device__ __forceinline__ float p8_tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// Interior tiles with 16-byte aligned operands: no bounds checks, running row pointers, and the residual rows of pass p+1 are
+// requested before pass p stores (loads and stores retire in order on one counter, so a load issued behind a store waits for it).
+template <int PASS, bool HAS_R, bool HAS_C, bool HAS_CB, int ACT>
+__device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float*& pR,
+                                             float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8]) {
+  if (HAS_R && PASS < 3) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rnext[it] = *reinterpret_cast<const float4*>(pR + (long long)(32 + it * 4) * E.ldr);
+  }
+  p8_acc_to_lds<(PASS >> 1), (PASS & 1)>(acc, tile, q, fr);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const float4 a4 = *reinterpret_cast<const float4*>(tile + (it * 4 + q) * P8_LDT + fr * 4);
+    float v[4] = {E.alpha * a4.x + b4.x, E.alpha * a4.y + b4.y, E.alpha * a4.z + b4.z, E.alpha * a4.w + b4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ACT == DMM_ACT_TANH) v[u] = HAS_C ? tanhf(v[u]) : p8_tanh_fast(v[u]);
+      else if (ACT == DMM_ACT_SIGMOID) v[u] = 1.0f / (1.0f + expf(-v[u]));
+    }
+    if (HAS_R) {
+      const float4 r4 = rcur[it];
+      v[0] = E.e1 * v[0] + E.e2 * r4.x; v[1] = E.e1 * v[1] + E.e2 * r4.y; v[2] = E.e1 * v[2] + E.e2 * r4.z; v[3] = E.e1 * v[3] + E.e2 * r4.w;
+    }
+    if (HAS_C) *reinterpret_cast<float4*>(pC + (long long)(it * 4) * E.ldc) = make_float4(v[0], v[1], v[2], v[3]);
+    if (HAS_CB) *reinterpret_cast<bf16x4*>(pCb + (long long)(it * 4) * E.ldcb) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
+  __builtin_amdgcn_wave_barrier();
+  if (HAS_R) pR += 32 * E.ldr;
+  if (HAS_C) pC += 32 * E.ldc;
+  if (HAS_CB) pCb += 32 * E.ldcb;
+}
+
+template <bool HAS_R, bool HAS_C, bool HAS_CB, int ACT>
+__device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
+  float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
+  const int n = n0 + wc * 64 + fr * 4;
+  const long long m = m0 + wr * 128 + q;
+  const float4 b4 = E.bias ? *reinterpret_cast<const float4*>(E.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* pR = HAS_R ? E.R + m * E.ldr + n : nullptr;
+  float* pC = HAS_C ? E.C + m * E.ldc + n : nullptr;
+  __bf16* pCb = HAS_CB ? E.Cb + m * E.ldcb + n : nullptr;
+  float4 ra[8], rb[8];
+  if (HAS_R) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) ra[it] = *reinterpret_cast<const float4*>(pR + (long long)(it * 4) * E.ldr);
+  }
+  p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
+  p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);
+  p8_fast_pass<2, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
+  p8_fast_pass<3, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);
+}
+
+// Edge tiles, unaligned operands and the rarely used operand combinations: bounds-checked, element-wise where needed.
+template <int QA, int MP>
+__device__ __forceinline__ void p8_generic_pass(const P8Epi& E, const P8Acc& acc, float* tile, int m0, int n0, int wave, int lane, bool vec_ok) {
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
+  const int mbase = m0 + wr * 128 + QA * 64 + MP * 32, nbase = n0 + wc * 64;
+  p8_acc_to_lds<QA, MP>(acc, tile, q, fr);
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + q;
+    const int m = mbase + row, n = nbase + fr * 4;
+    if (m >= E.M || n >= E.N) continue;
+    const float4 a4 = *reinterpret_cast<const float4*>(tile + row * P8_LDT + fr * 4);
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+    const int nv = min(4, E.N - n);
+    for (int u = 0; u < nv; ++u) {
+      float x = E.alpha * v[u] + (E.bias ? E.bias[n + u] : 0.f);
+      if (E.act == DMM_ACT_TANH) x = tanhf(x);
+      else if (E.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+      if (E.R) x = E.e1 * x + E.e2 * E.R[(long long)m * E.ldr + n + u];
+      else if (E.Rb) x = E.e1 * x + E.e2 * (float)E.Rb[(long long)m * E.ldrb + n + u];
+      v[u] = x;
+    }
+    if (nv == 4 && vec_ok) {
+      if (E.C) *reinterpret_cast<float4*>(E.C + (long long)m * E.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (E.Cb) *reinterpret_cast<bf16x4*>(E.Cb + (long long)m * E.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    } else {
+      for (int u = 0; u < nv; ++u) {
+        if (E.C) E.C[(long long)m * E.ldc + n + u] = v[u];
+        if (E.Cb) E.Cb[(long long)m * E.ldcb + n + u] = (__bf16)v[u];
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
+  P8Epi E;
+  E.C = P.C; E.Cb = P.Cb; E.R = P.R; E.Rb = P.Rb; E.bias = P.bias;
+  E.ldc = P.ldc; E.ldcb = P.ldcb; E.ldr = P.ldr; E.ldrb = P.ldrb;
+  E.M = P.M; E.N = P.N; E.act = P.act; E.alpha = P.alpha; E.e1 = P.e1; E.e2 = P.e2;
+  const bool vec_ok = (!E.C || (E.ldc % 4 == 0 && ((uintptr_t)E.C & 15) == 0)) && (!E.Cb || (E.ldcb % 4 == 0 && ((uintptr_t)E.Cb & 7) == 0));
+  const bool fast = vec_ok && m0 + 256 <= E.M && n0 + 256 <= E.N && !E.Rb && (!E.bias || ((uintptr_t)E.bias & 15) == 0) &&
+                    (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0));
+  if (fast && !E.R && !E.C && E.Cb && E.act == DMM_ACT_TANH) {
+    p8_epilogue_fast<false, false, true, DMM_ACT_TANH>(E, acc, smem, m0, n0, wave, lane);
+  } else if (fast && !E.R && !E.C && E.Cb && E.act == DMM_ACT_NONE) {
+    p8_epilogue_fast<false, false, true, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+  } else if (fast && E.R && E.C && E.Cb && E.act == DMM_ACT_NONE) {
+    p8_epilogue_fast<true, true, true, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+  } else if (fast && !E.R && E.C && !E.Cb && E.act == DMM_ACT_NONE) {
+    p8_epilogue_fast<false, true, false, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+  } else {
+    float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
+    p8_generic_pass<0, 0>(E, acc, tile, m0, n0, wave, lane, vec_ok);
+    p8_generic_pass<0, 1>(E, acc, tile, m0, n0, wave, lane, vec_ok);
+    p8_generic_pass<1, 0>(E, acc, tile, m0, n0, wave, lane, vec_ok);
+    p8_generic_pass<1, 1>(E, acc, tile, m0, n0, wave, lane, vec_ok);
+  }
+}
+
+#ifdef P8_TIMING
+__device__ unsigned long long p8_stamps[8 * 8192];
+#define P8_STAMP(i) if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 8192) p8_stamps[(blockIdx.x * 8 + (i))] = wall_clock64()
+#else
+#define P8_STAMP(i)
+#endif
+
+__global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Batch batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmBf16P& P = batch.p[blockIdx.y];
+  // Consecutive logical tiles share their A rows; the XCD-aware remap gives each XCD (private L2) a contiguous run of them.
+  const int bid = P.part ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int mtile = bid / P.nt, ntile = bid % P.nt;
+  const int m0 = mtile * 256, n0 = ntile * 256;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
+  const int nk = P.K / 64;
+  if (threadIdx.x < 64) { P8_STAMP(0); }
+
+  // ---- staging addresses: wave w fills row groups w and w + 8 (8 rows = 1 KiB each) of every unit
+  // (full per-lane pointers, held in registers: the asm barriers clobber memory, so anything read through P would be re-fetched)
+  const __bf16* offX[2][2];  // [unit][load]
+  const __bf16* offY[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = 8 * (wave + 8 * i) + (lane >> 3);       // unit row this lane fills
+    const int cs = ((lane & 7) ^ ((u >> 1) & 7)) * 8;     // source chunk (elements) that belongs at LDS chunk (lane & 7)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ra = m0 + (u >> 6) * 128 + h * 64 + (u & 63);
+      const int rb = n0 + (u >> 5) * 64 + h * 32 + (u & 31);
+      offX[h][i] = P.A + (long long)(ra < P.M ? ra : P.M - 1) * P.lda + cs;
+      offY[h][i] = P.B + (long long)(rb < P.N ? rb : P.N - 1) * P.ldb + cs;
+    }
+  }
+  auto issue = [&](const __bf16* const (&src)[2], int kt, char* unit) {
+    const int k0 = (kt < nk ? kt : nk - 1) * 64;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[0] + k0), (lds_ptr_t)(unit + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[1] + k0), (lds_ptr_t)(unit + (wave + 8) * 1024), 16, 0, 0);
+  };
+  // ---- fragment read offsets inside a unit (the row-dependent swizzle term depends only on the lane: rows step by 16)
+  int lo[2];
+  {
+    const int sw = (fr >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) lo[ks] = fr * 128 + (((q | (ks << 2)) ^ sw) << 4);
+  }
+
+  P8Acc acc;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc.v[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  char* const buf0 = smem;
+  char* const buf1 = smem + 4 * P8_UNIT;
+  constexpr int X0 = 0, X1 = P8_UNIT, Y0 = 2 * P8_UNIT, Y1 = 3 * P8_UNIT;
+  // prologue: the issue sequence up to (not including) phase 0 of tile 0
+  issue(offX[0], 0, buf0 + X0);
+  issue(offY[0], 0, buf0 + Y0);
+  issue(offY[1], 0, buf0 + Y1);
+  issue(offX[1], 0, buf0 + X1);
+  issue(offX[0], 1, buf1 + X0);
+  issue(offY[0], 1, buf1 + Y0);
+  P8_VMCNT8();   // X0(0), Y0(0) have landed (this wave's part)
+  P8_BARRIER();  // ... every wave's part
+  if (threadIdx.x < 64) { P8_STAMP(1); }
+  if (wr == 1) P8_BARRIER();  // row 1 runs one barrier behind row 0 from here on
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  for (int t = 0; t < nk; ++t) {
+    char* const cur = (t & 1) ? buf1 : buf0;
+    char* const oth = (t & 1) ? buf0 : buf1;
+    // ---- phase 0
+    p8_read_b(fb0, cur + Y0, wc, lo);
+    p8_read_a(fa, cur + X0, wr, lo);
+    issue(offY[1], t + 1, oth + Y1);
+    P8_VMCNT8();
+    P8_BARRIER();
+    P8_LGKM0();
+    p8_mma<0, 0>(acc, fa, fb0);
+    P8_BARRIER();
+    // ---- phase 1
+    p8_read_b(fb1, cur + Y1, wc, lo);
+    issue(offX[1], t + 1, oth + X1);
+    P8_VMCNT8();
+    P8_BARRIER();
+    P8_LGKM0();
+    p8_mma<0, 1>(acc, fa, fb1);
+    P8_BARRIER();
+    // ---- phase 2
+    p8_read_a(fa, cur + X1, wr, lo);
+    issue(offX[0], t + 2, cur + X0);
+    P8_BARRIER();
+    P8_LGKM0();
+    p8_mma<1, 1>(acc, fa, fb1);
+    P8_BARRIER();
+    // ---- phase 3
+    issue(offY[0], t + 2, cur + Y0);
+    P8_VMCNT8();
+    P8_BARRIER();
+    p8_mma<1, 0>(acc, fa, fb0);
+    P8_BARRIER();
+  }
+  if (wr == 0) P8_BARRIER();  // row 0 waits for row 1's last phase
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every LDS-DMA landed, every read done: LDS is free
+  if (threadIdx.x < 64) { P8_STAMP(2); }
+  p8_epilogue(P, acc, smem, m0, n0, wave, lane);
+  if (threadIdx.x < 64) { P8_STAMP(3); }
+#ifdef P8_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x < 64) { P8_STAMP(4); }
+#endif
+}
+
+void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL(gemm_bf16_nt_8ph_kernel, dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(512), P8_LDS, s, b);
+}
+
+}  // namespace dmm
+
+#ifdef P8_TIMING
+extern "C" int dmm_debug_p8_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dmm::p8_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -363,7 +363,8 @@ class DiffusionEngine:
         self.chain_rows = max(int(chain_rows or B_max), B_max)
         self.hp = dict(hp)
         self.dev = torch.device(device)
-        self.Kp = (items + te + 7) & ~7  # leading dimension of [x_t | temb | 0-pad]; also of out / dout
+        self.Kp = (items + te + 63) & ~63  # leading dimension of [x_t | temb | 0-pad]; also of out / dout.  Whole 64-wide K tiles: the
+        # 256 x 256 LDS-DMA GEMM tile (csrc/gemm_bf16_8ph.hip) takes no K remainder
         shapes = [("emb_layer.weight", (te, te)), ("emb_layer.bias", (te,)), ("in_layers.0.weight", (H, self.Kp)), ("in_layers.0.bias", (H,)),
                   ("out_layers.0.weight", (items, H)), ("out_layers.0.bias", (items,)), ("gate_layer.weight", (D, D)), ("gate_layer.bias", (D,))]
         self.P = [FlatParams(shapes, self.dev) for _ in range(M)]

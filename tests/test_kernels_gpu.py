@@ -218,12 +218,52 @@ def test_gemm_bf16_big_tile_and_batched(dev):
     for p, r in zip(probs, refs):
         close(p["out"][:, :N], r, rtol=1e-6, atol=1e-3, what="batched")
     M2, N2 = 9308, 1024
-    A = (torch.randn(M2, 128)).bfloat16(); Bw = (torch.randn(N2, 128)).bfloat16()
+    A = (torch.randn(M2, 136)).bfloat16(); Bw = (torch.randn(N2, 136)).bfloat16()  # K % 64 != 0 keeps the register-staged tiles
     outs = [torch.zeros(M2, N2, device=dev) for _ in range(3)]
     ops.gemm_bf16_nt_batched([dict(A=A.to(dev), B=Bw.to(dev), out=o) for o in outs])  # 3 * 37 * 8 = 888 tiles: the 256x128 kernel
     ref = A.double() @ Bw.double().t()
     for o in outs:
         close(o, ref, rtol=1e-5, atol=1e-3, what="big tile")
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 448])
+def test_gemm_bf16_lds_dma_tile(dev, K):
+    """The 256 x 256 LDS-DMA tile (csrc/gemm_bf16_8ph.hip; chosen when K % 64 == 0 and >= 192 tiles): integer data, so every
+    output is exact whatever the summation order -- a stale or early-read LDS unit (the kernel's counted waits / one-barrier
+    stagger) shows up as a wrong integer.  Ragged M and N (edge tiles take the generic epilogue, interior tiles the fast one),
+    3 problems per launch, every epilogue the chain uses, 1..7 K tiles (prologue / steady state / tail), repeated launches."""
+    from diffmm_amd import ops, _lib as L
+    M, N, nb = 2100, 2330, 3  # 9 x 10 x 3 = 270 tiles
+    ld = (N + 63) // 64 * 64
+    As, Bs, refs = [], [], []
+    for z in range(nb):
+        A = ((torch.arange(M * K).view(M, K) * (z + 3)) % 13 - 6).float().bfloat16()
+        Bw = ((torch.arange(N * K).view(N, K) * (z + 5)) % 7 - 3).float().bfloat16()
+        As.append(A.to(dev)); Bs.append(Bw.to(dev)); refs.append(A.double() @ Bw.double().t())
+    bias = (torch.arange(N) % 5 - 2).float()
+    R = [((torch.arange(M * ld).view(M, ld) * (z + 1)) % 9 - 4).float().to(dev) for z in range(nb)]
+    for rep in range(3):
+        C = [torch.full((M, ld), -7.0, device=dev) for _ in range(nb)]
+        Cb = [torch.full((M, ld), -7.0, dtype=torch.bfloat16, device=dev) for _ in range(nb)]
+        # posterior-mean epilogue of the chain: e1 * (A B^T + b) + e2 * R -> fp32 state + bf16 copy
+        ops.gemm_bf16_nt_batched([dict(A=As[z], B=Bs[z], out=C[z], out_bf16=Cb[z], bias=bias.to(dev), residual=R[z], e1=0.5, e2=2.0, N=N) for z in range(nb)])
+        for z in range(nb):
+            want = 0.5 * (refs[z] + bias.double()) + 2.0 * R[z][:, :N].cpu().double()
+            assert torch.equal(C[z][:, :N].cpu().double(), want), f"K={K} rep={rep} problem {z}: residual epilogue"
+            assert torch.equal(Cb[z][:, :N].cpu(), want.float().bfloat16()), "bf16 copy"
+            assert float((C[z][:, N:] + 7.0).abs().max()) == 0.0 and float((Cb[z][:, N:].float() + 7.0).abs().max()) == 0.0, "pad columns untouched"
+        # hidden layer of the chain: tanh -> bf16 only (fast tanh on interior tiles: bf16-level tolerance)
+        H16 = [torch.zeros(M, ld, dtype=torch.bfloat16, device=dev) for _ in range(nb)]
+        ops.gemm_bf16_nt_batched([dict(A=As[z], B=Bs[z], out=None, out_bf16=H16[z], bias=bias.to(dev), act=L.ACT_TANH, alpha=0.01, N=N) for z in range(nb)])
+        for z in range(nb):
+            close(H16[z][:, :N].float(), torch.tanh(0.01 * refs[z] + bias.double()), rtol=0, atol=4e-3, what="tanh -> bf16")
+    # plain fp32 output and a bf16 residual (generic epilogue)
+    out = torch.zeros(M, ld, device=dev)
+    ops.gemm_bf16_nt_batched([dict(A=As[0], B=Bs[0], out=out, N=N)] * 3)
+    assert torch.equal(out[:, :N].cpu().double(), refs[0])
+    Rb = R[1].bfloat16()
+    ops.gemm_bf16_nt_batched([dict(A=As[1], B=Bs[1], out=out, residual_bf16=Rb, e1=1.0, e2=1.0, N=N)] * 3)
+    assert torch.equal(out[:, :N].cpu().double(), refs[1] + Rb[:, :N].cpu().double())
 
 
 def test_gemm_asymmetric_identity_and_strided_views(dev):
