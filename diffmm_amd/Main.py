@@ -161,7 +161,7 @@ class Coach:
             edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, n_edges, precision=prec)
             if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
                 self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim))
-            adjs = [self.graph_builder.build(e) for e in edges]
+            adjs = self.graph_builder.build_all(edges)
         else:
             adjs = list(modal_adj_override)
         self.image_adj, self.text_adj = adjs[0], adjs[1]

@@ -518,10 +518,11 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   static const int force_tile = [] { const char* e = getenv("DMM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning knobs: 64 / 128 / 256
   static const int force_part = [] { const char* e = getenv("DMM_GEMM_PART"); return e ? atoi(e) : -1; }();
   const int M = a0->M, N = a0->N;
-  // 256 x 256 LDS-DMA tile (gemm_bf16_8ph.hip): K must be whole 64-wide tiles and the grid should fill the 256 CUs
+  // 256 x 256 LDS-DMA tile (gemm_bf16_8ph.hip): K must be whole 64-wide tiles and the grid should fill at least half of the 256
+  // CUs (the chain runs one launch per modality on concurrent streams)
   static const int use_8ph = [] { const char* e = getenv("DMM_GEMM_8PH"); return e ? atoi(e) : 1; }();  // 0: register-staged tiles only
   const long long t8 = (long long)cdiv(M, 256) * cdiv(N, 256) * n_batch;
-  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 192))) {
+  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 128))) {
     for (int i = 0; i < n_batch; ++i) {
       b.p[i].mt = cdiv(M, 256); b.p[i].nt = cdiv(N, 256); b.p[i].part = force_part >= 0 ? force_part : 1;
     }

@@ -11,6 +11,8 @@ algorithm itself needs a host value (the loss normalisation of Main.py:175-176).
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -607,6 +609,8 @@ class DiffusionEngine:
         for m in range(M):
             self._refresh_bf16_weights(m)
             self.cxa[m][:B, :I].copy_(x0)
+        if M > 1 and self.hp.get("chain_streams", os.environ.get("DMM_CHAIN_STREAMS", "1") != "0"):
+            return self._generate_views_streams(B)
         plan = self._chain_plans.get(("all", B))
         if plan is None:
             with L.Recorder() as plan:
@@ -623,6 +627,42 @@ class DiffusionEngine:
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
             self._chain_plans[("all", B)] = plan
         L.replay(plan)
+        fin = self.cxa if self.T % 2 == 0 else self.cxb
+        return [fin[m][:B, :I] for m in range(M)]
+
+    def _generate_views_streams(self, B: int) -> List[Tensor]:
+        """The modalities' chains are independent: each runs on its own HIP stream.  A layer-2 launch ends every workgroup in an
+        HBM-bound epilogue (fp32 state read + write, bf16 copy) and a layer-1 launch leaves CUs idle in its last round; with three
+        chains in flight the dispatcher fills those CUs with another chain's workgroups, and one chain's epilogues overlap another's
+        MFMA main loops.  Launches are recorded once (each call carries its stream) and replayed round-robin over the chains."""
+        I, M = self.I, self.M
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
+            self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
+        plan = self._chain_plans.get(("streams", B))
+        if plan is None:
+            per = []
+            for m in range(M):
+                with torch.cuda.stream(self._side_streams[m]), L.Recorder() as pm:
+                    cur, nxt, cur16, nxt16, h16 = self.cxa[m][:B], self.cxb[m][:B], self.cxa16[m][:B], self.cxb16[m][:B], self.ch16[m][:B]
+                    ops.zero_(nxt16)
+                    ops.cast_bf16(cur, cur16, cols=I, cols_pad=self.Kp)
+                    for i in range(self.T - 1, -1, -1):
+                        ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
+                        ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self.P[m].view("out_layers.0.bias"), residual=cur,
+                                         e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
+                        cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
+                per.append(pm)
+            plan = [c for group in zip(*per) for c in group]  # same length per chain: interleave launch by launch
+            self._chain_plans[("streams", B)] = plan
+        self._side_events[M].record(main)
+        for m in range(M):
+            self._side_streams[m].wait_event(self._side_events[M])
+        L.replay(plan)
+        for m in range(M):
+            self._side_events[m].record(self._side_streams[m])
+            main.wait_event(self._side_events[m])
         fin = self.cxa if self.T % 2 == 0 else self.cxb
         return [fin[m][:B, :I] for m in range(M)]
 

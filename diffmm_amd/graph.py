@@ -226,121 +226,59 @@ def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, kee
 # Index arithmetic runs as torch ops on the device the edge list already lives on (plumbing: sort / cumsum / scatter of
 # ~1e5 integers); the values follow the same float64 formula as normalized_bipartite_csr.
 # ======================================================================================================
-def plan_tasks_torch(rowptr: torch.Tensor, D: int, task_len: int = 32):
-    """torch port of plan_tasks (same Plan, bit for bit; checked against the numpy planner in tests/test_host_logic.py)."""
-    G = 1024 // D
-    if G * D != 1024 or D % 4:
-        raise ValueError(f"D={D} unsupported")
-    dev = rowptr.device
-    rp = rowptr.long()
-    length = rp[1:] - rp[:-1]
-    seg_len = 2 * G * task_len
-    k = torch.clamp((length + task_len - 1) // task_len, min=1, max=G)
-    giant = torch.nonzero(length > seg_len).flatten()
-    multi = torch.nonzero((k > 1) & (length <= seg_len)).flatten()
-    single = torch.nonzero(k == 1).flatten()
-    pad_row = torch.tensor([[-1, 0, 0, 1]], dtype=torch.long, device=dev)
-    parts = []
-    n_partial_blocks = 0
-    fix = torch.zeros((0, 4), dtype=torch.int32, device=dev)
-    if giant.numel():
-        nseg = (length[giant] + seg_len - 1) // seg_len
-        first = torch.cumsum(nseg, 0) - nseg
-        total_seg = int(nseg.sum())
-        seg_owner = torch.repeat_interleave(torch.arange(giant.numel(), device=dev), nseg, output_size=total_seg)
-        seg_j = torch.arange(total_seg, device=dev) - first[seg_owner]
-        sbeg = rp[giant][seg_owner] + seg_j * seg_len
-        send = torch.minimum(sbeg + seg_len, rp[giant + 1][seg_owner])
-        chunk = torch.clamp((send - sbeg + G - 1) // G, min=1)
-        sidx = torch.arange(total_seg, device=dev).repeat_interleave(G)
-        gidx = torch.arange(G, device=dev).repeat(total_seg)
-        beg = sbeg[sidx] + gidx * chunk[sidx]
-        end = torch.minimum(beg + chunk[sidx], send[sidx])
-        live = beg < end
-        nlive = torch.bincount(sidx[live], minlength=total_seg)
-        t = torch.full((total_seg * G, 4), -1, dtype=torch.long, device=dev)
-        t[:, 1:] = 0
-        t[live, 0] = giant[seg_owner[sidx[live]]]
-        t[live, 1] = beg[live]
-        t[live, 2] = end[live]
-        t[live, 3] = (gidx[live] << 16) | nlive[sidx[live]]
-        t[~live, 3] = 1
-        parts.append(t)
-        n_partial_blocks = total_seg
-        fix = torch.stack([giant, first, nseg, torch.zeros_like(giant)], dim=1).to(torch.int32)
-    if multi.numel():
-        km = k[multi]
-        kp = torch.ones_like(km)
-        while bool((kp < km).any()):  # next power of two, <= log2(G) rounds
-            kp = torch.where(kp < km, kp * 2, kp)
-        order = torch.sort(-kp, stable=True).indices
-        multi, kp = multi[order], kp[order]
-        kmm = torch.clamp(kp, max=G)
-        total = int(kmm.sum())
-        start = torch.cumsum(kmm, 0) - kmm
-        run_of = torch.repeat_interleave(torch.arange(multi.numel(), device=dev), kmm, output_size=total)
-        j = torch.arange(total, device=dev) - start[run_of]
-        chunk = (length[multi] + kmm - 1) // kmm
-        beg = rp[multi][run_of] + j * chunk[run_of]
-        end = torch.minimum(beg + chunk[run_of], rp[multi + 1][run_of])
-        live = beg < end
-        nlive = torch.bincount(run_of[live], minlength=multi.numel())
-        t = torch.full((total, 4), -1, dtype=torch.long, device=dev)
-        t[:, 1:] = 0
-        t[live, 0] = multi[run_of[live]]
-        t[live, 1] = beg[live]
-        t[live, 2] = end[live]
-        t[live, 3] = (j[live] << 16) | nlive[run_of[live]]
-        t[~live, 3] = 1
-        pad = (-total) % G
-        if pad:
-            t = torch.cat([t, pad_row.expand(pad, 4)])
-        parts.append(t)
-    head = int(sum(p.shape[0] for p in parts))
-    if single.numel():
-        t = torch.stack([single, rp[single], rp[single + 1], torch.ones_like(single)], dim=1)
-        pad = (-int(t.shape[0])) % G
-        if pad:
-            t = torch.cat([t, pad_row.expand(pad, 4)])
-        parts.append(t)
-    out = torch.cat(parts) if parts else pad_row.expand(G, 4)
-    return Plan(out.to(torch.int32).contiguous(), head, n_partial_blocks, fix)
-
-
 class DeviceGraphBuilder:
-    """Builds D^-1/2 (A + I) D^-1/2 CSR + task list on the device for edge lists that share the base graph's user degrees
-    (the rebuild keeps k_u = deg_u, Main.py:215-230): `item_idx[user_ptr[u] : user_ptr[u+1]]` are user u's items, distinct."""
+    """Builds D^-1/2 (A + I) D^-1/2 CSR + task list on the device (csrc/graph_build.hip: dmm_graph_build) for edge lists that
+    share the base graph's user degrees (the rebuild keeps k_u = deg_u, Main.py:215-230): `item_idx[user_ptr[u] : user_ptr[u+1]]`
+    are user u's items, distinct and ascending.  Bit-identical to `make_adjacency` on the same edges (tests/test_host_logic.py);
+    the only host read-back is the 32-byte size record."""
 
     def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = 32):
+        import ctypes as C
+        from . import _lib as L
         self.U, self.I, self.N, self.D, self.task_len = users, items, users + items, D, task_len
         self.dev = user_ptr.device
         up = user_ptr.long()
-        self.deg_u = up[1:] - up[:-1]
         self.E = int(up[-1])
-        self.edge_user = torch.repeat_interleave(torch.arange(users, device=self.dev), self.deg_u, output_size=self.E)
-        self.pos_user_edge = torch.arange(self.E, device=self.dev) + self.edge_user + 1  # slot of edge j inside its user row
+        self.user_ptr32 = up.to(torch.int32).contiguous()
+        self.edge_user = torch.repeat_interleave(torch.arange(users, device=self.dev, dtype=torch.int32), (up[1:] - up[:-1]), output_size=self.E).contiguous()
+        # d^-0.5 in fp64, computed by numpy exactly like normalized_bipartite_csr does (index = row length incl. the self loop)
+        with np.errstate(divide="ignore"):
+            self.dinv = torch.from_numpy(np.power(np.arange(self.N + 2, dtype=np.float64), -0.5)).to(self.dev)
+        sb, tc, fc = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().dmm_graph_build_scratch_bytes(users, items, self.E, D, C.byref(sb)), "dmm_graph_build_scratch_bytes")
+        L.check(L.lib().dmm_graph_build_task_capacity(users, items, self.E, D, task_len, C.byref(tc), C.byref(fc)), "dmm_graph_build_task_capacity")
+        self.scratch = torch.empty(sb.value, dtype=torch.uint8, device=self.dev)
+        self.task_cap, self.fix_cap = int(tc.value), int(fc.value)
+        self.nnz = 2 * self.E + self.N
 
     def build(self, item_idx: torch.Tensor, validate: bool = False) -> Adjacency:
-        U, I, N, E, dev = self.U, self.I, self.N, self.E, self.dev
-        item = item_idx[:E].long()
-        cnt_i = torch.bincount(item, minlength=I)
-        deg_n = torch.cat([self.deg_u, cnt_i]) + 1
-        rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
-        torch.cumsum(deg_n, 0, out=rowptr[1:])
-        nnz = 2 * E + N
-        col = torch.empty(nnz, dtype=torch.long, device=dev)
-        ar_u, ar_i = torch.arange(U, device=dev), torch.arange(I, device=dev)
-        col[rowptr[:U]] = ar_u                                  # user self loops come first in their rows (u < U <= U + item)
-        col[self.pos_user_edge] = U + item                      # a user's items keep the (ascending) top-k order
-        skey = torch.sort(item * U + self.edge_user).values    # item rows: users ascending
-        it_s = skey // U
-        col[(E + U) + torch.arange(E, device=dev) + it_s] = skey - it_s * U
-        col[rowptr[U + 1:] - 1] = U + ar_i                      # item self loops come last (users < U <= U + i)
-        dinv = deg_n.double() ** -0.5
-        row = torch.repeat_interleave(torch.arange(N, device=dev), deg_n, output_size=nnz)
-        val = ((dinv[row] * 1.0) * dinv[col]).float()
-        plan = plan_tasks_torch(rowptr, self.D, self.task_len)
-        if validate:
-            check_plan(rowptr.cpu().numpy(), plan.tasks.cpu().numpy(), self.D)
-        return Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr.to(torch.int32), col=col.to(torch.int32), val=val, tasks=plan.tasks,
-                         n_head_tasks=plan.head, n_partial_blocks=plan.n_partial_blocks, fix=plan.fix if plan.n_partial_blocks else None)
+        return self.build_all([item_idx], validate)[0]
+
+    def build_all(self, item_lists, validate: bool = False):
+        """One graph per edge list (the M modality graphs of a rebuild): all launches first, then ONE read-back of the size records."""
+        from . import _lib as L
+        dev, N, nnz = self.dev, self.N, self.nnz
+        metas = torch.zeros((len(item_lists), 8), dtype=torch.int32, device=dev)
+        outs = []
+        for i, item_idx in enumerate(item_lists):
+            if item_idx.dtype != torch.int32 or not item_idx.is_contiguous() or item_idx.numel() < self.E:
+                raise ValueError("DeviceGraphBuilder.build: item_idx must be a contiguous int32 tensor with one entry per edge")
+            rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            col = torch.empty(nnz, dtype=torch.int32, device=dev)
+            val = torch.empty(nnz, dtype=torch.float32, device=dev)
+            tasks = torch.empty((self.task_cap, 4), dtype=torch.int32, device=dev)
+            fix = torch.empty((self.fix_cap, 4), dtype=torch.int32, device=dev)
+            L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,
+                   L.ptr(self.dinv), L.ptr(rowptr), L.ptr(col), L.ptr(val), L.ptr(tasks), L.ptr(fix), L.ptr(metas[i]), L.ptr(self.scratch), L.stream())
+            outs.append((rowptr, col, val, tasks, fix))
+        adjs = []
+        for (rowptr, col, val, tasks, fix), m in zip(outs, metas.tolist()):
+            n_tasks, head, n_partial, n_fix, nnz_d = m[:5]
+            if nnz_d != nnz or n_tasks > self.task_cap or n_fix > self.fix_cap:
+                raise RuntimeError(f"dmm_graph_build: inconsistent sizes (nnz {nnz_d} vs {nnz}, tasks {n_tasks}/{self.task_cap}, fix {n_fix}/{self.fix_cap})")
+            tasks = tasks[:n_tasks]
+            if validate:
+                check_plan(rowptr.cpu().numpy().astype(np.int64), tasks.cpu().numpy(), self.D)
+            adjs.append(Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr, col=col, val=val, tasks=tasks, n_head_tasks=head, n_partial_blocks=n_partial,
+                                  fix=fix[:n_fix] if n_partial else None))
+        return adjs

@@ -231,6 +231,21 @@ int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids /*[rows] g
                   /*[U+1] indexed by user id*/, int32_t* out_idx, int rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Rebuild, second half: the modality graph of Main.py:232-253 (coo_matrix of the top-k edges -> DataHandler.makeTorchAdj,
+ * DataHandler.py:54-93) built on the device, together with the work list dmm_spmm_csr_f32 consumes.
+ *   user_ptr  int32 [U+1]  CSR of the user rows (k_u = train degree, fixed for the run);  edge_user int32 [E] = user of edge e
+ *   item_idx  int32 [E]    user-major item ids as dmm_topk_rows wrote them (distinct and ascending inside a user)
+ *   dinv_table f64 [>= max row length + 1]  entry d = d^-0.5 (host-computed, so values round exactly like the scipy path)
+ * Outputs (caller-allocated): rowptr int32 [U+I+1], col int32 [nnz], val f32 [nnz] with nnz = 2E + U + I (self loops included,
+ * columns ascending in every row), tasks int4 [dmm_graph_build_task_capacity], fix int4 [...], meta int32 [8] =
+ * {n_tasks, n_head_tasks, n_partial_blocks, n_fix, nnz, ...}.  Bit-identical to diffmm_amd/graph.py's host builder + planner. */
+int dmm_graph_build_scratch_bytes(int U, int I, int64_t E, int D, int64_t* bytes);
+int dmm_graph_build_task_capacity(int U, int I, int64_t E, int D, int task_len, int64_t* tasks, int64_t* fix);
+int dmm_graph_build(const int32_t* user_ptr, const int32_t* edge_user, const int32_t* item_idx, int U, int I, int64_t E, int D, int task_len,
+                    const double* dinv_table, int32_t* rowptr, int32_t* col, float* val, void* tasks, void* fix, int32_t* meta, void* scratch,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Evaluation: Coach.testEpoch (Main.py:403-411).  score [rows, cols] holds usrEmbeds[users] @ itmEmbeds^T (dmm_gemm); every
  * train item of users[r] (CSR trn_ptr/trn_col over ALL users, int64) is set to -1e8 IN PLACE -- the reference's
  * `allPreds * (1 - trnMask) - trnMask * 1e8` -- and the k best columns of the row are written to out[r*k .. r*k+k) in

@@ -494,6 +494,43 @@ def test_eval_metrics_random(dev, k):
         assert np.allclose(out[j], ref, rtol=1e-13, atol=0), (j, out[j], ref)
 
 
+@pytest.mark.parametrize("name,D,task_len", [("toy", 8, 2), ("mid", 16, 4), ("mid", 256, 4), ("tiktok", 64, 32), ("hub", 64, 32), ("hub", 4, 8)])
+def test_device_graph_builder_equals_host_builder(dev, name, D, task_len):
+    """dmm_graph_build (rebuilt modality graph + SpMM work list on the device) is bit-identical to the numpy builder and planner.
+    'hub': one item chosen by 6000 users -- an item row longer than the in-LDS sort (bitmap path) and giant rows in the plan."""
+    from diffmm_amd import graph, synth
+    rng = np.random.default_rng(1)
+    if name == "hub":
+        users, n_items = 6500, 300
+        deg = rng.integers(1, 6, size=users); deg[17] = 0
+        lists = []
+        for u, d in enumerate(deg):
+            rest = rng.choice(np.arange(1, n_items), size=max(0, d - 1), replace=False) if d else np.zeros(0, np.int64)
+            lists.append(np.sort(np.concatenate([[0], rest])) if (d and u < 6000) else np.sort(rng.choice(np.arange(1, n_items), size=d, replace=False)))
+        items = np.concatenate(lists)
+    else:
+        g = synth.named(name)
+        users, n_items = g.users, g.items
+        deg = np.bincount(g.trn_rows, minlength=users)
+        pop = 1.0 / np.arange(1, n_items + 1); pop /= pop.sum()  # skewed item choice: a few very long item rows, like a real rebuild
+        items = np.concatenate([np.sort(rng.choice(n_items, size=d, replace=False, p=pop)) for d in deg if d])
+    ptr = np.concatenate([[0], np.cumsum(deg)])
+    rows = np.repeat(np.arange(users), deg)
+    rp, c, v = graph.normalized_bipartite_csr(rows, items, users, n_items)
+    plan = graph.plan_tasks(rp, D, task_len, full=True)
+    gb = graph.DeviceGraphBuilder(T(ptr, dev), users, n_items, D, task_len)
+    for rep in range(2):  # the builder's scratch is reused
+        adj = gb.build(T(items.astype(np.int32), dev), validate=True)
+        assert np.array_equal(adj.rowptr.cpu().numpy(), rp), "rowptr"
+        assert np.array_equal(adj.col.cpu().numpy(), c), "col"
+        assert np.array_equal(adj.val.cpu().numpy(), v), "val (bitwise)"
+        assert np.array_equal(adj.tasks.cpu().numpy(), plan.tasks) and adj.n_head_tasks == plan.head and adj.n_partial_blocks == plan.n_partial_blocks
+        if plan.n_partial_blocks:
+            assert np.array_equal(adj.fix.cpu().numpy(), plan.fix)
+    if name == "hub":
+        assert plan.n_partial_blocks > 0 and np.diff(rp).max() > 4096
+
+
 # ------------------------------------------------------------------------------------------------
 # diffusion pieces vs the reference's vectors
 # ------------------------------------------------------------------------------------------------
