@@ -19,7 +19,8 @@ struct GemmBf16P {
   float alpha, e1, e2;
   int act;
   int mt, nt;  // tile counts
-  int part;    // XCD placement: 0 = grid order, 1 = each XCD owns a range of m tiles, 2 = a range of n tiles
+  int part;    // XCD placement: 0 = grid order; register-staged tiles: 1 = each XCD owns a range of m tiles, 2 = a range of n tiles;
+               // 256x256 tile: 1 = XCD-contiguous row-major ids, 2 = XCD-contiguous supertiles (default)
 };
 
 constexpr int GB_BK = 64;

@@ -106,6 +106,21 @@ __device__ __forceinline__ float p8_tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// The epilogue's streams (fp32 state in and out, bf16 copy out: 640 KiB per tile, each byte touched once per launch) are marked
+// non-temporal so they do not evict the A / B panels the other CUs of the XCD are re-reading from L2.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 p8_ld_stream(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void p8_st_stream(float* p, const float (&v)[4]) {
+  __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p));
+}
+__device__ __forceinline__ void p8_st_stream(__bf16* p, const float (&v)[4]) {
+  const bf16x4 b = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x2, b), reinterpret_cast<u32x2*>(p));
+}
+
 // Interior tiles with 16-byte aligned operands: no bounds checks, running row pointers, and the residual rows of pass p+1 are
 // requested before pass p stores (loads and stores retire in order on one counter, so a load issued behind a store waits for it).
 template <int PASS, bool HAS_R, bool HAS_C, bool HAS_CB, int ACT>
@@ -113,7 +128,7 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
                                              float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8]) {
   if (HAS_R && PASS < 3) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) rnext[it] = *reinterpret_cast<const float4*>(pR + (long long)(32 + it * 4) * E.ldr);
+    for (int it = 0; it < 8; ++it) rnext[it] = p8_ld_stream(pR + (long long)(32 + it * 4) * E.ldr);
   }
   p8_acc_to_lds<(PASS >> 1), (PASS & 1)>(acc, tile, q, fr);
 #pragma unroll
@@ -129,8 +144,8 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
       const float4 r4 = rcur[it];
       v[0] = E.e1 * v[0] + E.e2 * r4.x; v[1] = E.e1 * v[1] + E.e2 * r4.y; v[2] = E.e1 * v[2] + E.e2 * r4.z; v[3] = E.e1 * v[3] + E.e2 * r4.w;
     }
-    if (HAS_C) *reinterpret_cast<float4*>(pC + (long long)(it * 4) * E.ldc) = make_float4(v[0], v[1], v[2], v[3]);
-    if (HAS_CB) *reinterpret_cast<bf16x4*>(pCb + (long long)(it * 4) * E.ldcb) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
+    if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, v);
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
   __builtin_amdgcn_wave_barrier();
@@ -152,7 +167,7 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
   float4 ra[8], rb[8];
   if (HAS_R) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) ra[it] = *reinterpret_cast<const float4*>(pR + (long long)(it * 4) * E.ldr);
+    for (int it = 0; it < 8; ++it) ra[it] = p8_ld_stream(pR + (long long)(it * 4) * E.ldr);
   }
   p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
   p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);
@@ -230,9 +245,27 @@ __device__ unsigned long long p8_stamps[8 * 8192];
 __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Batch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GemmBf16P& P = batch.p[blockIdx.y];
-  // Consecutive logical tiles share their A rows; the XCD-aware remap gives each XCD (private L2) a contiguous run of them.
-  const int bid = P.part ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int mtile = bid / P.nt, ntile = bid % P.nt;
+  // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each) and an XCD runs ~32 of them at a time.
+  // xcd_remap gives every XCD one contiguous run of logical tile ids; the ids walk the tile grid in SUPERTILES of SM x SN tiles
+  // (SM * SN ~ 32), so the tiles an XCD has in flight share SM row panels of A and SN row panels of B instead of streaming all
+  // of B for every row panel (row-major order: (1 + 32) panels per 32 tiles; 4 x 8 supertiles: 12).
+  int mtile, ntile;
+  {
+    const int bid = P.part ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (P.part == 2) {
+      const int SN = P.nt < 8 ? P.nt : 8, SM = 32 / SN > 0 ? 32 / SN : 1;
+      const int band = bid / (SM * P.nt);
+      const int hb = min(SM, P.mt - band * SM);
+      const int i = bid - band * SM * P.nt;
+      const int c = i / (hb * SN), r = i - c * hb * SN;
+      const int w = min(SN, P.nt - c * SN);
+      mtile = band * SM + r / w;
+      ntile = c * SN + r % w;
+    } else {
+      mtile = bid / P.nt;
+      ntile = bid % P.nt;
+    }
+  }
   const int m0 = mtile * 256, n0 = ntile * 256;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;

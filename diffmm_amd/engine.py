@@ -141,6 +141,10 @@ class JointEngine:
     def set_adjacency(self, adj: Adjacency, modal_adj: Sequence[Adjacency]):
         assert adj.n == self.N and adj.D == self.D and len(modal_adj) == self.M
         self.adj, self.modal_adj = adj, list(modal_adj)
+        # launch plans hold raw pointers into the adjacency arrays: drop every plan recorded for a graph set that is gone
+        live = (adj.uid, tuple(a.uid for a in self.modal_adj))
+        for k in [k for k in self._plans if (k[2], k[3]) != live]:
+            del self._plans[k]
 
     # -- forward of gcn_MM (+ optionally the 3 perturbed CL layers) ---------------------------------
     def _project(self, precision: int):
@@ -265,7 +269,7 @@ class JointEngine:
         marshalling.  Per step only the batch indices (copied into static buffers), the Philox offsets and Adam's (lr, step)
         change."""
         B = int(users.shape[0])
-        key = (B, precision, id(self.adj), tuple(id(a) for a in self.modal_adj), self.world)
+        key = (B, precision, self.adj.uid, tuple(a.uid for a in self.modal_adj), self.world)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 8:

@@ -7,7 +7,8 @@ pointers / column ids, fp32 values) plus the task list the HIP SpMM kernel consu
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+import itertools
+from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
 import numpy as np
@@ -168,9 +169,14 @@ def check_plan(rowptr: np.ndarray, tasks: np.ndarray, D: int) -> None:
         assert (t[h:h + m, 0] == t[h, 0]).all() and np.array_equal(pos[h:h + m], np.arange(m)), "run not contiguous"
 
 
+_adjacency_uid = itertools.count(1)
+
+
 @dataclass
 class Adjacency:
-    """A normalised adjacency resident in HBM: CSR arrays + the SpMM task list for one embedding width."""
+    """A normalised adjacency resident in HBM: CSR arrays + the SpMM task list for one embedding width.
+    `uid` is unique for the life of the process: recorded launch plans (which hold raw device pointers into these arrays) are keyed
+    by it -- never by id(), which CPython reuses as soon as an object is collected."""
     n: int
     nnz: int
     D: int
@@ -182,6 +188,7 @@ class Adjacency:
     n_partial_blocks: int = 0  # leading workgroups that are segments of giant rows
     fix: Optional[torch.Tensor] = None  # int32 [n_giant, 4]: row, first_slot, n_slots, 0
     host: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
+    uid: int = field(default_factory=lambda: next(_adjacency_uid))
 
     @property
     def n_tasks(self) -> int:

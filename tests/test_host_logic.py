@@ -118,3 +118,21 @@ def test_schedule_tables_match_reference_vectors():
             s = schedule_tables(Tn, sc, 0.0001, 0.02)
             for k in s:
                 assert np.allclose(s[k], z[f"T{Tn}_s{sc}/{k}"], rtol=1e-12, atol=1e-15), (Tn, sc, k)
+
+
+def test_adjacency_uid_is_never_reused():
+    """Launch plans are keyed by Adjacency.uid.  id() of a collected object is handed out again by CPython (that is how a plan
+    recorded for the graphs of epoch e was once replayed, stale pointers and task counts included, on the graphs of epoch e+2)."""
+    import gc
+    import torch
+    from diffmm_amd import graph
+    z = torch.zeros(1, dtype=torch.int32)
+    mk = lambda: graph.Adjacency(n=1, nnz=1, D=64, rowptr=z, col=z, val=z.float(), tasks=torch.zeros((1, 4), dtype=torch.int32))
+    seen, ids = set(), set()
+    for _ in range(200):
+        a = mk()
+        assert a.uid not in seen
+        seen.add(a.uid); ids.add(id(a))
+        del a
+        gc.collect()
+    assert len(ids) < 200, "this interpreter did reuse id() values, as the docstring says"

@@ -4,8 +4,13 @@ import numpy as np, torch
 from diffmm_amd import ops, _lib as L
 
 dev = torch.device("cuda:0")
+import os
 M, N, nb = 9308, 6710, 3
-for K, mode in ((64, "cb"), (1024, "cb"), (1024, "res"), (6720, "l1")):
+cases = ((64, "cb"), (1024, "cb"), (1024, "res"), (6720, "l1"))
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    M, N, nb = 2048, 2048, 1
+    cases = ((1024, "res"), (1024, "cb"))
+for K, mode in cases:
     if mode == "l1":
         N = 1024
     Np = (N + 63) // 64 * 64
@@ -34,3 +39,5 @@ for K, mode in ((64, "cb"), (1024, "cb"), (1024, "res"), (6720, "l1")):
         print(f"   {name:15s} mean {x.mean():7.2f}  p10 {np.percentile(x, 10):7.2f}  p90 {np.percentile(x, 90):7.2f} us")
     starts = np.sort((s[:, 0] - t0) * 0.01)
     print("   block starts (us) every 100th:", np.round(starts[::100], 1)[:12])
+    if os.environ.get("P8_DUMP"):
+        np.save(os.path.join("gpurun_out", f"stamps_{mode}_{K}_{os.environ['P8_DUMP']}.npy"), s)
