@@ -126,9 +126,9 @@ __device__ __forceinline__ void p8_st_stream(__bf16* p, const float (&v)[4]) {
 template <int PASS, bool HAS_R, bool HAS_C, bool HAS_CB, int ACT>
 __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float*& pR,
                                              float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8]) {
-  if (HAS_R && PASS < 3) {
+  if (HAS_R && PASS < 2) {  // two passes ahead: 16 KiB of residual rows in flight per wave while a pass is being stored
 #pragma unroll
-    for (int it = 0; it < 8; ++it) rnext[it] = p8_ld_stream(pR + (long long)(32 + it * 4) * E.ldr);
+    for (int it = 0; it < 8; ++it) rnext[it] = p8_ld_stream(pR + (long long)(64 + it * 4) * E.ldr);
   }
   p8_acc_to_lds<(PASS >> 1), (PASS & 1)>(acc, tile, q, fr);
 #pragma unroll
@@ -164,15 +164,17 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
   const float* pR = HAS_R ? E.R + m * E.ldr + n : nullptr;
   float* pC = HAS_C ? E.C + m * E.ldc + n : nullptr;
   __bf16* pCb = HAS_CB ? E.Cb + m * E.ldcb + n : nullptr;
-  float4 ra[8], rb[8];
+  float4 ra[8], rb[8], rc[8];
   if (HAS_R) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) ra[it] = p8_ld_stream(pR + (long long)(it * 4) * E.ldr);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rb[it] = p8_ld_stream(pR + (long long)(32 + it * 4) * E.ldr);
   }
-  p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
-  p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);
-  p8_fast_pass<2, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
-  p8_fast_pass<3, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);
+  p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rc);  // uses ra, requests pass 2 into rc
+  p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);  // uses rb, requests pass 3 into ra
+  p8_fast_pass<2, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rc, rb);
+  p8_fast_pass<3, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
 }
 
 // Edge tiles, unaligned operands and the rarely used operand combinations: bounds-checked, element-wise where needed.
