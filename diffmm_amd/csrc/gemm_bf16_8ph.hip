@@ -228,6 +228,8 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
     p8_epilogue_fast<true, true, true, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
   } else if (fast && !E.R && E.C && !E.Cb && E.act == DMM_ACT_NONE) {
     p8_epilogue_fast<false, true, false, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+  } else if (fast && !E.R && E.C && E.Cb && E.act == DMM_ACT_TANH) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
+    p8_epilogue_fast<false, true, true, DMM_ACT_TANH>(E, acc, smem, m0, n0, wave, lane);
   } else {
     float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
     p8_generic_pass<0, 0>(E, acc, tile, m0, n0, wave, lane, vec_ok);

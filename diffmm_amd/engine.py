@@ -405,10 +405,11 @@ class DiffusionEngine:
         self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
         self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
-        Bp8 = (B_max + 7) & ~7
+        Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
         self.dpre16, self.doutT16, self.hT16, self.dpreT16 = zb(B_max, H), zb(items, Bp8), zb(H, Bp8), zb(H, Bp8)
         self.xcatT16, self.w1T16, self.w2T16 = zb(Kp, Bp8), zb(Kp, H), zb(H, Kp)
+        self._ws = None  # per-modality workspaces of the batched training step (allocated on first use)
         self.rng_step = 0
         self.world, self.rank = 1, 0
 
@@ -505,32 +506,14 @@ class DiffusionEngine:
         ops.zero_(P.grad)
         ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], dout, dum)
         ops.gemm(dum, feat, out=dout, trans_b=True, precision=precision, N=I, accumulate=True)  # d(out F) -> dout += dum F^T
-        if precision == 1:
-            # every large product in NT form on the bf16 kernel; K-contiguous operands come from cast / transpose-cast passes
-            Bp8 = (B + 7) & ~7
-            ops.transpose_cast_bf16(dout, self.doutT16, rows=B, cols=I)            # dout^T  [I, B]
-            ops.transpose_cast_bf16(a["h"][:B], self.hT16, rows=B, cols=H)          # h^T     [H, B]
-            ops.gemm_bf16_nt(self.doutT16[:, :Bp8], self.hT16[:, :Bp8], out=P.g("out_layers.0.weight"), N=H, K=Bp8)  # dW2 = dout^T h
-            ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
-            ops.cast_bf16(dout, self.xb16[:B])                                       # dout (pad columns are zero)
-            ops.transpose_cast_bf16(P.view("out_layers.0.weight"), self.w2T16, rows=I, cols=H)  # W2^T [H, I -> Kp]
-            ops.gemm_bf16_nt(self.xb16[:B], self.w2T16, out=self.dh[:B], K=Kp)     # dh = dout W2
-            ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
-            ops.transpose_cast_bf16(self.dpre[:B], self.dpreT16, rows=B, cols=H)    # dpre^T  [H, B]
-            ops.transpose_cast_bf16(a["xcat"][:B], self.xcatT16, rows=B, cols=Kp)   # xcat^T  [Kp, B]
-            ops.gemm_bf16_nt(self.dpreT16[:, :Bp8], self.xcatT16[:, :Bp8], out=P.g("in_layers.0.weight"), K=Bp8)  # dW1 = dpre^T [x|temb]
-            ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
-            ops.cast_bf16(self.dpre[:B], self.dpre16[:B])
-            ops.transpose_cast_bf16(P.view("in_layers.0.weight"), self.w1T16, rows=H, cols=Kp)  # W1^T [Kp, H]
-            ops.gemm_bf16_nt(self.dpre16[:B], self.w1T16, out=self.dxcat[:B])       # d[x'|temb] = dpre W1
-        else:
-            ops.gemm(dout, a["h"][:B], out=P.g("out_layers.0.weight"), trans_a=True, precision=precision, M=I)  # dW2 = dout^T h
-            ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
-            ops.gemm(dout, P.view("out_layers.0.weight"), out=self.dh[:B], precision=precision, K=I)  # dh = dout W2
-            ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
-            ops.gemm(self.dpre[:B], a["xcat"][:B], out=P.g("in_layers.0.weight"), trans_a=True, precision=precision)  # dW1 = dpre^T [x|temb]
-            ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
-            ops.gemm(self.dpre[:B], P.view("in_layers.0.weight"), out=self.dxcat[:B], precision=precision)  # d[x'|temb] = dpre W1
+        # (the precision == 1 training step runs staged over the modalities on the bf16 NT kernels: _backward_batched)
+        ops.gemm(dout, a["h"][:B], out=P.g("out_layers.0.weight"), trans_a=True, precision=precision, M=I)  # dW2 = dout^T h
+        ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
+        ops.gemm(dout, P.view("out_layers.0.weight"), out=self.dh[:B], precision=precision, K=I)  # dh = dout W2
+        ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
+        ops.gemm(self.dpre[:B], a["xcat"][:B], out=P.g("in_layers.0.weight"), trans_a=True, precision=precision)  # dW1 = dpre^T [x|temb]
+        ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
+        ops.gemm(self.dpre[:B], P.view("in_layers.0.weight"), out=self.dxcat[:B], precision=precision)  # d[x'|temb] = dpre W1
         ops.temb_bwd(a["t"][:B], self.dxcat[:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
         if precision == 1:
             ops.zero_(self.dpg[:B])
@@ -539,6 +522,92 @@ class DiffusionEngine:
         ops.gemm(self.dgate[:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=precision)  # dWg = dgate_pre^T proj
         ops.colsum(self.dgate[:B], B, D, P.g("gate_layer.bias"))
 
+    # -- precision == 1: the same arithmetic as loss_forward / loss_backward, staged over the modalities ------------------------
+    def _workspaces(self):
+        if self._ws is None:
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+            zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
+            Bm, Kp, H, D, I = self.B_max, self.Kp, self.H, self.D, self.I
+            Bp = (Bm + 63) & ~63
+            self._ws = []
+            for m in range(self.M):
+                if m == 0:  # modality 0 keeps the buffers the single-modality path uses
+                    w = dict(xa16=self.cxa16[0], h16=self.ch16[0], xb16=self.cxb16[0], dout=self.dout, dum=self.dum, doutT16=self.doutT16, hT16=self.hT16,
+                             w2T16=self.w2T16, dh=self.dh, dpre=self.dpre, dpreT16=self.dpreT16, xcatT16=self.xcatT16, dpre16=self.dpre16,
+                             w1T16=self.w1T16, dxcat=self.dxcat, dpg=self.dpg, dgate=self.dgate, dproj=self.dproj)
+                else:
+                    w = dict(xa16=self.cxa16[m], h16=self.ch16[m], xb16=self.cxb16[m], dout=z(Bm, Kp), dum=z(Bm, D), doutT16=zb(I, Bp), hT16=zb(H, Bp),
+                             w2T16=zb(H, Kp), dh=z(Bm, H), dpre=z(Bm, H), dpreT16=zb(H, Bp), xcatT16=zb(Kp, Bp), dpre16=zb(Bm, H), w1T16=zb(Kp, H),
+                             dxcat=z(Bm, Kp), dpg=z(Bm, D), dgate=z(Bm, D), dproj=z(Bm, D))
+                self._ws.append(w)
+        return self._ws
+
+    def _forward_batched(self, x0p: Tensor, ts, noise, feats, i_embs: Tensor, reg_term: float):
+        B, I, M = x0p.shape[0], self.I, self.M
+        W = self._workspaces()
+        for m in range(M):
+            a, P = self.act[m], self.P[m]
+            a["t"][:B].copy_(ts[m])
+            ops.qsample_temb(x0p, noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, P.view("emb_layer.weight"),
+                             P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None, seed=self.hp.get("seed", 1818),
+                             offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
+            self._gate_fwd(m, a["xcat"][:B], feats[m], 1)
+            ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
+            ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+            self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
+            ops.cast_bf16(a["xcat"][:B], W[m]["xa16"][:B])
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["xa16"][:B], B=self.w1_16[m], out=self.act[m]["h"][:B], out_bf16=W[m]["h16"][:B],
+                                       bias=self.P[m].view("in_layers.0.bias"), act=L.ACT_TANH) for m in range(M)])
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self.w2_16[m], out=self.act[m]["out"][:B], bias=self.P[m].view("out_layers.0.bias"), N=I)
+                                  for m in range(M)])
+        for m in range(M):
+            a = self.act[m]
+            ops.zero_(a["um"][:B])
+            ops.gemm(a["out"][:B], feats[m], out=a["um"][:B], precision=1, K=I, split_k=8)
+            if m == 0:
+                ops.zero_(self.ui[:B])
+                ops.gemm(x0p, i_embs, out=self.ui[:B], precision=1, K=I, split_k=8)
+            a["w"] = self.w_table[a["t"][:B].long()]
+            ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
+
+    def _backward_batched(self, x0p: Tensor, feats, reg_term: float, gscale: float):
+        B, I, H, D, Kp, M = x0p.shape[0], self.I, self.H, self.D, self.Kp, self.M
+        W = self._workspaces()
+        Bp = (B + 63) & ~63
+        for m in range(M):
+            a, P, w = self.act[m], self.P[m], W[m]
+            ops.zero_(P.grad)
+            ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
+                          w["dum"][:B])
+            ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)  # dout += dum F^T
+            ops.transpose_cast_bf16(w["dout"][:B], w["doutT16"], rows=B, cols=I, rows_pad=Bp)      # dout^T [I, B]
+            ops.transpose_cast_bf16(a["h"][:B], w["hT16"], rows=B, cols=H, rows_pad=Bp)            # h^T    [H, B]
+            ops.colsum(w["dout"][:B], B, I, P.g("out_layers.0.bias"))
+            ops.cast_bf16(w["dout"][:B], w["xb16"][:B])                                             # dout (pad columns are zero)
+            ops.transpose_cast_bf16(P.view("out_layers.0.weight"), w["w2T16"], rows=I, cols=H)     # W2^T   [H, I -> Kp]
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["doutT16"][:, :Bp], B=W[m]["hT16"][:, :Bp], out=self.P[m].g("out_layers.0.weight"), N=H, K=Bp)
+                                  for m in range(M)])                                               # dW2 = dout^T h
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["xb16"][:B], B=W[m]["w2T16"], out=W[m]["dh"][:B], K=Kp) for m in range(M)])  # dh = dout W2
+        for m in range(M):
+            a, P, w = self.act[m], self.P[m], W[m]
+            ops.tanh_bwd(w["dh"][:B], a["h"][:B], w["dpre"][:B])
+            ops.transpose_cast_bf16(w["dpre"][:B], w["dpreT16"], rows=B, cols=H, rows_pad=Bp)      # dpre^T [H, B]
+            ops.transpose_cast_bf16(a["xcat"][:B], w["xcatT16"], rows=B, cols=Kp, rows_pad=Bp)     # xcat^T [Kp, B]
+            ops.colsum(w["dpre"][:B], B, H, P.g("in_layers.0.bias"))
+            ops.cast_bf16(w["dpre"][:B], w["dpre16"][:B])
+            ops.transpose_cast_bf16(P.view("in_layers.0.weight"), w["w1T16"], rows=H, cols=Kp)     # W1^T   [Kp, H]
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["dpreT16"][:, :Bp], B=W[m]["xcatT16"][:, :Bp], out=self.P[m].g("in_layers.0.weight"), K=Bp)
+                                  for m in range(M)])                                               # dW1 = dpre^T [x|temb]
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=W[m]["w1T16"], out=W[m]["dxcat"][:B]) for m in range(M)])   # d[x'|temb] = dpre W1
+        for m in range(M):
+            a, P, w = self.act[m], self.P[m], W[m]
+            ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
+            ops.zero_(w["dpg"][:B])
+            ops.gemm(w["dxcat"][:B], feats[m], out=w["dpg"][:B], precision=1, K=I, split_k=8)      # d(proj*gate) = dx' F
+            ops.gate_bwd(w["dpg"][:B], a["proj"][:B], a["gate"][:B], w["dproj"][:B], w["dgate"][:B])
+            ops.gemm(w["dgate"][:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=1)  # dWg = dgate_pre^T proj
+            ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))
+
     def train_step(self, x0: Tensor, feats: Sequence[Tensor], i_embs: Tensor, t: Optional[Sequence[Tensor]] = None,
                    noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True, n_contrib: Optional[int] = None) -> List[float]:
         """One iteration of Main.py:145-192 over all modalities.  `feats` are the projected, detached modality features."""
@@ -546,13 +615,19 @@ class DiffusionEngine:
         x0p = self._set_x0(x0)
         reg = self.hp["reg"]
         reg_term = float(reg) * float(reg) * float((i_embs.double() ** 2).sum())  # l2_reg_loss(reg,[i_embs]) * reg (Model.py:421,425) -- host value
-        for m in range(M):
-            tm = t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32)
-            self.loss_forward(m, x0p, tm.to(torch.int32), noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
+        ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32)).to(torch.int32) for m in range(M)]
+        if precision == 1:  # the modalities' large GEMMs go out as one batched launch each (enough 256 x 256 tiles to fill the chip)
+            self._forward_batched(x0p, ts, noise, feats, i_embs, reg_term)
+        else:
+            for m in range(M):
+                self.loss_forward(m, x0p, ts[m], noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
         means = [float(self.act[m]["loss"][:B].mean()) for m in range(M)]  # the reference syncs here too (.item(), Main.py:155,159,172)
         total = sum(means)
+        if precision == 1:
+            self._backward_batched(x0p, feats, reg_term, 1.0 / (B * total))
         for m in range(M):
-            self.loss_backward(m, x0p, feats[m], reg_term, 1.0 / (B * total), precision)
+            if precision != 1:
+                self.loss_backward(m, x0p, feats[m], reg_term, 1.0 / (B * total), precision)
             if update:
                 self.reduce_and_step(m, contributing=True, n_contrib=n_contrib)
         self.rng_step += 1

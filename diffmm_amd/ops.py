@@ -194,11 +194,14 @@ def cast_bf16(src: Tensor, dst: Tensor, cols: Optional[int] = None, cols_pad: Op
     L.call("dmm_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), src.shape[0], cols, cols_pad, L.stream())
 
 
-def transpose_cast_bf16(src: Tensor, dst: Tensor, rows: Optional[int] = None, cols: Optional[int] = None) -> None:
-    """dst[c, r] = bf16(src[r, c]); dst is [cols, ld >= round_up(rows, 8)] and its columns rows..round_up(rows, 8) are zeroed."""
+def transpose_cast_bf16(src: Tensor, dst: Tensor, rows: Optional[int] = None, cols: Optional[int] = None, rows_pad: Optional[int] = None) -> None:
+    """dst[c, r] = bf16(src[r, c]); dst is [cols, ld >= rows_pad] and its columns rows..rows_pad are zeroed (rows_pad defaults to
+    round_up(rows, 8); the GEMM that contracts over `rows` wants whole 64-wide K tiles)."""
     rows = src.shape[0] if rows is None else rows
     cols = src.shape[1] if cols is None else cols
-    rp = (rows + 7) & ~7
+    rp = (rows + 7) & ~7 if rows_pad is None else rows_pad
+    if rp < rows or rp % 8:
+        raise ValueError("transpose_cast_bf16: rows_pad must be a multiple of 8 that covers the rows")
     if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] < cols or dst.stride(0) < rp:
         raise ValueError("transpose_cast_bf16: bad operands")
     L.call("dmm_transpose_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), rows, cols, rp, L.stream())

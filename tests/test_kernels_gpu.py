@@ -589,6 +589,37 @@ def test_denoise_and_diffusion_loss_vs_reference(dev, name):
         assert err < 6e-2, f"bf16-path grad {k}: max err {err:.3e} of the gradient scale"
 
 
+def test_train_step_batched_bf16_matches_split_precision(dev):
+    """The benchmark's training step (precision 1: the modalities' large GEMMs batched onto the bf16 NT kernels, 256 x 256 LDS-DMA
+    tile included at this size) against the same step in split-bf16 (~fp32) arithmetic, which the golden vectors pin."""
+    from diffmm_amd.engine import DiffusionEngine
+    torch.manual_seed(3)
+    items, D, H, M, T_, B = 2500, 64, 1024, 3, 20, 2048
+    hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3, seed=11)
+    E = DiffusionEngine(items, D, H, 10, M, T_, hp, dev, B)
+    for m in range(M):
+        P = E.P[m]
+        P.data.normal_(0, 0.02)
+        P.view("in_layers.0.weight")[:, items + 10:].zero_()  # pad columns of W1 are zero by construction
+    x0 = (torch.rand(B, items, device=dev) < 0.004).float()
+    feats = [torch.nn.functional.normalize(torch.randn(items, D, device=dev)) for _ in range(M)]
+    ie = torch.randn(items, D, device=dev) * 0.1
+    t = [torch.randint(0, T_, (B,), device=dev, dtype=torch.int32) for _ in range(M)]
+    noise = [torch.randn(B, items, device=dev) for _ in range(M)]
+    m3 = E.train_step(x0, feats, ie, t=t, noise=noise, precision=3, update=False)
+    g3 = [{k: E.P[m].g(k).clone() for k in ("in_layers.0.weight", "out_layers.0.weight", "in_layers.0.bias", "out_layers.0.bias", "gate_layer.weight", "emb_layer.weight")}
+          for m in range(M)]
+    m1 = E.train_step(x0, feats, ie, t=t, noise=noise, precision=1, update=False)
+    for m in range(M):
+        assert abs(m1[m] - m3[m]) < 2e-2 * abs(m3[m]), f"loss of modality {m}: {m1[m]} vs {m3[m]}"
+        for k, ref in g3[m].items():
+            got = E.P[m].g(k)
+            err = float((got - ref).abs().max()) / float(ref.abs().max())
+            assert err < 6e-2, f"modality {m} grad {k}: max err {err:.3e} of the gradient scale"
+            cos = float((got * ref).sum() / (got.norm() * ref.norm()))
+            assert cos > 0.999, f"modality {m} grad {k}: cosine {cos:.5f}"
+
+
 def test_transpose_cast(dev):
     from diffmm_amd import ops
     x = torch.randn(1116, 6710, device=dev)
