@@ -1,0 +1,184 @@
+// Products between an item-space row block [B, I] and an [I, d] feature / embedding table in the diffusion training step -- shapes a
+// square-tile GEMM handles badly (one side is d = 64 or 128) and that are bound by streaming the [B, I] operand once:
+//   dmm_item_project   out[B, d] += X[B, :I] . F[I, d]      Denoise gate input  x_t @ modal_feat            (Model.py:207)
+//                                                           usr_model_embeds = model_output @ model_feats   (Model.py:413)
+//                                                           usr_id_embeds    = x_start @ itmEmbeds          (Model.py:414)
+//                                                           and the gradient  d(proj * gate) = dx' @ modal_feat
+//   dmm_item_expand    Y[B, :I] = R[B, :I] + P[B, d] . F[I, d]^T   x_t + (proj * gate) @ modal_feat.T      (Model.py:209)
+//                                                           and the gradient  dout += dum @ model_feats.T
+// Arithmetic: operands rounded to bf16 as they are loaded (the "precision 1" mode of dmm_gemm), MFMA 16x16x32, fp32 accumulation.
+#include "common.h"
+
+namespace dmm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 is_cvt8(const float4& a, const float4& b) {
+  return bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+}
+
+// ---- project: 256 rows x D per workgroup (4 waves x 64 rows), one K slice of `kchunk` items; F is staged transposed in LDS -----------
+constexpr int IP_KS = 128;  // items per LDS stage
+
+template <int D>
+__global__ __launch_bounds__(256) void item_project_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ F, long long ldf,
+                                                           float* __restrict__ out, long long ldo, int B, int I, int kchunk) {
+  constexpr int NT = D / 16;
+  constexpr int LDT = IP_KS * 2 + 16;  // bytes per feature column in LDS (+16: the 16 columns of a fragment read hit distinct banks)
+  __shared__ __attribute__((aligned(16))) char ft[D * LDT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.x * 256 + wave * 64;
+  const int kbeg = blockIdx.y * kchunk, kend = min(I, kbeg + kchunk);
+  if (kbeg >= kend) return;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* xrow[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) xrow[mt] = X + (long long)min(row0 + mt * 16 + fr, B - 1) * ldx + kg * 8;
+
+  for (int k0 = kbeg; k0 < kend; k0 += IP_KS) {
+    __syncthreads();  // the previous stage's fragment reads are done
+    // stage F[k0 .. k0+KS, :] transposed (column-major, bf16); items past the slice are zero, so whatever X holds there is ignored
+    for (int idx = threadIdx.x; idx < IP_KS * (D / 4); idx += 256) {
+      const int kk = idx / (D / 4), c4 = idx % (D / 4);
+      const int k = k0 + kk;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kend) v = *reinterpret_cast<const float4*>(F + (long long)k * ldf + c4 * 4);
+      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 0) * LDT + kk * 2) = (__bf16)v.x;
+      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 1) * LDT + kk * 2) = (__bf16)v.y;
+      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 2) * LDT + kk * 2) = (__bf16)v.z;
+      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 3) * LDT + kk * 2) = (__bf16)v.w;
+    }
+    __syncthreads();
+    const int steps = min(IP_KS, (kend - k0 + 31) & ~31) / 32;
+    for (int s = 0; s < steps; ++s) {
+      const int k = k0 + s * 32;
+      float4 xa[4][2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        xa[mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + k);
+        xa[mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + k + 4);
+      }
+      bf16x8 fb[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const bf16x8*>(ft + (nt * 16 + fr) * LDT + (s * 32 + kg * 8) * 2);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const bf16x8 fa = is_cvt8(xa[mt][0], xa[mt][1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + mt * 16 + kg * 4 + r;
+      if (row < B) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) atomicAdd(out + (long long)row * ldo + nt * 16 + fr, acc[mt][nt][r]);
+      }
+    }
+}
+
+// ---- expand: 64 rows x 256 item columns per workgroup; the product is formed transposed (features x rows) so that every lane
+// ends up with 4 consecutive item columns of one row: 16-byte residual loads and stores ------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void item_expand_kernel(const float* __restrict__ P, long long ldp, const float* __restrict__ F, long long ldf,
+                                                          const float* __restrict__ R, long long ldr, float* __restrict__ Y, long long ldy, int B, int I) {
+  constexpr int KS = D / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 256 + wave * 64;
+  if (col0 >= I) return;
+  const bool vec = (ldr % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)R | (uintptr_t)Y) & 15) == 0;
+  // residual first: 16 float4 per lane in flight while the operands are fetched and multiplied
+  float4 rr[4][4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
+      rr[ct][rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < B && col < I) {
+        const float* p = R + (long long)row * ldr + col;
+        if (vec && col + 3 < I) rr[ct][rt] = *reinterpret_cast<const float4*>(p);
+        else {
+          rr[ct][rt].x = p[0];
+          if (col + 1 < I) rr[ct][rt].y = p[1];
+          if (col + 2 < I) rr[ct][rt].z = p[2];
+          if (col + 3 < I) rr[ct][rt].w = p[3];
+        }
+      }
+    }
+  bf16x8 ff[4][KS], fp[4][KS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* f = F + (long long)min(col0 + t * 16 + fr, I - 1) * ldf + ks * 32 + kg * 8;
+      const float* p = P + (long long)min(row0 + t * 16 + fr, B - 1) * ldp + ks * 32 + kg * 8;
+      ff[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
+      fp[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+    }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], acc, 0, 0, 0);
+      // acc[r] = (item column col0 + ct*16 + kg*4 + r, row row0 + rt*16 + fr)
+      const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
+      if (row < B && col < I) {
+        const float4 r4 = rr[ct][rt];
+        float* y = Y + (long long)row * ldy + col;
+        if (vec && col + 3 < I) *reinterpret_cast<float4*>(y) = make_float4(r4.x + acc[0], r4.y + acc[1], r4.z + acc[2], r4.w + acc[3]);
+        else {
+          y[0] = r4.x + acc[0];
+          if (col + 1 < I) y[1] = r4.y + acc[1];
+          if (col + 2 < I) y[2] = r4.z + acc[2];
+          if (col + 3 < I) y[3] = r4.w + acc[3];
+        }
+      }
+    }
+}
+
+}  // namespace dmm
+using namespace dmm;
+
+extern "C" int dmm_item_project(const float* X, int64_t ldx, const float* F, int64_t ldf, float* out, int64_t ldo, int B, int I, int D, void* stream) {
+  DMM_CHECK_ARG(X && F && out && B > 0 && I > 0, "dmm_item_project: bad arguments");
+  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_project: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(ldx % 4 == 0 && ldf % 4 == 0 && (((uintptr_t)X | (uintptr_t)F) & 15) == 0 && ldx >= ((I + 31) & ~31),
+                "dmm_item_project: X and F rows must be 16-byte aligned and X rows readable up to round_up(I, 32)");
+  // K slices: enough workgroups to fill the chip a few times over, slices a multiple of 32 items
+  const int rb = (B + 255) / 256;
+  int ks = std::max(1, std::min(64, 768 / rb));
+  int kchunk = (((I + ks - 1) / ks) + 31) & ~31;
+  ks = (I + kchunk - 1) / kchunk;
+  hipStream_t s = (hipStream_t)stream;
+  if (D == 64) hipLaunchKernelGGL(item_project_kernel<64>, dim3(rb, ks), dim3(256), 0, s, X, (long long)ldx, F, (long long)ldf, out, (long long)ldo, B, I, kchunk);
+  else hipLaunchKernelGGL(item_project_kernel<128>, dim3(rb, ks), dim3(256), 0, s, X, (long long)ldx, F, (long long)ldf, out, (long long)ldo, B, I, kchunk);
+  DMM_LAUNCH_CHECK("dmm_item_project");
+  return 0;
+}
+
+extern "C" int dmm_item_expand(const float* P, int64_t ldp, const float* F, int64_t ldf, const float* R, int64_t ldr, float* Y, int64_t ldy, int B, int I,
+                               int D, void* stream) {
+  DMM_CHECK_ARG(P && F && R && Y && B > 0 && I > 0, "dmm_item_expand: bad arguments");
+  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_expand: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(ldp % 4 == 0 && ldf % 4 == 0 && (((uintptr_t)P | (uintptr_t)F) & 15) == 0, "dmm_item_expand: P and F rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((I + 255) / 256, (B + 63) / 64);
+  if (D == 64) hipLaunchKernelGGL(item_expand_kernel<64>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
+  else hipLaunchKernelGGL(item_expand_kernel<128>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
+  DMM_LAUNCH_CHECK("dmm_item_expand");
+  return 0;
+}

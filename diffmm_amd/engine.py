@@ -465,15 +465,29 @@ class DiffusionEngine:
         self._mlp(m, xcat, a["h"][:B], a["out"][:B], precision)
         return a["out"][:B, : self.I]
 
+    def _item_kernels(self, precision: int) -> bool:
+        """The dedicated item-space kernels (csrc/itemspace.hip) cover the bf16 single-product mode at d = 64 / 128."""
+        return precision == 1 and self.D in (64, 128)
+
+    def _project_items(self, X: Tensor, F: Tensor, out: Tensor, precision: int):
+        """out = X[:, :I] @ F"""
+        if precision == 1:
+            ops.zero_(out)
+        if self._item_kernels(precision):
+            ops.item_project(X, F, out, self.I)
+        else:
+            ops.gemm(X, F, out=out, precision=precision, K=self.I, split_k=8 if precision == 1 else 1)
+
     def _gate_fwd(self, m: int, xcat: Tensor, feat: Tensor, precision: int):
         a, P, B, I = self.act[m], self.P[m], xcat.shape[0], self.I
-        if precision == 1:
-            ops.zero_(a["proj"][:B])
-        ops.gemm(xcat, feat, out=a["proj"][:B], precision=precision, K=I, split_k=8 if precision == 1 else 1)
+        self._project_items(xcat, feat, a["proj"][:B], precision)
         ops.gemm(a["proj"][:B], P.view("gate_layer.weight"), out=a["gate"][:B], trans_b=True, bias=P.view("gate_layer.bias"), act=L.ACT_SIGMOID,
                  precision=precision)
         ops.mul(a["proj"][:B], a["gate"][:B], a["pg"][:B])
-        ops.gemm(a["pg"][:B], feat, out=xcat, trans_b=True, residual=xcat, e1=1.0, e2=1.0, precision=precision, N=I)  # x_t += (proj*gate) F^T
+        if self._item_kernels(precision):
+            ops.item_expand(a["pg"][:B], feat, xcat, xcat, I)  # x_t += (proj*gate) F^T
+        else:
+            ops.gemm(a["pg"][:B], feat, out=xcat, trans_b=True, residual=xcat, e1=1.0, e2=1.0, precision=precision, N=I)
 
     # -- training_losses forward for one modality (Model.py:385-428) ------------------------------------
     def loss_forward(self, m: int, x0p: Tensor, t: Tensor, noise: Optional[Tensor], feat: Tensor, i_embs: Tensor, reg_term: float, precision: int,
@@ -562,11 +576,9 @@ class DiffusionEngine:
                                   for m in range(M)])
         for m in range(M):
             a = self.act[m]
-            ops.zero_(a["um"][:B])
-            ops.gemm(a["out"][:B], feats[m], out=a["um"][:B], precision=1, K=I, split_k=8)
+            self._project_items(a["out"][:B], feats[m], a["um"][:B], 1)
             if m == 0:
-                ops.zero_(self.ui[:B])
-                ops.gemm(x0p, i_embs, out=self.ui[:B], precision=1, K=I, split_k=8)
+                self._project_items(x0p, i_embs, self.ui[:B], 1)
             a["w"] = self.w_table[a["t"][:B].long()]
             ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
 
@@ -579,7 +591,10 @@ class DiffusionEngine:
             ops.zero_(P.grad)
             ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
                           w["dum"][:B])
-            ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)  # dout += dum F^T
+            if self._item_kernels(1):
+                ops.item_expand(w["dum"][:B], feats[m], w["dout"][:B], w["dout"][:B], I)                                    # dout += dum F^T
+            else:
+                ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)
             ops.transpose_cast_bf16(w["dout"][:B], w["doutT16"], rows=B, cols=I, rows_pad=Bp)      # dout^T [I, B]
             ops.transpose_cast_bf16(a["h"][:B], w["hT16"], rows=B, cols=H, rows_pad=Bp)            # h^T    [H, B]
             ops.colsum(w["dout"][:B], B, I, P.g("out_layers.0.bias"))
@@ -602,8 +617,7 @@ class DiffusionEngine:
         for m in range(M):
             a, P, w = self.act[m], self.P[m], W[m]
             ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
-            ops.zero_(w["dpg"][:B])
-            ops.gemm(w["dxcat"][:B], feats[m], out=w["dpg"][:B], precision=1, K=I, split_k=8)      # d(proj*gate) = dx' F
+            self._project_items(w["dxcat"][:B], feats[m], w["dpg"][:B], 1)                          # d(proj*gate) = dx' F
             ops.gate_bwd(w["dpg"][:B], a["proj"][:B], a["gate"][:B], w["dproj"][:B], w["dgate"][:B])
             ops.gemm(w["dgate"][:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=1)  # dWg = dgate_pre^T proj
             ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))

@@ -408,3 +408,25 @@ def eval_metrics(top: Tensor, users: Tensor, tst_ptr: Tensor, tst_col: Tensor) -
     out = torch.empty(top.shape[0], 3, dtype=torch.float64, device=top.device)
     L.call("dmm_eval_metrics", L.ptr(top), L.ptr(_i32c(users, "users")), L.ptr(tst_ptr), L.ptr(tst_col), top.shape[0], top.shape[1], L.ptr(out), L.stream())
     return out
+
+
+def item_project(X: Tensor, F: Tensor, out: Tensor, I: int) -> None:
+    """out[B, D] += X[B, :I] @ F[I, D] (bf16-rounded operands).  `out` must be zeroed by the caller (atomic accumulation)."""
+    B, D = X.shape[0], F.shape[1]
+    for t in (X, F, out):
+        if t.dtype != torch.float32 or t.stride(1) != 1:
+            raise ValueError("item_project: fp32 tensors with unit inner stride")
+    if F.shape[0] < I or out.shape[0] < B or out.shape[1] < D or X.shape[1] < ((I + 31) & ~31):
+        raise ValueError("item_project: shape mismatch (X needs round_up(I, 32) readable columns)")
+    L.call("dmm_item_project", L.ptr(X), X.stride(0), L.ptr(F), F.stride(0), L.ptr(out), out.stride(0), B, I, D, L.stream())
+
+
+def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:
+    """Y[B, :I] = R[B, :I] + P[B, D] @ F[I, D]^T (bf16-rounded operands); Y may be R."""
+    B, D = P.shape[0], P.shape[1]
+    for t in (P, F, R, Y):
+        if t.dtype != torch.float32 or t.stride(1) != 1:
+            raise ValueError("item_expand: fp32 tensors with unit inner stride")
+    if F.shape[0] < I or F.shape[1] != D or R.shape[0] < B or Y.shape[0] < B or R.shape[1] < I or Y.shape[1] < I:
+        raise ValueError("item_expand: shape mismatch")
+    L.call("dmm_item_expand", L.ptr(P), P.stride(0), L.ptr(F), F.stride(0), L.ptr(R), R.stride(0), L.ptr(Y), Y.stride(0), B, I, D, L.stream())

@@ -231,6 +231,16 @@ int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids /*[rows] g
                   /*[U+1] indexed by user id*/, int32_t* out_idx, int rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Item-space products of the diffusion training step (bf16-rounded operands, fp32 accumulation; D = 64 or 128):
+ *   dmm_item_project  out[B, D] += X[B, :I] . F[I, D]   -- Model.py:207 (x_t @ modal_feat), :413 (model_output @ model_feats), :414
+ *                     (x_start @ itmEmbeds).  `out` is accumulated with atomics: zero it first.  X rows must be readable (finite
+ *                     values) up to round_up(I, 32) columns; those columns are multiplied by zero.
+ *   dmm_item_expand   Y[B, :I] = R[B, :I] + P[B, D] . F[I, D]^T  -- Model.py:209 (x_t + (proj * gate) @ modal_feat.T); Y may alias R. */
+int dmm_item_project(const float* X, int64_t ldx, const float* F, int64_t ldf, float* out, int64_t ldo, int B, int I, int D, void* stream);
+int dmm_item_expand(const float* P, int64_t ldp, const float* F, int64_t ldf, const float* R, int64_t ldr, float* Y, int64_t ldy, int B, int I, int D,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Rebuild, second half: the modality graph of Main.py:232-253 (coo_matrix of the top-k edges -> DataHandler.makeTorchAdj,
  * DataHandler.py:54-93) built on the device, together with the work list dmm_spmm_csr_f32 consumes.
  *   user_ptr  int32 [U+1]  CSR of the user rows (k_u = train degree, fixed for the run);  edge_user int32 [E] = user of edge e

@@ -620,6 +620,32 @@ def test_train_step_batched_bf16_matches_split_precision(dev):
             assert cos > 0.999, f"modality {m} grad {k}: cosine {cos:.5f}"
 
 
+@pytest.mark.parametrize("B,I,D", [(300, 700, 64), (4096, 6710, 64), (1116, 2531, 128)])
+def test_item_project_and_expand(dev, B, I, D):
+    """csrc/itemspace.hip against fp64 products of the bf16-rounded operands (only the fp32 summation order differs)."""
+    from diffmm_amd import ops
+    torch.manual_seed(B + D)
+    ld = (I + 10 + 63) // 64 * 64
+    X = torch.randn(B, ld, device=dev)  # columns >= I hold (finite) junk, like the time-embedding columns of [x_t | temb | 0]
+    F = torch.randn(I, D, device=dev)
+    out = torch.zeros(B, D, device=dev)
+    ops.item_project(X, F, out, I)
+    ref = X[:, :I].bfloat16().double() @ F.bfloat16().double()
+    close(out, ref, rtol=1e-5, atol=2e-4 * np.sqrt(I / 64), what="item_project")
+    P = torch.randn(B, D, device=dev)
+    R = torch.randn(B, ld, device=dev)
+    want = R.clone().double()
+    want[:, :I] += P.bfloat16().double() @ F.bfloat16().double().t()
+    Y = torch.full((B, ld), 5.0, device=dev)
+    ops.item_expand(P, F, R, Y, I)
+    close(Y[:, :I], want[:, :I], rtol=1e-5, atol=1e-4, what="item_expand")
+    assert float((Y[:, I:] - 5.0).abs().max()) == 0.0, "columns beyond I untouched"
+    Rc = R.clone()
+    ops.item_expand(P, F, Rc, Rc, I)  # in place
+    close(Rc[:, :I], want[:, :I], rtol=1e-5, atol=1e-4, what="item_expand in place")
+    assert torch.equal(Rc[:, I:], R[:, I:])
+
+
 def test_transpose_cast(dev):
     from diffmm_amd import ops
     x = torch.randn(1116, 6710, device=dev)
