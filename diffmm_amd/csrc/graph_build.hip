@@ -11,7 +11,7 @@
 //                         the planner's order is class-major, row-ascending inside a class) and one counting the giant rows;
 //                         the last phase also writes every row's tasks
 //   3. gb_fill            user rows (self loop, then the user's items in top-k order) and the unsorted contents of the item rows
-//   4. gb_finish_item_rows  every item row sorted by user id (rank by counting in LDS; a bitmap pass for rows longer than 4096),
+//   4. gb_finish_item_rows  every item row sorted by user id (rank by counting in LDS; a bitmap pass for rows longer than 256 entries),
 //                         self loop last, values
 // All index arithmetic is 32-bit: nnz = 2 E + N < 2^31 is checked by the host wrapper.
 #include "common.h"
@@ -20,7 +20,7 @@ namespace dmm {
 
 constexpr int GB_MAXCH = 12;      // row length + up to 10 task classes + giant-row count
 constexpr int GB_SCAN_BLOCK = 1024;
-constexpr int GB_SORT_CAP = 4096; // item-row entries sorted in LDS
+constexpr int GB_SORT_CAP = 256;  // item-row entries ranked by counting in LDS (O(L^2)); longer rows take the bitmap pass (O(U/32 + L))
 
 struct GbShape {
   int U, I, N, E, G, logG, task_len, seg_len, nch;  // nch = 1 + (logG + 2) + 1
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void gb_finish_item_rows(GbShape S, const int3
   }
 }
 
-constexpr int GB_LONG_GROUPS = 32;
+constexpr int GB_LONG_GROUPS = 256;
 
 }  // namespace dmm
 using namespace dmm;

@@ -619,7 +619,8 @@ class DiffusionEngine:
             ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
             self._project_items(w["dxcat"][:B], feats[m], w["dpg"][:B], 1)                          # d(proj*gate) = dx' F
             ops.gate_bwd(w["dpg"][:B], a["proj"][:B], a["gate"][:B], w["dproj"][:B], w["dgate"][:B])
-            ops.gemm(w["dgate"][:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=1)  # dWg = dgate_pre^T proj
+            # dWg = dgate_pre^T proj: a single d x d output tile with K = B -- split K over 32 workgroups (P.grad was zeroed above)
+            ops.gemm(w["dgate"][:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=1, split_k=32)
             ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))
 
     def train_step(self, x0: Tensor, feats: Sequence[Tensor], i_embs: Tensor, t: Optional[Sequence[Tensor]] = None,
