@@ -702,9 +702,14 @@ class DiffusionEngine:
             return self._generate_views_bf16_state(x0)
         for m in range(M):
             self._refresh_bf16_weights(m)
-            self.cxa[m][:B, :I].copy_(x0)
         if M > 1 and self.hp.get("chain_streams", os.environ.get("DMM_CHAIN_STREAMS", "1") != "0"):
+            if not hasattr(self, "cx0"):  # x_T = x_0 is the same for every modality: one fp32 + one bf16 copy feed all first steps
+                self.cx0 = torch.zeros_like(self.cxa[0])  # (read-only while the chains run: none of them may own it)
+                self.cx016 = torch.zeros_like(self.cxa16[0])
+            self.cx0[:B, :I].copy_(x0)
             return self._generate_views_streams(B)
+        for m in range(M):
+            self.cxa[m][:B, :I].copy_(x0)
         plan = self._chain_plans.get(("all", B))
         if plan is None:
             with L.Recorder() as plan:
@@ -736,24 +741,30 @@ class DiffusionEngine:
             self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
         plan = self._chain_plans.get(("streams", B))
         if plan is None:
+            with L.Recorder() as head:  # on the caller's stream, before the chains fork: the shared bf16 copy of x_0
+                ops.cast_bf16(self.cx0[:B], self.cx016[:B], cols=I, cols_pad=self.Kp)
+                for m in range(M):  # temb / pad columns of the ping-pong operands stay zero (temb enters through the bias table)
+                    ops.zero_(self.cxb16[m][:B])
+                    ops.zero_(self.cxa16[m][:B])
             per = []
             for m in range(M):
                 with torch.cuda.stream(self._side_streams[m]), L.Recorder() as pm:
-                    cur, nxt, cur16, nxt16, h16 = self.cxa[m][:B], self.cxb[m][:B], self.cxa16[m][:B], self.cxb16[m][:B], self.ch16[m][:B]
-                    ops.zero_(nxt16)
-                    ops.cast_bf16(cur, cur16, cols=I, cols_pad=self.Kp)
+                    cur, nxt, cur16, nxt16, h16 = self.cx0[:B], self.cxb[m][:B], self.cx016[:B], self.cxb16[m][:B], self.ch16[m][:B]
+                    own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
                     for i in range(self.T - 1, -1, -1):
                         ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
                         ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self.P[m].view("out_layers.0.bias"), residual=cur,
                                          e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
-                        cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
+                        # the first step read the shared x_0 buffers; from then on the chain ping-pongs between its own pair
+                        cur, nxt, cur16, nxt16 = nxt, (own if i == self.T - 1 else cur), nxt16, (own16 if i == self.T - 1 else cur16)
                 per.append(pm)
-            plan = [c for group in zip(*per) for c in group]  # same length per chain: interleave launch by launch
+            plan = dict(head=head, chains=[c for group in zip(*per) for c in group])  # same length per chain: interleave launch by launch
             self._chain_plans[("streams", B)] = plan
+        L.replay(plan["head"])
         self._side_events[M].record(main)
         for m in range(M):
             self._side_streams[m].wait_event(self._side_events[M])
-        L.replay(plan)
+        L.replay(plan["chains"])
         for m in range(M):
             self._side_events[m].record(self._side_streams[m])
             main.wait_event(self._side_events[m])

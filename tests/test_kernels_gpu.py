@@ -646,6 +646,32 @@ def test_item_project_and_expand(dev, B, I, D):
     assert torch.equal(Rc[:, I:], R[:, I:])
 
 
+def test_reverse_chains_on_streams_match_single_chain(dev):
+    """generate_views_bf16 (one HIP stream per modality, shared x_0 copies, recorded launch plan) against the single-modality chain:
+    the same arithmetic on the same operands -- equal up to the summation order of differently tiled GEMMs -- and bit-identical
+    from call to call (a chain that read a buffer another chain still owned would not be)."""
+    from diffmm_amd.engine import DiffusionEngine
+    torch.manual_seed(5)
+    items, D, H, M, T_, B = 1500, 64, 1024, 3, 7, 700
+    hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3)
+    E = DiffusionEngine(items, D, H, 10, M, T_, hp, dev, B)
+    for m in range(M):
+        E.P[m].data.normal_(0, 0.03)
+        E.P[m].view("in_layers.0.weight")[:, items + 10:].zero_()
+    x0 = (torch.rand(B, items, device=dev) < 0.01).float()
+    first = [v.clone() for v in E.generate_views_bf16(x0)]
+    again = [v.clone() for v in E.generate_views_bf16(x0)]
+    for m in range(M):
+        assert torch.equal(first[m], again[m]), f"modality {m}: the stream chains are not reproducible"
+        single = E.generate_view_bf16(m, x0)
+        scale = float(single.abs().max())
+        assert float((first[m] - single).abs().max()) < 2e-3 * scale, f"modality {m}: streams vs single chain"
+    E.hp["chain_streams"] = False
+    batched = E.generate_views_bf16(x0)
+    for m in range(M):
+        assert float((first[m] - batched[m]).abs().max()) < 2e-3 * float(batched[m].abs().max()), f"modality {m}: streams vs batched launches"
+
+
 def test_transpose_cast(dev):
     from diffmm_amd import ops
     x = torch.randn(1116, 6710, device=dev)
