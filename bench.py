@@ -98,12 +98,16 @@ def roofline(coach, args):
             "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6}
     spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sb / ts / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": ts * 1e6, "algorithmic_bytes": sb}
-    try:  # HBM-side traffic per launch from the committed PMC passes (profiles/README.md); bench.py itself cannot run rocprofv3
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")))
-        if args.precision == 1 and args.batch == 4096 and args.workload == "tiktok":
+    try:  # fabric-side traffic per launch from the committed PMC passes (profiles/README.md); bench.py itself cannot run rocprofv3
+        if args.precision == 1 and args.batch == 4096 and args.workload == "tiktok" and nb == 3:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")))
             spmm["traffic"] = pmc["spmm_kernel_64"]["traffic_bytes"]
-            gemm["traffic_note"] = ("PMC passes were taken on the single-problem 4096-row launch (463 MB fabric-side per launch vs 77 MB algorithmic, "
-                                    "L2 hit rate 33 % on the batched launch): profiles/r1_pmc_traffic.json, profiles/README.md")
+            chain = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_chain_gemm.json")))
+            l1, l2 = chain["gemm_bf16_nt_8ph_layer1"], chain["gemm_bf16_nt_8ph_layer2"]
+            gemm["traffic"] = l1["traffic_bytes"]
+            gemm["traffic_note"] = (f"layer 1: {l1['traffic_bytes'] / 1e6:.0f} MB fabric-side per launch vs {l1['algorithmic_bytes'] / 1e6:.0f} MB of operands + output "
+                                    f"(L2 hit rate {l1['tcc_hit'] / (l1['tcc_hit'] + l1['tcc_miss']):.0%}); layer 2: {l2['traffic_bytes'] / 1e6:.0f} MB vs "
+                                    f"{l2['algorithmic_bytes'] / 1e6:.0f} MB; profiles/r1_pmc_chain_gemm.json")
     except Exception:
         pass
     return gemm, spmm
