@@ -156,9 +156,7 @@ class Coach:
         if modal_adj_override is None:
             dd = h.diffusionData
             n_edges = int(dd.ptr[-1])
-            if int(cfg.hyper.sampling_step) != 0:
-                raise NotImplementedError("sampling_step > 0 (noised start of the reverse chain) is not on the HIP path yet")
-            edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, n_edges, precision=prec)
+            edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, n_edges, precision=prec, sampling_step=int(cfg.hyper.sampling_step))
             if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
                 self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim))
             adjs = self.graph_builder.build_all(edges)

@@ -87,6 +87,7 @@ _SIGS = {
     "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P]),
     "dmm_topk_rows": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _P]),
+    "dmm_noised_start": (C.c_int, [_P, _L, _P, _F, _F, _P, _L, _I, _I, _U64, _U64, _P]),
     "dmm_item_project": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_item_expand": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_graph_build_scratch_bytes": (C.c_int, [_I, _I, _L, _I, _P]),

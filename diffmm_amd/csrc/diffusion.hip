@@ -69,6 +69,53 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
   }
 }
 
+// Start of a reverse chain with sampling_step > 0 (GaussianDiffusion.generate_view -> forward_cal_xt without a noise argument,
+// Model.py:310-313,336-341): x_T = sqrt_ac[s] * x_0 + sqrt_1mac[s] * sign(x_0) * randn / max(||randn_row||, 1e-12) -- the noise is
+// row-normalised over ALL I columns and then kept only where x_0 is non-zero.  One workgroup per row; the row's normals are drawn
+// twice from the same Philox counters (norm pass, write pass) instead of being stored.  `randn` (optional) replaces the draw.
+__global__ __launch_bounds__(256) void noised_start_kernel(const float* __restrict__ x0, long long ldx0, const float* __restrict__ randn, float a, float c,
+                                                           float* __restrict__ xT, long long ldx, int I, unsigned long long seed,
+                                                           unsigned long long offset) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* __restrict__ xr = x0 + (long long)b * ldx0;
+  float* __restrict__ row = xT + (long long)b * ldx;
+  const unsigned long long base = offset + (unsigned long long)b * ((I + 3) / 4);
+  float ss = 0.f;
+  for (int q = threadIdx.x; q * 4 < I; q += 256) {
+    float e[4];
+    if (randn) {
+      for (int u = 0; u < 4; ++u) e[u] = 4 * q + u < I ? randn[(long long)b * I + 4 * q + u] : 0.f;
+    } else {
+      const uint4 r = philox4(seed, base + q, 0xd1ffu);
+      const float2 n0 = box_muller(r.x, r.y), n1 = box_muller(r.z, r.w);
+      e[0] = n0.x; e[1] = n0.y; e[2] = n1.x; e[3] = n1.y;
+    }
+    for (int u = 0; u < 4; ++u)
+      if (4 * q + u < I) ss = fmaf(e[u], e[u], ss);
+  }
+  ss = block_sum_256(ss, red);
+  const float scale = c / fmaxf(sqrtf(ss), 1e-12f);
+  for (int q = threadIdx.x; q * 4 < I; q += 256) {
+    float e[4];
+    if (randn) {
+      for (int u = 0; u < 4; ++u) e[u] = 4 * q + u < I ? randn[(long long)b * I + 4 * q + u] : 0.f;
+    } else {
+      const uint4 r = philox4(seed, base + q, 0xd1ffu);
+      const float2 n0 = box_muller(r.x, r.y), n1 = box_muller(r.z, r.w);
+      e[0] = n0.x; e[1] = n0.y; e[2] = n1.x; e[3] = n1.y;
+    }
+    for (int u = 0; u < 4; ++u) {
+      const int j = 4 * q + u;
+      if (j < I) {
+        const float x = xr[j];
+        const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+        row[j] = a * x + scale * sg * e[u];
+      }
+    }
+  }
+}
+
 // d w_emb[c][k] += sum_b dtemb[b][c] * e_b[k],  d b_emb[c] += sum_b dtemb[b][c]   (te <= 32; one workgroup per 64 batch rows,
 // thread = one (c, k) pair, partial sums added with fp32 atomics)
 __global__ __launch_bounds__(1024) void temb_bwd_kernel(const int32_t* __restrict__ t, const float* __restrict__ dxcat, long long ldx, int I,
@@ -361,6 +408,15 @@ extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* nois
   hipLaunchKernelGGL(qsample_temb_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)ldx0, noise, t, sqrt_ac, sqrt_1mac, w_emb,
                      b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out);
   DMM_LAUNCH_CHECK("dmm_qsample_temb");
+  return 0;
+}
+
+extern "C" int dmm_noised_start(const float* x0, int64_t ldx0, const float* randn, float sqrt_ac, float sqrt_1mac, float* xT, int64_t ldx, int B, int I,
+                                uint64_t seed, uint64_t offset, void* stream) {
+  DMM_CHECK_ARG(x0 && xT && B > 0 && I > 0, "dmm_noised_start: bad arguments");
+  hipLaunchKernelGGL(noised_start_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)ldx0, randn, sqrt_ac, sqrt_1mac, xT, (long long)ldx, I,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  DMM_LAUNCH_CHECK("dmm_noised_start");
   return 0;
 }
 

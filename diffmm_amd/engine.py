@@ -812,9 +812,25 @@ class DiffusionEngine:
             cur, nxt = nxt, cur
         return cur[:, :I]
 
-    def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1) -> List[Tensor]:
+    def noised_start(self, m: int, x0: Tensor, sampling_step: int, noise: Optional[Tensor] = None) -> Tensor:
+        """x_T of generate_view for sampling_step > 0 (Model.py:310-313): forward_cal_xt(x_0, t = sampling_step - 1) with the reference's
+        default noise sign(x_0) * normalize(randn), drawn afresh per modality (or from `noise`, for parity tests).  Returns a [B, I] view."""
+        B, I = x0.shape[0], self.I
+        if not hasattr(self, "_xT"):
+            self._xT = torch.zeros(self.chain_rows, self.Kp, dtype=torch.float32, device=self.dev)
+            self._xT_calls = 0
+        ops.noised_start(x0, noise, float(np.float32(self.sched["sqrt_alphas_cumprod"][sampling_step - 1])),
+                         float(np.float32(self.sched["sqrt_one_minus_alphas_cumprod"][sampling_step - 1])), self._xT[:B], I,
+                         seed=self.hp.get("seed", 1818) + 1,  # its own Philox stream, apart from the training draws
+                         offset=self._xT_calls * self.chain_rows * ((I + 3) // 4))
+        self._xT_calls += 1
+        return self._xT[:B, :I]
+
+    def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1,
+                      sampling_step: int = 0) -> List[Tensor]:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
-        int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]])."""
+        int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]]).
+        sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
         if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow, evenly over the replicas
             all_users = torch.cat([b.reshape(-1) for b in user_batches])
@@ -826,13 +842,13 @@ class DiffusionEngine:
             if i % self.world != self.rank:  # user chunks are sharded over the replicas (dist.shard_owner)
                 continue
             x0 = dense_rows(ub)
-            if precision == 1:
+            if precision == 1 and sampling_step == 0:
                 views = self.generate_views_bf16(x0)
                 for m in range(self.M):
                     ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
                 continue
             for m in range(self.M):
-                den = self.generate_view(m, x0, precision)
+                den = self.generate_view(m, self.noised_start(m, x0, sampling_step) if sampling_step else x0, precision)
                 ops.topk_rows(den, ub.to(torch.int32), deg_ptr, out[m], self.I)
         if self.world > 1:  # every edge slot is written by exactly one replica: a sum all-reduce is an all-gather
             from . import dist as D_

@@ -430,3 +430,12 @@ def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:
     if F.shape[0] < I or F.shape[1] != D or R.shape[0] < B or Y.shape[0] < B or R.shape[1] < I or Y.shape[1] < I:
         raise ValueError("item_expand: shape mismatch")
     L.call("dmm_item_expand", L.ptr(P), P.stride(0), L.ptr(F), F.stride(0), L.ptr(R), R.stride(0), L.ptr(Y), Y.stride(0), B, I, D, L.stream())
+
+
+def noised_start(x0: Tensor, randn: Optional[Tensor], sqrt_ac: float, sqrt_1mac: float, xT: Tensor, I: int, seed: int = 0, offset: int = 0) -> None:
+    """xT[:, :I] = sqrt_ac * x0 + sqrt_1mac * sign(x0) * normalize(randn) (Model.py:336-341); randn None = in-kernel Philox draw."""
+    if x0.dtype != torch.float32 or xT.dtype != torch.float32 or x0.stride(1) != 1 or xT.stride(1) != 1 or x0.shape[1] < I or xT.shape[1] < I:
+        raise ValueError("noised_start: fp32 operands with at least I columns")
+    if randn is not None and (randn.dtype != torch.float32 or not randn.is_contiguous() or tuple(randn.shape) != (x0.shape[0], I)):
+        raise ValueError("noised_start: randn must be a contiguous fp32 [B, I] tensor")
+    L.call("dmm_noised_start", L.ptr(x0), x0.stride(0), L.ptr(randn), sqrt_ac, sqrt_1mac, L.ptr(xT), xT.stride(0), x0.shape[0], I, seed, offset, L.stream())

@@ -230,6 +230,12 @@ int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w
 int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids /*[rows] global user ids*/, const int32_t* out_ptr
                   /*[U+1] indexed by user id*/, int32_t* out_idx, int rows, int cols, void* stream);
 
+/* Start of a reverse chain with sampling_step > 0 (generate_view -> forward_cal_xt without noise, Model.py:310-313,336-341):
+ * xT[b, :I] = sqrt_ac * x0 + sqrt_1mac * sign(x0) * n / max(||n||_2, 1e-12), n ~ N(0, 1)^I per row (in-kernel Philox) or `randn`
+ * ([B, I] contiguous) when given. */
+int dmm_noised_start(const float* x0, int64_t ldx0, const float* randn, float sqrt_ac, float sqrt_1mac, float* xT, int64_t ldx, int B, int I,
+                     uint64_t seed, uint64_t offset, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Item-space products of the diffusion training step (bf16-rounded operands, fp32 accumulation; D = 64 or 128):
  *   dmm_item_project  out[B, D] += X[B, :I] . F[I, D]   -- Model.py:207 (x_t @ modal_feat), :413 (model_output @ model_feats), :414

@@ -108,3 +108,23 @@ def test_epochs_match_reference(fx):
                     close_weights(p, z[f"ep{ep}/den{m}/{k}"], n_diff, lr, f"ep{ep} den{m} {k}")
     assert draws.i == int(z["n_draws"])
     close(np.array(draws.checks), z["draw_checksum"], rtol=1e-12, what="the random draws must be the recorded ones")
+
+
+@pytest.mark.parametrize("precision", [1, 3])
+def test_epoch_with_noised_chain_start(precision):
+    """sampling_step > 0 (every modality's reverse chain starts from its own q_sample(x_0)): the epoch runs on both arithmetic modes
+    and the rebuilt graphs keep every user's degree with distinct items (the structural contract of Main.py:215-230)."""
+    need_gpu()
+    z = load("epoch_mid.npz")
+    coach, h, M = _coach(z)
+    coach.precision = precision
+    coach.config.hyper.sampling_step = 2
+    res = coach.trainEpoch()
+    assert all(np.isfinite(v) for v in res.values())
+    deg = np.bincount(z["trn_rows"], minlength=int(z["users"]))
+    U = int(z["users"])
+    for adj in [coach.image_adj, coach.text_adj] + ([coach.audio_adj] if M == 3 else []):
+        rp, col = adj.rowptr.cpu().numpy(), adj.col.cpu().numpy()
+        for u in range(U):
+            items = col[rp[u] + 1:rp[u + 1]]  # after the self loop
+            assert len(items) == deg[u] and len(set(items.tolist())) == deg[u] and (items >= U).all()

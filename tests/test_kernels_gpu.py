@@ -566,6 +566,21 @@ def test_denoise_and_diffusion_loss_vs_reference(dev, name):
     gv = E.generate_view(0, x0, precision=1).cpu()  # dedicated bf16 chain
     gscale = float(np.abs(z["genview/out"]).max())
     assert float((gv - T(z["genview/out"])).abs().max()) < 3e-2 * gscale, "bf16 reverse chain within 3 % of the output scale"
+    # sampling_step > 0: the chain starts from q_sample(x_0, t = sampling_step - 1) (Model.py:310-313); same draws through the oracle
+    from oracle import diffmm_oracle as O
+    sched = O.schedule(int(z["T"]), float(z["noise_scale"]), 0.0001, 0.02)
+    Por = {k[2:]: T(z[k]) for k in z.files if k.startswith("p/")}
+    ss = max(1, int(z["T"]) // 2)
+    want = O.generate_view(Por, T(z["x0"]), sched, ss, randn=T(z["noise"]))
+    close(E.generate_view(0, E.noised_start(0, x0, ss, noise=noise), precision=3), want, rtol=2e-4, atol=5e-5, what="generate_view, noised start")
+    drawn = E.noised_start(0, x0, ss).clone()  # in-kernel Philox draw: unit-norm rows, supported on x_0's non-zeros only
+    a_, b_ = float(E.sqrt_ac[ss - 1]), float(E.sqrt_1mac[ss - 1])
+    resid = (drawn - a_ * x0) / b_
+    assert float(resid[x0 == 0].abs().max()) == 0.0, "noise only where x_0 is non-zero"
+    nz = (x0 != 0).float().sum(1)
+    # E[sum over the row's non-zeros of n_j^2 / ||n||^2] = nnz / I
+    assert abs(float((resid ** 2).sum()) / float(nz.sum()) * I - 1.0) < 0.2
+    assert not torch.equal(drawn, E.noised_start(0, x0, ss)), "every call draws fresh noise"
     # training_losses with the recorded draws: value and every gradient
     means = E.train_step(x0, [feat], ie, t=[t], noise=[noise], precision=3, update=False)
     close(E.act[0]["loss"][:B], z["tl/loss"], rtol=1e-4, atol=1e-7, what="training_losses")
