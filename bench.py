@@ -217,7 +217,9 @@ def main():
            "config": {"workload": f"synthetic {args.workload}-shape graph: U={h.graph.users} I={h.graph.items} E={h.graph.nnz}, M={len(h.graph.feats)} modalities, "
                                   f"d={args.latdim}, T={args.T}, batch={args.batch}; step = 1 epoch = {n_diff} diffusion iters + rebuild + {n_joint} joint iters",
                       "parallelism": f"dp{world}", "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
-                      "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3}}}
+                      "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3},
+                      # the two per-phase rates next to the blended headline (`value`); host-side phase boundaries of rank 0
+                      "phase_iters_per_s": {"diffusion": n_diff * args.steps / max(phases[0], 1e-9), "joint": n_joint * args.steps / max(phases[2], 1e-9)}}}
     if replicas_identical is not None:
         out["replicas_identical"] = replicas_identical
     if not args.no_roofline:
