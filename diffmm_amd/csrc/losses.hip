@@ -232,9 +232,11 @@ template <int D, int PREC>
 __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, TermTable T, int B, float* __restrict__ lse,
                                                                 float* __restrict__ row_loss) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+  // One workgroup = 32 own rows; its 4 waves walk different quarters of the other view and merge their (max, sum, diagonal) through
+  // LDS -- 4x the waves of a one-wave-per-row-block layout (which left one wave per SIMD, nothing to overlap its load latency with).
+  __shared__ float part[4][32][3];
   const int t = blockIdx.y;
-  const int i0 = (blockIdx.x * 4 + wave) * 32;
-  if (i0 >= B) return;  // wave-uniform; the kernel has no workgroup barrier
+  const int i0 = blockIdx.x * 32;
   const dmm_infonce_term term = T.t[t];
   const int Bp = pk.Bp;
   const int tiles = Bp >> 5;
@@ -249,14 +251,16 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
   const int i = i0 + fr;
   float m = -INFINITY, ssum = 0.f, diag = 0.f;
   bf16x8 ca[D / 16], cl[D / 16], na[D / 16], nl[D / 16];
+  const int n_t = (B + 31) >> 5, per = (n_t + 3) >> 2;
+  const int jt0 = wave * per, jt1 = min(n_t, jt0 + per);
 #pragma unroll
   for (int ks = 0; ks < D / 16; ++ks) {
-    const size_t o = frag_off<D>(term.b, tiles, 0, ks, fh, fr);
+    const size_t o = frag_off<D>(term.b, tiles, min(jt0, n_t - 1), ks, fh, fr);
     ca[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
     if (PREC == 3) cl[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
   }
-  for (int j0 = 0; j0 < B; j0 += 32) {
-    if (j0 + 32 < B) {  // next tile's operand: in flight under this tile's math
+  for (int j0 = jt0 * 32; j0 < jt1 * 32; j0 += 32) {
+    if (j0 + 32 < jt1 * 32) {  // next tile's operand: in flight under this tile's math
 #pragma unroll
       for (int ks = 0; ks < D / 16; ++ks) {
         const size_t o = frag_off<D>(term.b, tiles, (j0 >> 5) + 1, ks, fh, fr);
@@ -301,10 +305,26 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
   const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64), d2 = __shfl_xor(diag, 32, 64);
   const float M = fmaxf(m, m2);
   const float L = (m > -INFINITY ? ssum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
-  if (fh == 0 && i < B) {
-    const float l = M + __logf(L);
+  if (fh == 0) {
+    part[wave][fr][0] = M;
+    part[wave][fr][1] = L;
+    part[wave][fr][2] = diag + d2;
+  }
+  __syncthreads();
+  if (wave == 0 && fh == 0 && i < B) {
+    float Mx = -INFINITY, dg = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      Mx = fmaxf(Mx, part[w][fr][0]);
+      dg += part[w][fr][2];
+    }
+    float Ls = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (part[w][fr][0] > -INFINITY) Ls += part[w][fr][1] * __expf(part[w][fr][0] - Mx);
+    const float l = Mx + __logf(Ls);
     lse[(size_t)t * B + i] = l;
-    row_loss[(size_t)t * B + i] = (l - (diag + d2)) * (term.weight / (float)B);
+    row_loss[(size_t)t * B + i] = (l - dg) * (term.weight / (float)B);
   }
 }
 
@@ -562,7 +582,7 @@ extern "C" int dmm_infonce_fwd(const float* zhat, const void* bf16_pack, int n_s
   if (bf16_pack && precision != 0 && mfma_ok(D)) {
     DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_fwd: precision must be 0 (fp32 VALU), 1 or 3");
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
-    DISPATCH_MFMA(D, precision, infonce_fwd_mfma_kernel, dim3(cdiv(B, 128), n_terms), dim3(256), 0, (hipStream_t)stream, pk, T, B, lse, row_loss);
+    DISPATCH_MFMA(D, precision, infonce_fwd_mfma_kernel, dim3(cdiv(B, 32), n_terms), dim3(256), 0, (hipStream_t)stream, pk, T, B, lse, row_loss);
     DMM_LAUNCH_CHECK("dmm_infonce_fwd(mfma)");
     return 0;
   }
