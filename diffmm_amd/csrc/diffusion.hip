@@ -274,6 +274,119 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+// Register-resident variant for rows of up to 256 * NC columns (NC = 32: 8192; NC = 80: 20480): the row is read from memory ONCE
+// (keys held in registers through the four radix passes and the compaction), the bucket holding rank k is found by a parallel
+// suffix scan over the 256 bins instead of a one-thread walk, and the compaction needs no barrier per 256-column chunk
+// (per-(chunk, wave) counts go to LDS once, two waves scan them, every thread then knows its output positions).
+// Same selection rule and output order as topk_rows_kernel (ascending column, ties at the threshold -> smaller columns).
+template <int NC>
+__global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restrict__ x, long long ldx, const int32_t* __restrict__ row_ids,
+                                                             const int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_idx, int cols) {
+  __shared__ int hist[256];
+  __shared__ int wsum[4];
+  __shared__ int sm4[4];
+  __shared__ uint32_t sel_prefix;
+  __shared__ int sel_k;
+  __shared__ int cg[NC * 4 + 64], ct[NC * 4 + 64];
+  const int u = row_ids[blockIdx.x];
+  const int beg = out_ptr[u];
+  int k = out_ptr[u + 1] - beg;
+  if (k <= 0) return;  // uniform per block
+  if (k > cols) k = cols;
+  const float* __restrict__ r = x + (long long)blockIdx.x * ldx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t key[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + threadIdx.x;
+    key[i] = j < cols ? fkey(r[j]) : 0u;
+  }
+  uint32_t prefix = 0, mask = 0;
+  int kk = k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (i * 256 + (int)threadIdx.x < cols && (key[i] & mask) == prefix) atomicAdd(&hist[(key[i] >> shift) & 255], 1);
+    __syncthreads();
+    // thread t owns bin 255 - t: an inclusive scan over t is a suffix sum over the bins
+    const int v = hist[255 - threadIdx.x];
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += n;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) inc += wsum[w];
+    const int exc = inc - v;
+    if (exc < kk && kk <= inc) {  // exactly one bin: the one holding rank kk
+      sel_prefix = prefix | ((uint32_t)(255 - threadIdx.x) << shift);
+      sel_k = kk - exc;
+    }
+    __syncthreads();
+    prefix = sel_prefix;
+    kk = sel_k;
+    mask |= 255u << shift;
+  }
+  const uint32_t T = prefix;  // the k-th largest key
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) c += (i * 256 + (int)threadIdx.x < cols && key[i] > T) ? 1 : 0;
+  const int n_gt = block_sum_int(c, sm4);
+  const int need_ties = k - n_gt;  // >= 1 by construction
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int rank[NC];  // (gt elements before me in my wave's part of the chunk) << 8 | (ties before me there)
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const bool valid = i * 256 + (int)threadIdx.x < cols;
+    const unsigned long long mg = __ballot(valid && key[i] > T), mt = __ballot(valid && key[i] == T);
+    if (lane == 0) {
+      cg[i * 4 + wave] = __popcll(mg);
+      ct[i * 4 + wave] = __popcll(mt);
+    }
+    rank[i] = (__popcll(mg & below) << 8) | __popcll(mt & below);
+  }
+  __syncthreads();
+  if (wave < 2) {  // wave 0: exclusive prefix of the gt counts in (chunk, wave) order; wave 1: of the tie counts
+    int* a = wave == 0 ? cg : ct;
+    constexpr int PER = (NC * 4 + 63) / 64;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int idx = lane * PER + q;
+      loc[q] = idx < NC * 4 ? a[idx] : 0;
+      sum += loc[q];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += n;
+    }
+    int run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int idx = lane * PER + q;
+      if (idx < NC * 4) a[idx] = run;
+      run += loc[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + threadIdx.x;
+    if (j < cols) {
+      const bool gt = key[i] > T, tie = key[i] == T;
+      const int gt_before = cg[i * 4 + wave] + (rank[i] >> 8);
+      const int tie_rank = ct[i * 4 + wave] + (rank[i] & 255);
+      if (gt || (tie && tie_rank < need_ties)) out_idx[beg + gt_before + min(tie_rank, need_ties)] = j;
+    }
+  }
+}
+
 // Evaluation (Coach.testEpoch, Main.py:403-411): scores of one user against all items with the user's TRAIN items pushed to
 // -1e8 (the reference multiplies by (1 - mask) and subtracts 1e8 * mask), then the k best columns in descending score order
 // (ties -> smaller column id).  One workgroup per user; k <= 64.  k selection rounds of a workgroup-wide arg-max would cost
@@ -439,7 +552,9 @@ extern "C" int dmm_diff_loss(const float* out, const float* x0, int64_t ld, cons
 extern "C" int dmm_topk_rows(const float* x, int64_t ldx, const int32_t* row_ids, const int32_t* out_ptr, int32_t* out_idx, int rows, int cols,
                              void* stream) {
   DMM_CHECK_ARG(x && row_ids && out_ptr && out_idx && rows > 0 && cols > 0, "dmm_topk_rows: bad arguments");
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, row_ids, out_ptr, out_idx, cols);
+  if (cols <= 256 * 32) hipLaunchKernelGGL(topk_rows_reg_kernel<32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, row_ids, out_ptr, out_idx, cols);
+  else if (cols <= 256 * 80) hipLaunchKernelGGL(topk_rows_reg_kernel<80>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, row_ids, out_ptr, out_idx, cols);
+  else hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, row_ids, out_ptr, out_idx, cols);
   DMM_LAUNCH_CHECK("dmm_topk_rows");
   return 0;
 }
