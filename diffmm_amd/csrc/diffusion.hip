@@ -274,84 +274,81 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
-// Register-resident variant for rows of up to 256 * NC columns (NC = 32: 8192; NC = 80: 20480): the row is read from memory ONCE
-// (keys held in registers through the four radix passes and the compaction), the bucket holding rank k is found by a parallel
-// suffix scan over the 256 bins instead of a one-thread walk, and the compaction needs no barrier per 256-column chunk
-// (per-(chunk, wave) counts go to LDS once, two waves scan them, every thread then knows its output positions).
-// Same selection rule and output order as topk_rows_kernel (ascending column, ties at the threshold -> smaller columns).
+// ---- register-resident selection for rows of up to 256 * NC columns (NC = 32: 8192; NC = 80: 20480) --------------------------------
+// The row is read from memory ONCE (order-preserving keys held in registers through the four radix passes and the compaction), the
+// bucket holding rank k is found by a parallel suffix scan over the 256 bins instead of a one-thread walk, and the compaction
+// needs no barrier per 256-column chunk (per-(chunk, wave) counts go to LDS once, two waves scan them, every thread then knows the
+// output positions of its elements).  Selection rule: the k largest; ties at the threshold -> smaller columns.
 template <int NC>
-__global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restrict__ x, long long ldx, const int32_t* __restrict__ row_ids,
-                                                             const int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_idx, int cols) {
-  __shared__ int hist[256];
-  __shared__ int wsum[4];
-  __shared__ int sm4[4];
-  __shared__ uint32_t sel_prefix;
-  __shared__ int sel_k;
-  __shared__ int cg[NC * 4 + 64], ct[NC * 4 + 64];
-  const int u = row_ids[blockIdx.x];
-  const int beg = out_ptr[u];
-  int k = out_ptr[u + 1] - beg;
-  if (k <= 0) return;  // uniform per block
-  if (k > cols) k = cols;
-  const float* __restrict__ r = x + (long long)blockIdx.x * ldx;
+struct TopkShared {
+  int hist[256];
+  int wsum[4];
+  int sm4[4];
+  uint32_t sel_prefix;
+  int sel_k;
+  int cg[NC * 4 + 64], ct[NC * 4 + 64];
+};
+
+// k-th largest key of the row (k >= 1, k <= number of valid columns)
+template <int NC>
+__device__ __forceinline__ uint32_t topk_select_threshold(const uint32_t (&key)[NC], int cols, int k, TopkShared<NC>& S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t key[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int j = i * 256 + threadIdx.x;
-    key[i] = j < cols ? fkey(r[j]) : 0u;
-  }
   uint32_t prefix = 0, mask = 0;
   int kk = k;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    hist[threadIdx.x] = 0;
+    S.hist[threadIdx.x] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NC; ++i)
-      if (i * 256 + (int)threadIdx.x < cols && (key[i] & mask) == prefix) atomicAdd(&hist[(key[i] >> shift) & 255], 1);
+      if (i * 256 + (int)threadIdx.x < cols && (key[i] & mask) == prefix) atomicAdd(&S.hist[(key[i] >> shift) & 255], 1);
     __syncthreads();
     // thread t owns bin 255 - t: an inclusive scan over t is a suffix sum over the bins
-    const int v = hist[255 - threadIdx.x];
+    const int v = S.hist[255 - threadIdx.x];
     int inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int n = __shfl_up(inc, o, 64);
       if (lane >= o) inc += n;
     }
-    if (lane == 63) wsum[wave] = inc;
+    if (lane == 63) S.wsum[wave] = inc;
     __syncthreads();
-    for (int w = 0; w < wave; ++w) inc += wsum[w];
+    for (int w = 0; w < wave; ++w) inc += S.wsum[w];
     const int exc = inc - v;
     if (exc < kk && kk <= inc) {  // exactly one bin: the one holding rank kk
-      sel_prefix = prefix | ((uint32_t)(255 - threadIdx.x) << shift);
-      sel_k = kk - exc;
+      S.sel_prefix = prefix | ((uint32_t)(255 - threadIdx.x) << shift);
+      S.sel_k = kk - exc;
     }
     __syncthreads();
-    prefix = sel_prefix;
-    kk = sel_k;
+    prefix = S.sel_prefix;
+    kk = S.sel_k;
     mask |= 255u << shift;
   }
-  const uint32_t T = prefix;  // the k-th largest key
+  return prefix;
+}
+
+// pos[i] = position (0 .. k-1, ascending column order) of this thread's i-th element among the selected ones, or -1
+template <int NC>
+__device__ __forceinline__ void topk_positions(const uint32_t (&key)[NC], int cols, int k, uint32_t T, TopkShared<NC>& S, int (&pos)[NC]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int c = 0;
 #pragma unroll
   for (int i = 0; i < NC; ++i) c += (i * 256 + (int)threadIdx.x < cols && key[i] > T) ? 1 : 0;
-  const int n_gt = block_sum_int(c, sm4);
+  const int n_gt = block_sum_int(c, S.sm4);
   const int need_ties = k - n_gt;  // >= 1 by construction
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int rank[NC];  // (gt elements before me in my wave's part of the chunk) << 8 | (ties before me there)
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const bool valid = i * 256 + (int)threadIdx.x < cols;
     const unsigned long long mg = __ballot(valid && key[i] > T), mt = __ballot(valid && key[i] == T);
     if (lane == 0) {
-      cg[i * 4 + wave] = __popcll(mg);
-      ct[i * 4 + wave] = __popcll(mt);
+      S.cg[i * 4 + wave] = __popcll(mg);
+      S.ct[i * 4 + wave] = __popcll(mt);
     }
-    rank[i] = (__popcll(mg & below) << 8) | __popcll(mt & below);
+    pos[i] = (__popcll(mg & below) << 8) | __popcll(mt & below);  // ranks inside the wave's part of the chunk, for now
   }
   __syncthreads();
   if (wave < 2) {  // wave 0: exclusive prefix of the gt counts in (chunk, wave) order; wave 1: of the tie counts
-    int* a = wave == 0 ? cg : ct;
+    int* a = wave == 0 ? S.cg : S.ct;
     constexpr int PER = (NC * 4 + 63) / 64;
     int loc[PER], sum = 0;
 #pragma unroll
@@ -377,13 +374,74 @@ __global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restr
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
+    const bool valid = i * 256 + (int)threadIdx.x < cols;
+    const bool gt = valid && key[i] > T, tie = valid && key[i] == T;
+    const int gt_before = S.cg[i * 4 + wave] + (pos[i] >> 8);
+    const int tie_rank = S.ct[i * 4 + wave] + (pos[i] & 255);
+    pos[i] = (gt || (tie && tie_rank < need_ties)) ? gt_before + min(tie_rank, need_ties) : -1;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restrict__ x, long long ldx, const int32_t* __restrict__ row_ids,
+                                                             const int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_idx, int cols) {
+  __shared__ TopkShared<NC> S;
+  const int u = row_ids[blockIdx.x];
+  const int beg = out_ptr[u];
+  int k = out_ptr[u + 1] - beg;
+  if (k <= 0) return;  // uniform per block
+  if (k > cols) k = cols;
+  const float* __restrict__ r = x + (long long)blockIdx.x * ldx;
+  uint32_t key[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
     const int j = i * 256 + threadIdx.x;
-    if (j < cols) {
-      const bool gt = key[i] > T, tie = key[i] == T;
-      const int gt_before = cg[i * 4 + wave] + (rank[i] >> 8);
-      const int tie_rank = ct[i * 4 + wave] + (rank[i] & 255);
-      if (gt || (tie && tie_rank < need_ties)) out_idx[beg + gt_before + min(tie_rank, need_ties)] = j;
+    key[i] = j < cols ? fkey(r[j]) : 0u;
+  }
+  const uint32_t T = topk_select_threshold<NC>(key, cols, k, S);
+  int pos[NC];
+  topk_positions<NC>(key, cols, k, T, S, pos);
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (pos[i] >= 0) out_idx[beg + pos[i]] = i * 256 + threadIdx.x;
+}
+
+// Evaluation (Coach.testEpoch, Main.py:403-411), register-resident: the user's TRAIN items are set to -1e8 in the score row (in
+// place, like the streaming kernel below), the k winners are found as above, parked in LDS and ordered by a rank sort
+// (descending score, equal scores: smaller column first).  k <= 64.
+template <int NC>
+__global__ __launch_bounds__(256) void eval_topk_reg_kernel(float* __restrict__ score, long long ld, const int32_t* __restrict__ users,
+                                                             const int64_t* __restrict__ trn_ptr, const int64_t* __restrict__ trn_col, int cols, int k,
+                                                             int32_t* __restrict__ out) {
+  __shared__ TopkShared<NC> S;
+  __shared__ uint32_t wkey[64];
+  __shared__ int wcol[64];
+  const int u = users[blockIdx.x];
+  float* __restrict__ r = score + (long long)blockIdx.x * ld;
+  for (long long p = trn_ptr[u] + threadIdx.x; p < trn_ptr[u + 1]; p += 256) r[trn_col[p]] = -1e8f;
+  __syncthreads();
+  const int kq = k < cols ? k : cols;
+  uint32_t key[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + threadIdx.x;
+    key[i] = j < cols ? fkey(r[j]) : 0u;
+  }
+  const uint32_t T = topk_select_threshold<NC>(key, cols, kq, S);
+  int pos[NC];
+  topk_positions<NC>(key, cols, kq, T, S, pos);
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (pos[i] >= 0) {
+      wkey[pos[i]] = key[i];
+      wcol[pos[i]] = i * 256 + threadIdx.x;
     }
+  __syncthreads();
+  if ((int)threadIdx.x < kq) {  // winners sit in ascending column order: rank = how many beat me (larger key, or equal key at a smaller column)
+    const uint32_t mk = wkey[threadIdx.x];
+    int rank = 0;
+    for (int b = 0; b < kq; ++b) rank += (wkey[b] > mk || (wkey[b] == mk && b < (int)threadIdx.x)) ? 1 : 0;
+    out[(long long)blockIdx.x * k + rank] = wcol[threadIdx.x];
   }
 }
 
@@ -507,7 +565,9 @@ extern "C" int dmm_eval_metrics(const int32_t* top, const int32_t* users, const 
 extern "C" int dmm_eval_topk(float* score, int64_t ld, const int32_t* users, const int64_t* trn_ptr, const int64_t* trn_col, int rows, int cols,
                              int k, int32_t* out, void* stream) {
   DMM_CHECK_ARG(score && users && trn_ptr && trn_col && out && rows > 0 && cols > 0 && k >= 1 && k <= 64, "dmm_eval_topk: bad arguments (k <= 64)");
-  hipLaunchKernelGGL(eval_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
+  if (cols <= 256 * 32) hipLaunchKernelGGL(eval_topk_reg_kernel<32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
+  else if (cols <= 256 * 80) hipLaunchKernelGGL(eval_topk_reg_kernel<80>, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
+  else hipLaunchKernelGGL(eval_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
   DMM_LAUNCH_CHECK("dmm_eval_topk");
   return 0;
 }
