@@ -98,6 +98,28 @@ __global__ __launch_bounds__(256) void gb_count_items(const int32_t* __restrict_
   }
 }
 
+// The same with a workgroup-private histogram in LDS (I <= GB_LDS_ITEMS): a popular item of a rebuilt graph is chosen by thousands of
+// users, and that many atomics on ONE address serialise in L2 (~100 us at TikTok size); here a hot item costs one global atomic per
+// workgroup.  Each workgroup takes a contiguous chunk of GB_CHUNK edges.
+constexpr int GB_CHUNK = 2048;
+constexpr int GB_LDS_ITEMS = 18 * 1024;  // 2 x 72 KiB of LDS in gb_fill_lds
+
+__global__ __launch_bounds__(256) void gb_count_items_lds(const int32_t* __restrict__ item, int E, int I, int32_t* __restrict__ cnt) {
+  extern __shared__ int gb_h[];
+  for (int b = threadIdx.x; b < I; b += 256) gb_h[b] = 0;
+  __syncthreads();
+  const int e0 = blockIdx.x * GB_CHUNK, e1 = min(E, e0 + GB_CHUNK);
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int it = item[e];
+    if ((unsigned)it < (unsigned)I) atomicAdd(&gb_h[it], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < I; b += 256) {
+    const int c = gb_h[b];
+    if (c) atomicAdd(&cnt[b], c);
+  }
+}
+
 // phase 1: per-workgroup channel sums
 __global__ __launch_bounds__(GB_SCAN_BLOCK) void gb_scan_partial(GbShape S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ cnt,
                                                                 int32_t* __restrict__ blocksum /*[nch][nb]*/) {
@@ -252,6 +274,50 @@ __global__ __launch_bounds__(256) void gb_fill(GbShape S, const int32_t* __restr
   }
 }
 
+// gb_fill with workgroup-private slot allocation (I <= GB_LDS_ITEMS): an edge takes its rank inside the workgroup's chunk from an LDS
+// counter; the chunk's block of slots in the item row comes from ONE global atomic per (workgroup, item).  Slot order inside an item row
+// is arbitrary either way (gb_finish_item_rows orders the row).
+__global__ __launch_bounds__(256) void gb_fill_lds(GbShape S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ edge_user,
+                                                   const int32_t* __restrict__ item, const int32_t* __restrict__ cnt, const int32_t* __restrict__ rowptr,
+                                                   const double* __restrict__ dinv, int32_t* __restrict__ fill, int32_t* __restrict__ col,
+                                                   float* __restrict__ val) {
+  extern __shared__ int gb_h[];  // [I] local counts, then [I] bases
+  int* hb = gb_h + S.I;
+  for (int b = threadIdx.x; b < S.I; b += 256) gb_h[b] = 0;
+  __syncthreads();
+  constexpr int PER = GB_CHUNK / 256;
+  const int e0 = blockIdx.x * GB_CHUNK, e1 = min(S.E, e0 + GB_CHUNK);
+  int lr[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int e = e0 + q * 256 + threadIdx.x;
+    lr[q] = e < e1 ? atomicAdd(&gb_h[item[e]], 1) : 0;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < S.I; b += 256) {
+    const int c = gb_h[b];
+    if (c) hb[b] = atomicAdd(&fill[b], c);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int e = e0 + q * 256 + threadIdx.x;
+    if (e < e1) {
+      const int u = edge_user[e], it = item[e];
+      const int lu = user_ptr[u + 1] - user_ptr[u] + 1, li = cnt[it] + 1;
+      const int p = rowptr[u] + 1 + (e - user_ptr[u]);
+      col[p] = S.U + it;
+      val[p] = gb_val(dinv, lu, li);
+      col[rowptr[S.U + it] + hb[it] + lr[q]] = u;
+    }
+  }
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < S.U; u += gridDim.x * 256) {
+    const int lu = user_ptr[u + 1] - user_ptr[u] + 1, p = rowptr[u];
+    col[p] = u;
+    val[p] = gb_val(dinv, lu, lu);
+  }
+}
+
 // One workgroup per item row: users ascending, self loop last.  Users of a row are distinct, so "number of smaller entries" is a
 // permutation.  Rows longer than GB_SORT_CAP take the bitmap path (one U-bit map per workgroup in `bitmaps`).
 __global__ __launch_bounds__(256) void gb_finish_item_rows(GbShape S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ cnt,
@@ -372,13 +438,26 @@ extern "C" int dmm_graph_build(const int32_t* user_ptr, const int32_t* edge_user
     return 2;
   }
   const int eg = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (std::max<int64_t>(E, U) + 255) / 256));
-  if (E > 0) hipLaunchKernelGGL(gb_count_items, dim3(eg), dim3(256), 0, s, item_idx, S.E, I, cnt);
+  const bool lds_path = I <= GB_LDS_ITEMS && E > 0;
+  const int cg = (int)((E + GB_CHUNK - 1) / GB_CHUNK);
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gb_count_items_lds), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_ITEMS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gb_fill_lds), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_ITEMS * 8);
+    return true;
+  }();
+  (void)once;
+  if (lds_path) hipLaunchKernelGGL(gb_count_items_lds, dim3(cg), dim3(256), (size_t)I * 4, s, item_idx, S.E, I, cnt);
+  else if (E > 0) hipLaunchKernelGGL(gb_count_items, dim3(eg), dim3(256), 0, s, item_idx, S.E, I, cnt);
   hipLaunchKernelGGL(gb_scan_partial, dim3(nb), dim3(GB_SCAN_BLOCK), 0, s, S, user_ptr, (const int32_t*)cnt, blocksum);
   hipLaunchKernelGGL(gb_scan_blocks, dim3(1), dim3(GB_SCAN_BLOCK), 0, s, S, nb, blocksum, base, (int4*)tasks, meta, rowptr);
   hipLaunchKernelGGL(gb_scan_emit, dim3(nb), dim3(GB_SCAN_BLOCK), 0, s, S, user_ptr, (const int32_t*)cnt, (const int32_t*)blocksum, (const int32_t*)base,
                      rowptr, (int4*)tasks, (int4*)fix);
-  hipLaunchKernelGGL(gb_fill, dim3(eg), dim3(256), 0, s, S, user_ptr, edge_user, item_idx, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table, fill,
-                     col, val);
+  if (lds_path)
+    hipLaunchKernelGGL(gb_fill_lds, dim3(cg), dim3(256), (size_t)I * 8, s, S, user_ptr, edge_user, item_idx, (const int32_t*)cnt, (const int32_t*)rowptr,
+                       dinv_table, fill, col, val);
+  else
+    hipLaunchKernelGGL(gb_fill, dim3(eg), dim3(256), 0, s, S, user_ptr, edge_user, item_idx, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table, fill,
+                       col, val);
   hipLaunchKernelGGL(gb_finish_item_rows, dim3(std::min(I, 65535)), dim3(256), 0, s, S, user_ptr, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table,
                      col, val, bitmaps, 0);
   hipLaunchKernelGGL(gb_finish_item_rows, dim3(GB_LONG_GROUPS), dim3(256), 0, s, S, user_ptr, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table, col,
