@@ -62,7 +62,6 @@ _SIGS = {
     "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_transpose_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_temb_bias_table": (C.c_int, [_P, _P, _I, _P, _L, _I, _P, _I, _I, _P, _P]),
-    "dmm_temb_bf16": (C.c_int, [_I, _P, _P, _I, _P, _L, _I, _I, _P]),
     "dmm_rownorm_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "dmm_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "dmm_gcn_mix_fwd": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _L, _P]),

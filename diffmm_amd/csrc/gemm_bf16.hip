@@ -1,4 +1,6 @@
-// bf16 x bf16 -> fp32 NT GEMM for the reverse diffusion chain: C = post(act(alpha * A B^T + bias)).
+// bf16 x bf16 -> fp32 NT GEMM for the reverse diffusion chain and the diffusion training step: C = post(act(alpha * A B^T + bias)).
+// This file: the host entry points, the cast / transpose helpers and the REGISTER-STAGED tiles used for small launches and for
+// K % 64 != 0; launches with K % 64 == 0 and >= 128 tiles of 256 x 256 go to the LDS-DMA tile in gemm_bf16_8ph.hip.
 //   A [M, K] bf16 row-major (activations), B [N, K] bf16 row-major (nn.Linear weight layout), K % 8 == 0.
 // The chain (GaussianDiffusion.generate_view -> p_mean_variance -> Denoise.forward, Model.py:300-322,357-378,210-218) issues
 // two of these per timestep, user batch and modality: T * ceil(U/B) * M pairs per epoch -- the FLOP-dominant kernel of the
@@ -256,114 +258,6 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_kernel(const GemmBf16Batc
   gemm_epilogue<BN>(P, acc, smem, m0, n0, wave, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Variant with direct global -> LDS staging (global_load_lds_dwordx4, "LDS-DMA"): no staging VGPRs and no ds_write instructions
-// (whose VGPR -> LDS transfer is ~13 cycles per wave-instruction and shares the LDS pipe with the fragment reads).
-// One wave-instruction fills 8 tile rows (1 KiB, lane-linear in LDS); the XOR swizzle is applied on the per-lane SOURCE address.
-// Requires K % 64 == 0 (out-of-range ROWS read clamped addresses; their outputs are discarded by the epilogue).
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int ROWS, int NWAVES>
-__device__ __forceinline__ void glds_tile(const __bf16* __restrict__ base, long long ld, int row0, int rows, int k0, char* tile, int wave, int lane) {
-#pragma unroll
-  for (int g = wave; g < ROWS / 8; g += NWAVES) {
-    const int r = 8 * g + (lane >> 3);          // tile row this lane fills
-    const int c = (lane & 7) ^ ((r >> 1) & 7);  // source chunk that belongs at LDS chunk (lane & 7) of that row
-    const int gr = row0 + r < rows ? row0 + r : rows - 1;
-    const __bf16* src = base + (long long)gr * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(tile + g * 1024), 16, 0, 0);
-  }
-}
-
-template <int BM, int BN>
-__global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_glds_kernel(const GemmBf16Batch batch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = BM / 32;  // waves
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int WN = BN / 2, NT = WN / 32;
-  const GemmBf16P& P = batch.p[blockIdx.y];
-  const int mtile = blockIdx.x / P.nt, ntile = blockIdx.x % P.nt;
-  const int m0 = mtile * BM, n0 = ntile * BN;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  const int nk = P.K / GB_BK;
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  glds_tile<BM, NW>(P.A, P.lda, m0, P.M, 0, smem, wave, lane);
-  glds_tile<BN, NW>(P.B, P.ldb, n0, P.N, 0, smem + A_BYTES, wave, lane);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    char* a_t = smem + cur * STAGE;
-    char* b_t = a_t + A_BYTES;
-    if (kt + 1 < nk) {
-      glds_tile<BM, NW>(P.A, P.lda, m0, P.M, (kt + 1) * GB_BK, smem + (cur ^ 1) * STAGE, wave, lane);
-      glds_tile<BN, NW>(P.B, P.ldb, n0, P.N, (kt + 1) * GB_BK, smem + (cur ^ 1) * STAGE + A_BYTES, wave, lane);
-    }
-    mma_tile<NT>(acc, a_t, b_t, wm * 64 + fr, wn * WN + fr, fh);
-    __syncthreads();  // hipcc drains the pending LDS-DMA (vmcnt(0)) in front of this barrier
-    cur ^= 1;
-  }
-  gemm_epilogue<BN>(P, acc, smem, m0, n0, wave, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// LDS-ring variant: 256 x 128 tile, 8 waves (two per SIMD), BK = 64, THREE 48 KiB stages filled by LDS-DMA.  Two K tiles are in
-// flight while a third is being multiplied: a load has two full MFMA phases to land.  hipcc neither counts LDS-DMA completion at
-// a ds_read nor may a __syncthreads() be used (it would drain the ring), so ordering is explicit:
-//     s_waitcnt vmcnt(GL)   -- this wave's part of tile kt has landed (the GL loads of tile kt+1 may still be in flight)
-//     s_barrier             -- (RAW) every wave's part of tile kt has landed; (WAR) every wave finished reading tile kt-1
-//     issue tile kt+2 into the stage tile kt-1 occupied;  ds_read + MFMA on tile kt
-// Loads past the last tile are still issued (clamped addresses, a free stage) so the count GL per tile is a constant.
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_ring_kernel(const GemmBf16Batch batch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = BM / 32;  // 3 stages
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int GL = (BM / 8 + BN / 8) / NW;  // LDS-DMA instructions per wave per K tile
-  constexpr int WN = BN / 2, NT = WN / 32;
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "row groups must divide evenly over the waves");
-  const GemmBf16P& P = batch.p[blockIdx.y];
-  const int mtile = blockIdx.x / P.nt, ntile = blockIdx.x % P.nt;
-  const int m0 = mtile * BM, n0 = ntile * BN;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  const int nk = P.K / GB_BK;
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto issue = [&](int kt, int stage) {
-    const int k0 = (kt < nk ? kt : 0) * GB_BK;  // past the end: re-read tile 0 into a stage nobody reads any more
-    glds_tile<BM, NW>(P.A, P.lda, m0, P.M, k0, smem + stage * STAGE, wave, lane);
-    glds_tile<BN, NW>(P.B, P.ldb, n0, P.N, k0, smem + stage * STAGE + A_BYTES, wave, lane);
-  };
-  issue(0, 0);
-  issue(1, 1);
-  int st = 0;  // stage of tile kt
-  for (int kt = 0; kt < nk; ++kt) {
-    if (GL == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else if (GL == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    const int nst = st == 0 ? 2 : st - 1;  // stage of tile kt-1 == stage of tile kt+2
-    issue(kt + 2, nst);
-    const char* a_t = smem + st * STAGE;
-    const char* b_t = a_t + A_BYTES;
-    mma_tile<NT>(acc, a_t, b_t, wm * 64 + fr, wn * WN + fr, fh);
-    st = st == 2 ? 0 : st + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ring drained, every wave done reading: LDS is free
-  gemm_epilogue<BN>(P, acc, smem, m0, n0, wave, lane);
-}
-
 // fp32 [rows, cols] (ld lds) -> bf16 (ld ldd); columns cols..cols_pad are zero-filled
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, long long lds, __bf16* __restrict__ dst, long long ldd,
                                                          int rows, int cols, int cols_pad) {
@@ -394,35 +288,6 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* _
 }
 
 // time embedding of a single timestep (every row of the reverse chain shares it) -> bf16 columns I.. of xb, zero padded to ldx
-__global__ __launch_bounds__(256) void temb_bf16_kernel(int t, const float* __restrict__ w_emb, const float* __restrict__ b_emb, int te,
-                                                         __bf16* __restrict__ xb, long long ldx, int B, int I) {
-  __shared__ float e[32], o[32];
-  if (threadIdx.x < te) {
-    const int k = threadIdx.x, half = te / 2;
-    float v = 0.f;
-    if (!((te & 1) && k == te - 1)) {
-      const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
-      const float ang = (float)t * f;
-      v = k < half ? cosf(ang) : sinf(ang);
-    }
-    e[k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < te) {
-    float v = b_emb[threadIdx.x];
-    for (int k = 0; k < te; ++k) v = fmaf(w_emb[threadIdx.x * te + k], e[k], v);
-    o[threadIdx.x] = v;
-  }
-  __syncthreads();
-  const int width = (int)(ldx - I);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)B * width; i += (long long)gridDim.x * 256) {
-    const int b = (int)(i / width), c = (int)(i % width);
-    xb[(long long)b * ldx + I + c] = c < te ? (__bf16)o[c] : (__bf16)0.f;
-  }
-}
-
-// Per-timestep layer-1 bias of the reverse chain: every row of a chain step shares the timestep, so the time embedding's
-// contribution W1[:, I:I+te] . emb_layer(features(t)) is a vector; table[t][h] = b1[h] + that, for all T steps at once (fp32).
 __global__ __launch_bounds__(256) void temb_bias_table_kernel(const float* __restrict__ w_emb, const float* __restrict__ b_emb, int te,
                                                                const float* __restrict__ w1, long long ldw1, int I, const float* __restrict__ b1,
                                                                int H, float* __restrict__ table) {
@@ -471,28 +336,6 @@ static void launch_tile(const GemmBf16Batch& b, int blocks, hipStream_t s) {
     return true;
   }();
   (void)once;
-  static const int use_glds = [] { const char* e = getenv("DMM_GEMM_GLDS"); return e ? atoi(e) : 0; }();  // 1: 2-stage LDS-DMA, 2: 3-stage ring
-  if constexpr (BM == 256) {
-    if (use_glds == 2 && b.p[0].K % GB_BK == 0 && b.p[0].K >= 2 * GB_BK && b.p[0].part == 0) {
-      constexpr int RING = 3 * (BM + BN) * 128;
-      static bool once3 = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_ring_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, RING);
-        return true;
-      }();
-      (void)once3;
-      hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<BM, BN>), dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(BM * 2), RING, s, b);
-      return;
-    }
-  }
-  if (use_glds == 1 && b.p[0].K % GB_BK == 0 && b.p[0].part == 0) {
-    static bool once2 = [] {
-      if (LDS > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_glds_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      return true;
-    }();
-    (void)once2;
-    hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<BM, BN>), dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(BM * 2), LDS, s, b);
-    return;
-  }
   hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(blocks, b.n), dim3(BM * 2), LDS, s, b);
 }
 
@@ -580,11 +423,3 @@ extern "C" int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst,
   return 0;
 }
 
-extern "C" int dmm_temb_bf16(int t, const float* w_emb, const float* b_emb, int te, void* xb, int64_t ldx, int B, int I, void* stream) {
-  DMM_CHECK_ARG(w_emb && b_emb && xb && te >= 2 && te <= 32 && ldx >= I + te && B > 0, "dmm_temb_bf16: bad arguments");
-  const long long n = (long long)B * (ldx - I);
-  hipLaunchKernelGGL(temb_bf16_kernel, dim3((unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, w_emb,
-                     b_emb, te, (__bf16*)xb, (long long)ldx, B, I);
-  DMM_LAUNCH_CHECK("dmm_temb_bf16");
-  return 0;
-}

@@ -693,13 +693,11 @@ class DiffusionEngine:
         return (self.xa if self.T % 2 == 0 else self.xb)[:B, :I]
 
     def generate_views_bf16(self, x0: Tensor) -> List[Tensor]:
-        """All modalities' reverse chains advanced together: per timestep two batched launches (M problems each).
-        chain_state == 'fp32' (default): the running x_t is kept in fp32 (residual read + write) next to its bf16 MFMA operand copy;
-        'bf16': only the bf16 copy is carried between steps (half the HBM traffic of the layer-2 epilogue), fp32 is written by the
-        last step only, for the top-k."""
+        """All modalities' reverse chains: the running x_t is kept in fp32 (the posterior-mean residual and the final top-k) next to the
+        bf16 copy the next layer-1 GEMM reads.  One HIP stream per modality by default (hp chain_streams / DMM_CHAIN_STREAMS=0: one
+        batched launch per layer and step instead).  (Carrying only the bf16 copy between steps was measured: no faster, 0.6 % of the
+        rebuilt edges change -- not kept.)"""
         B, I, M = x0.shape[0], self.I, self.M
-        if self.hp.get("chain_state", "fp32") == "bf16":
-            return self._generate_views_bf16_state(x0)
         for m in range(M):
             self._refresh_bf16_weights(m)
         if M > 1 and self.hp.get("chain_streams", os.environ.get("DMM_CHAIN_STREAMS", "1") != "0"):
@@ -770,31 +768,6 @@ class DiffusionEngine:
             main.wait_event(self._side_events[m])
         fin = self.cxa if self.T % 2 == 0 else self.cxb
         return [fin[m][:B, :I] for m in range(M)]
-
-    def _generate_views_bf16_state(self, x0: Tensor) -> List[Tensor]:
-        B, I, M = x0.shape[0], self.I, self.M
-        for m in range(M):
-            self._refresh_bf16_weights(m)
-        self.cxa[0][:B, :I].copy_(x0)
-        plan = self._chain_plans.get(("all16", B))
-        if plan is None:
-            with L.Recorder() as plan:
-                cur16, nxt16, h16 = [t[:B] for t in self.cxa16], [t[:B] for t in self.cxb16], [t[:B] for t in self.ch16]
-                fin = [t[:B] for t in self.cxb]
-                for m in range(M):
-                    ops.zero_(nxt16[m])
-                    ops.cast_bf16(self.cxa[0][:B], cur16[m], cols=I, cols_pad=self.Kp)
-                for i in range(self.T - 1, -1, -1):
-                    ops.gemm_bf16_nt_batched([dict(A=cur16[m], B=self.w1_16[m], out_bf16=h16[m], bias=self.bias_t[m][i], act=L.ACT_TANH)
-                                              for m in range(M)])
-                    last = i == 0
-                    ops.gemm_bf16_nt_batched([dict(A=h16[m], B=self.w2_16[m], out=fin[m] if last else None, out_bf16=None if last else nxt16[m],
-                                                   bias=self.P[m].view("out_layers.0.bias"), residual_bf16=cur16[m], e1=float(self.c1[i]),
-                                                   e2=float(self.c2[i]), N=I) for m in range(M)])
-                    cur16, nxt16 = nxt16, cur16
-            self._chain_plans[("all16", B)] = plan
-        L.replay(plan)
-        return [self.cxb[m][:B, :I] for m in range(M)]
 
     def generate_view(self, m: int, x0: Tensor, precision: int = 1) -> Tensor:
         """sampling_step == 0 path: x_T = x0, then T deterministic posterior-mean steps.  Returns a [B, I] view (ld = Kp)."""

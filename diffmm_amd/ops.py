@@ -213,10 +213,6 @@ def temb_bias_table(w_emb: Tensor, b_emb: Tensor, w1: Tensor, I: int, b1: Tensor
            L.stream())
 
 
-def temb_bf16(t: int, w_emb: Tensor, b_emb: Tensor, xb: Tensor, I: int) -> None:
-    L.call("dmm_temb_bf16", int(t), L.ptr(w_emb), L.ptr(b_emb), w_emb.shape[0], L.ptr(xb), xb.stride(0), xb.shape[0], I, L.stream())
-
-
 # ------------------------------------------------------------------------------------------------
 # normalisation / mixing
 # ------------------------------------------------------------------------------------------------

@@ -102,8 +102,9 @@ int dmm_gemm(const dmm_gemm_args* a /*host*/, void* stream);
 
 /* bf16 NT GEMM of the reverse diffusion chain (GaussianDiffusion.generate_view, Model.py:300-322: T x Denoise.forward +
  * posterior mean): A [M,K] and B [N,K] are bf16 row-major with K % 8 == 0; outputs fp32 (C) and/or bf16 (Cb); same epilogue
- * as dmm_gemm.  dmm_cast_bf16 makes the bf16 copies (weights once per epoch, x_0 once per chain); dmm_temb_bf16 writes the
- * time embedding of one timestep (all rows of a chain step share it) into columns I.. of the bf16 operand. */
+ * as dmm_gemm.  dmm_cast_bf16 makes the bf16 copies (weights once per epoch, x_0 once per chain); the time embedding of a chain
+ * step (all rows share t) enters as that step's bias row of dmm_temb_bias_table.  Tile choice: K % 64 == 0 and >= 128 tiles of
+ * 256 x 256 -> the LDS-DMA tile of csrc/gemm_bf16_8ph.hip; otherwise the register-staged 128 x 64 / 128 x 128 / 256 x 128 tiles. */
 typedef struct dmm_gemm_bf16_args {
   const void* A; int64_t lda;
   const void* B; int64_t ldb;
@@ -117,7 +118,7 @@ typedef struct dmm_gemm_bf16_args {
   int32_t act;
 } dmm_gemm_bf16_args;
 int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a /*host*/, void* stream);
-/* up to 4 problems of one shape in one launch (the modalities' chains advance together: enough tiles for 256 x 128 workgroup tiles) */
+/* up to 4 problems of one shape in one launch (the modalities' large GEMMs go out together: enough tiles to fill the chip) */
 int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* a /*host array*/, int n_batch, void* stream);
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
@@ -125,7 +126,6 @@ int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ld
 /* table[t][h] = b1[h] + sum_c W1[h][I+c] * emb_layer(features(t))[c]: the layer-1 bias of chain step t (all rows share t), T x H */
 int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int te, const float* w1, int64_t ldw1, int I, const float* b1, int H,
                         int T, float* table, void* stream);
-int dmm_temb_bf16(int t, const float* w_emb, const float* b_emb, int te, void* xb, int64_t ldx, int B, int I, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Row L2 normalisation, F.normalize(x, p=2, dim=1, eps=1e-12): Model.py:89,92,104; Utils.py:72.
