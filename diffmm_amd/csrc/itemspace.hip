@@ -7,6 +7,8 @@
 //   dmm_item_expand    Y[B, :I] = R[B, :I] + P[B, d] . F[I, d]^T   x_t + (proj * gate) @ modal_feat.T      (Model.py:209)
 //                                                           and the gradient  dout += dum @ model_feats.T
 // Arithmetic: operands rounded to bf16 as they are loaded (the "precision 1" mode of dmm_gemm), MFMA 16x16x32, fp32 accumulation.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmm {
@@ -56,13 +58,20 @@ __global__ __launch_bounds__(256) void item_project_kernel(const float* __restri
     }
     __syncthreads();
     const int steps = min(IP_KS, (kend - k0 + 31) & ~31) / 32;
+    // the X fragments of k-step s+1 are requested before the MFMAs of step s (the request past the last step repeats it: no branch
+    // around a load, so the compiler keeps counted waits)
+    float4 xa[4][2], xn[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      xa[mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + k0);
+      xa[mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + k0 + 4);
+    }
     for (int s = 0; s < steps; ++s) {
-      const int k = k0 + s * 32;
-      float4 xa[4][2];
+      const int kn = k0 + min(s + 1, steps - 1) * 32;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        xa[mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + k);
-        xa[mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + k + 4);
+        xn[mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + kn);
+        xn[mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + kn + 4);
       }
       bf16x8 fb[NT];
 #pragma unroll
@@ -72,6 +81,11 @@ __global__ __launch_bounds__(256) void item_project_kernel(const float* __restri
         const bf16x8 fa = is_cvt8(xa[mt][0], xa[mt][1]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[nt], acc[mt][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        xa[mt][0] = xn[mt][0];
+        xa[mt][1] = xn[mt][1];
       }
     }
   }
@@ -160,7 +174,8 @@ extern "C" int dmm_item_project(const float* X, int64_t ldx, const float* F, int
                 "dmm_item_project: X and F rows must be 16-byte aligned and X rows readable up to round_up(I, 32)");
   // K slices: enough workgroups to fill the chip a few times over, slices a multiple of 32 items
   const int rb = (B + 255) / 256;
-  int ks = std::max(1, std::min(64, 768 / rb));
+  static const int force_ks = [] { const char* e = getenv("DMM_ITEM_KS"); return e ? atoi(e) : 0; }();  // tuning knob
+  int ks = force_ks > 0 ? force_ks : std::max(1, std::min(64, 384 / rb));
   int kchunk = (((I + ks - 1) / ks) + 31) & ~31;
   ks = (I + kchunk - 1) / kchunk;
   hipStream_t s = (hipStream_t)stream;
