@@ -1,6 +1,6 @@
 // bf16 x bf16 -> fp32 NT GEMM for the reverse diffusion chain and the diffusion training step: C = post(act(alpha * A B^T + bias)).
 // This file: the host entry points, the cast / transpose helpers and the REGISTER-STAGED tiles used for small launches and for
-// K % 64 != 0; launches with K % 64 == 0 and >= 128 tiles of 256 x 256 go to the LDS-DMA tile in gemm_bf16_8ph.hip.
+// K % 64 != 0; launches with K % 64 == 0 and >= 64 tiles of 256 x 256 go to the LDS-DMA tile in gemm_bf16_8ph.hip.
 //   A [M, K] bf16 row-major (activations), B [N, K] bf16 row-major (nn.Linear weight layout), K % 8 == 0.
 // The chain (GaussianDiffusion.generate_view -> p_mean_variance -> Denoise.forward, Model.py:300-322,357-378,210-218) issues
 // two of these per timestep, user batch and modality: T * ceil(U/B) * M pairs per epoch -- the FLOP-dominant kernel of the
@@ -361,11 +361,12 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   static const int force_tile = [] { const char* e = getenv("DMM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning knobs: 64 / 128 / 256
   static const int force_part = [] { const char* e = getenv("DMM_GEMM_PART"); return e ? atoi(e) : -1; }();
   const int M = a0->M, N = a0->N;
-  // 256 x 256 LDS-DMA tile (gemm_bf16_8ph.hip): K must be whole 64-wide tiles and the grid should fill at least half of the 256
-  // CUs (the chain runs one launch per modality on concurrent streams)
+  // 256 x 256 LDS-DMA tile (gemm_bf16_8ph.hip): K must be whole 64-wide tiles and the grid should fill at least a quarter of the
+  // 256 CUs (the chain runs one launch per modality on concurrent streams; with users sharded over 2 replicas a layer-1 launch has 76
+  // tiles -- one round of the LDS-DMA tile is still twice as fast as the register-staged tiles at that size)
   static const int use_8ph = [] { const char* e = getenv("DMM_GEMM_8PH"); return e ? atoi(e) : 1; }();  // 0: register-staged tiles only
   const long long t8 = (long long)cdiv(M, 256) * cdiv(N, 256) * n_batch;
-  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 128))) {
+  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 64))) {
     for (int i = 0; i < n_batch; ++i) {
       b.p[i].mt = cdiv(M, 256); b.p[i].nt = cdiv(N, 256); b.p[i].part = force_part >= 0 ? force_part : 2;
     }

@@ -103,7 +103,7 @@ int dmm_gemm(const dmm_gemm_args* a /*host*/, void* stream);
 /* bf16 NT GEMM of the reverse diffusion chain (GaussianDiffusion.generate_view, Model.py:300-322: T x Denoise.forward +
  * posterior mean): A [M,K] and B [N,K] are bf16 row-major with K % 8 == 0; outputs fp32 (C) and/or bf16 (Cb); same epilogue
  * as dmm_gemm.  dmm_cast_bf16 makes the bf16 copies (weights once per epoch, x_0 once per chain); the time embedding of a chain
- * step (all rows share t) enters as that step's bias row of dmm_temb_bias_table.  Tile choice: K % 64 == 0 and >= 128 tiles of
+ * step (all rows share t) enters as that step's bias row of dmm_temb_bias_table.  Tile choice: K % 64 == 0 and >= 64 tiles of
  * 256 x 256 -> the LDS-DMA tile of csrc/gemm_bf16_8ph.hip; otherwise the register-staged 128 x 64 / 128 x 128 / 256 x 128 tiles. */
 typedef struct dmm_gemm_bf16_args {
   const void* A; int64_t lda;
