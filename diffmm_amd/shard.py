@@ -1,0 +1,101 @@
+"""User-sharded graph propagation: the exchange step the path needs once the graph no longer fits one GPU.
+
+Replica g owns a contiguous range of users (balanced by edges) and holds
+  * the user rows of the normalised adjacency for its users (all their items), and
+  * the item rows restricted to its users' columns,
+as ONE local CSR over `n_local = users_g + items` nodes ([own users ; all items]), with the values of the FULL graph
+(D^-1/2 from the global degrees).  Items -- embeddings, features, projections -- are replicated.  For Y = A X:
+  user rows  Y_u[U_g] = D_u X_u[U_g] + A_ui[U_g, :] X_i                  complete on the owner, no communication;
+  item rows  Y_i      = D_i X_i + sum_g A_iu[:, U_g] X_u[U_g]            one all-reduce of an [items, d] partial per SpMM
+(the item self loops are kept by exactly one replica each, so the reduced sum is the exact row).  The backward is the same
+pattern (A is symmetric).  This module is the building block -- partition, local blocks, the SpMM + exchange -- with its
+own tests (tests/test_shard.py: the blocks reassemble the full matrix; sharded == unsharded SpMM on the GPU); round 1's training
+engines still replicate the graph (diffmm_amd/dist.py), which is the faster layout while it fits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import graph
+
+
+def user_ranges(trn_rows: np.ndarray, users: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous user ranges with (nearly) equal numbers of edges: cut the cumulative degree at multiples of E / world."""
+    deg = np.bincount(np.asarray(trn_rows, dtype=np.int64), minlength=users)
+    cum = np.concatenate([[0], np.cumsum(deg)])
+    cuts = [int(np.searchsorted(cum, cum[-1] * g / world, side="left")) for g in range(world + 1)]
+    cuts[0], cuts[-1] = 0, users
+    for g in range(1, world + 1):  # ranges may be empty on tiny graphs but never overlap or go backwards
+        cuts[g] = max(cuts[g], cuts[g - 1])
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
+def local_block_csr(trn_rows: np.ndarray, trn_cols: np.ndarray, users: int, items: int, u0: int, u1: int, rank: int, world: int):
+    """CSR (rowptr int32, col int32, val fp32) of replica `rank`'s block over the local node order [users u0..u1 ; all items].
+    Values are those of graph.normalized_bipartite_csr on the FULL edge list (same fp64 products, one rounding); item i's self loop is
+    kept where i % world == rank."""
+    r = np.asarray(trn_rows, dtype=np.int64)
+    c = np.asarray(trn_cols, dtype=np.int64)
+    e = np.unique(r * items + c)  # the reference binarises duplicate interactions (DataHandler.py:83)
+    eu, ei = e // items, e % items
+    deg_u = np.bincount(eu, minlength=users) + 1  # + self loop
+    deg_i = np.bincount(ei, minlength=items) + 1
+    su, si = deg_u.astype(np.float64) ** -0.5, deg_i.astype(np.float64) ** -0.5
+    mine = (eu >= u0) & (eu < u1)
+    lu, li = eu[mine] - u0, ei[mine]
+    nu = u1 - u0
+    own_items = np.arange(items, dtype=np.int64)[np.arange(items) % world == rank]
+    # entries (row, col) in local ids: user self loops, user->item, item->user, owned item self loops
+    src = np.concatenate([np.arange(nu), lu, nu + li, nu + own_items])
+    dst = np.concatenate([np.arange(nu), nu + li, lu, nu + own_items])
+    s_src = np.concatenate([su[u0:u1], su[eu[mine]], si[li], si[own_items]])
+    s_dst = np.concatenate([su[u0:u1], si[li], su[eu[mine]], si[own_items]])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    val = ((s_src[order] * 1.0) * s_dst[order]).astype(np.float32)
+    n = nu + items
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=n), out=rowptr[1:])
+    if rowptr[-1] >= 2 ** 31:
+        raise ValueError("more than 2^31 non-zeros in one shard: use more replicas")
+    return rowptr.astype(np.int32), dst.astype(np.int32), val
+
+
+@dataclass
+class UserShard:
+    """Replica-local view of the sharded graph: `adj` is a graph.Adjacency over [own users ; all items]."""
+    rank: int
+    world: int
+    u0: int
+    u1: int
+    items: int
+    adj: graph.Adjacency
+
+    @property
+    def n_users(self) -> int:
+        return self.u1 - self.u0
+
+
+def make_user_shard(trn_rows, trn_cols, users: int, items: int, rank: int, world: int, D: int, device, task_len: int = 32) -> UserShard:
+    u0, u1 = user_ranges(trn_rows, users, world)[rank]
+    rowptr, col, val = local_block_csr(trn_rows, trn_cols, users, items, u0, u1, rank, world)
+    return UserShard(rank, world, u0, u1, items, graph.adjacency_from_csr(rowptr, col, val, D, device, task_len))
+
+
+def sharded_spmm(shard: UserShard, x_users: torch.Tensor, x_items: torch.Tensor, y: torch.Tensor, group=None, reduce: bool = True) -> torch.Tensor:
+    """y[:n_users] = rows of A X for the replica's users (complete); y[n_users:] = the item rows, all-reduced over the replicas.
+    x_users [n_users, d] is the replica's slice of the user embeddings, x_items [items, d] the replicated item table.
+    One C-ABI launch (dmm_spmm_csr_f32, the two X tensors are never concatenated) + one collective on the [items, d] view."""
+    from . import ops
+    nu = shard.n_users
+    if x_users.shape[0] != nu or x_items.shape[0] != shard.items or y.shape[0] != nu + shard.items:
+        raise ValueError("sharded_spmm: operand rows do not match the shard")
+    ops.spmm_batched([ops.SpmmOp(shard.adj, x_users, y=y, x_hi=x_items, split=nu)])
+    if reduce and shard.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(y[nu:], group=group)
+    return y
