@@ -368,7 +368,7 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   const long long t8 = (long long)cdiv(M, 256) * cdiv(N, 256) * n_batch;
   if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 64))) {
     for (int i = 0; i < n_batch; ++i) {
-      b.p[i].mt = cdiv(M, 256); b.p[i].nt = cdiv(N, 256); b.p[i].part = (force_part >= 0 ? force_part : 2) | (getenv("DMM_GEMM_BLOCKED") ? 0x100 : 0);
+      b.p[i].mt = cdiv(M, 256); b.p[i].nt = cdiv(N, 256); b.p[i].part = force_part >= 0 ? force_part : 2;
     }
     launch_gemm_bf16_8ph(b, (hipStream_t)stream);
     DMM_LAUNCH_CHECK("dmm_gemm_bf16_nt (256x256)");

@@ -217,12 +217,6 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
   E.C = P.C; E.Cb = P.Cb; E.R = P.R; E.Rb = P.Rb; E.bias = P.bias;
   E.ldc = P.ldc; E.ldcb = P.ldcb; E.ldr = P.ldr; E.ldrb = P.ldrb;
   E.M = P.M; E.N = P.N; E.act = P.act; E.alpha = P.alpha; E.e1 = P.e1; E.e2 = P.e2;
-  if ((P.part & 0x100) && E.R && E.C) {  // EXPERIMENT: fp32 state in 256 x 256 blocked layout (one contiguous 256 KiB block per tile)
-    const long long tile = (long long)(m0 >> 8) * P.nt + (n0 >> 8);
-    E.R = P.R + tile * 65536 - ((long long)m0 * 256 + n0);
-    E.C = P.C + tile * 65536 - ((long long)m0 * 256 + n0);
-    E.ldr = E.ldc = 256;
-  }
   const bool vec_ok = (!E.C || (E.ldc % 4 == 0 && ((uintptr_t)E.C & 15) == 0)) && (!E.Cb || (E.ldcb % 4 == 0 && ((uintptr_t)E.Cb & 7) == 0));
   const bool fast = vec_ok && m0 + 256 <= E.M && n0 + 256 <= E.N && !E.Rb && (!E.bias || ((uintptr_t)E.bias & 15) == 0) &&
                     (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0));
@@ -261,8 +255,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
   // of B for every row panel (row-major order: (1 + 32) panels per 32 tiles; 4 x 8 supertiles: 12).
   int mtile, ntile;
   {
-    const int bid = (P.part & 0xff) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    if ((P.part & 0xff) == 2) {
+    const int bid = P.part ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (P.part == 2) {
       const int SN = P.nt < 8 ? P.nt : 8, SM = 32 / SN > 0 ? 32 / SN : 1;
       const int band = bid / (SM * P.nt);
       const int hb = min(SM, P.mt - band * SM);

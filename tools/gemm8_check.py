@@ -51,10 +51,8 @@ def timeit(M, N, K, nb, mode, n=20):
     B = [torch.randn(N, K, device=dev).bfloat16() for _ in range(nb)]
     bias = torch.randn(N, device=dev)
     Np = (N + 63) // 64 * 64  # leading dimensions as the engine allocates them (vectorised epilogue path)
-    Mp_ = (M + 255) // 256 * 256 + (256 if os.environ.get("DMM_GEMM_BLOCKED") else 0)  # room for the blocked-layout experiment
-    Npb = (N + 255) // 256 * 256 if os.environ.get("DMM_GEMM_BLOCKED") else Np
-    R = [torch.randn(Mp_, Npb, device=dev).view(-1)[: Mp_ * Npb].view(Mp_, Npb)[:M, :N] if os.environ.get("DMM_GEMM_BLOCKED") else torch.randn(M, Np, device=dev)[:, :N] for _ in range(nb)]
-    C = [torch.empty(Mp_, Npb, device=dev)[:M, :N] if os.environ.get("DMM_GEMM_BLOCKED") else torch.empty(M, Np, device=dev)[:, :N] for _ in range(nb)]
+    R = [torch.randn(M, Np, device=dev)[:, :N] for _ in range(nb)]
+    C = [torch.empty(M, Np, device=dev)[:, :N] for _ in range(nb)]
     Cb = [torch.empty(M, Np, device=dev, dtype=torch.bfloat16)[:, :N] for _ in range(nb)]
     if mode == "tanh":
         probs = [dict(A=A[i], B=B[i], out=None, out_bf16=Cb[i], bias=bias, act=L.ACT_TANH) for i in range(nb)]
