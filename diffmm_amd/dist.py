@@ -8,7 +8,7 @@ loss.  (InfoNCE negatives stay replica-local.)
 """
 from __future__ import annotations
 
-from typing import Iterator, List, Optional, Sequence, Tuple, TypeVar
+from typing import Iterator, Optional, Sequence, Tuple, TypeVar
 
 import torch
 

@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import os
 
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -21,7 +20,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .graph import Adjacency, adjacency_from_csr, normalized_bipartite_csr
+from .graph import Adjacency
 
 Tensor = torch.Tensor
 MODAL = ("image", "text", "audio")

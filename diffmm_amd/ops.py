@@ -6,7 +6,7 @@ caller-visible HBM buffers.  No CPU path exists: non-CUDA tensors raise.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

@@ -15,7 +15,7 @@ engines still replicate the graph (diffmm_amd/dist.py), which is the faster layo
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import numpy as np
 import torch
