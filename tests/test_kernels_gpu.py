@@ -494,7 +494,8 @@ def test_eval_metrics_random(dev, k):
         assert np.allclose(out[j], ref, rtol=1e-13, atol=0), (j, out[j], ref)
 
 
-@pytest.mark.parametrize("name,D,task_len", [("toy", 8, 2), ("mid", 16, 4), ("mid", 256, 4), ("tiktok", 64, 32), ("hub", 64, 32), ("hub", 4, 8)])
+@pytest.mark.parametrize("name,D,task_len", [("toy", 8, 2), ("mid", 16, 4), ("mid", 256, 4), ("tiktok", 64, 32), ("hub", 64, 32), ("hub", 4, 8),
+                                             ("wide18000", 128, 32), ("wide20000", 64, 32)])
 def test_device_graph_builder_equals_host_builder(dev, name, D, task_len):
     """dmm_graph_build (rebuilt modality graph + SpMM work list on the device) is bit-identical to the numpy builder and planner.
     'hub': one item chosen by 6000 users -- an item row longer than the in-LDS sort (bitmap path) and giant rows in the plan."""
@@ -508,6 +509,11 @@ def test_device_graph_builder_equals_host_builder(dev, name, D, task_len):
             rest = rng.choice(np.arange(1, n_items), size=max(0, d - 1), replace=False) if d else np.zeros(0, np.int64)
             lists.append(np.sort(np.concatenate([[0], rest])) if (d and u < 6000) else np.sort(rng.choice(np.arange(1, n_items), size=d, replace=False)))
         items = np.concatenate(lists)
+    elif name.startswith("wide"):  # item counts around the LDS-histogram limit of the builder (18432): both code paths
+        users, n_items = 2500, int(name[4:])
+        deg = rng.integers(0, 9, size=users)
+        pop = 1.0 / np.arange(1, n_items + 1) ** 0.8; pop /= pop.sum()
+        items = np.concatenate([np.sort(rng.choice(n_items, size=d, replace=False, p=pop)) for d in deg if d])
     else:
         g = synth.named(name)
         users, n_items = g.users, g.items
