@@ -210,7 +210,7 @@ def main():
         replicas_identical = bool(torch.equal(lo, hi))
     if rank != 0:
         return
-    out = {"metric": "BPR+diffusion train iters/sec on TikTok d=64 T=40", "value": iters_per_epoch * args.steps / dt, "unit": "iters/s",
+    out = {"metric": "BPR+diffusion train iters/sec on TikTok d=64 T=40, at 1/2/4/8 GPUs", "value": iters_per_epoch * args.steps / dt, "unit": "iters/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
            "data": "synthetic",
