@@ -296,22 +296,53 @@ class JointEngine:
             self.P.step += 1
             for c in plan["adam"]:
                 c[1][9], c[1][13] = self.lr, self.P.step
-        L.replay(plan["calls"])
         if self.world > 1:
-            self.allreduce_grads(contributing=True, n_contrib=n_contrib)
+            # the embedding gradient is final after the last backward SpMM: its all-reduce (bucket 1) runs on a side stream under the
+            # modality projections' backward (the rest of the plan); bucket 2 (projection / mixing weights) follows on this stream.
+            if "split" not in plan:
+                last = max(i for i, c in enumerate(plan["calls"]) if c[2].startswith("dmm_spmm"))
+                plan["split"] = last + 1
+            k = plan["split"]
+            L.replay(plan["calls"][:k])
+            work = self._exchange_embedding_grads_async(n_contrib)
+            L.replay(plan["calls"][k:])
+            self._exchange_tail_grads(work, n_contrib)
             self.apply_adam(fold_extras=False)
+        else:
+            L.replay(plan["calls"])
         self.rng_step += 1
         return self.loss_parts
+
+    # -- gradient exchange between replicas: ALWAYS two collectives, bucket 1 = embedding table, bucket 2 = everything behind it -------
+    def _exchange_embedding_grads_async(self, n_contrib: Optional[int], contributing: bool = True):
+        import torch.distributed as dist
+        ne, nu = self.N * self.D, self.U * self.D
+        g = self.P.grad
+        if contributing:
+            for t in self.T:  # fold the user-row parts of the modal SpMM backward into the flat buffer first
+                ops.add_inplace(g[:nu], t.view(-1)[:nu], 1.0)
+        else:
+            g.zero_()
+        if not hasattr(self, "_comm_stream"):
+            self._comm_stream, self._comm_event = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
+        self._comm_event.record(torch.cuda.current_stream())
+        self._comm_stream.wait_event(self._comm_event)
+        with torch.cuda.stream(self._comm_stream):
+            return dist.all_reduce(g[:ne], async_op=True)
+
+    def _exchange_tail_grads(self, work, n_contrib: Optional[int]):
+        import torch.distributed as dist
+        ne = self.N * self.D
+        dist.all_reduce(self.P.grad[ne:])
+        work.wait()  # the current stream waits for bucket 1
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self.P.grad.mul_(1.0 / float(n_contrib or self.world))
 
     def allreduce_grads(self, contributing: bool, n_contrib: Optional[int] = None):
         """Data-parallel step: average the local gradients of the replicas that hold a minibatch (RCCL all-reduce on the
         flat gradient buffer).  A replica without a minibatch in this global step contributes zeros."""
-        from . import dist as D_
-        ne = self.U * self.D
-        if contributing:
-            for t in self.T:  # fold the user-row parts of the modal SpMM backward into the flat buffer first
-                ops.add_inplace(self.P.grad[:ne], t.view(-1)[:ne], 1.0)
-        D_.allreduce_mean_(self.P.grad, contributing, n_contrib or self.world)
+        work = self._exchange_embedding_grads_async(n_contrib, contributing)  # same two collectives as the overlapped path of _step_planned
+        self._exchange_tail_grads(work, n_contrib)
 
     def apply_adam(self, fold_extras: bool = True):
         P, U, D = self.P, self.U, self.D
