@@ -21,7 +21,10 @@ def _mean(rows, key, a=10, b=30):
 
 @pytest.mark.parametrize("run,ref_run", [("hip_synth_tiktok_T5_B1024_seed1818_prec1.csv", "ref_cpu_synth_tiktok_T5_B1024_seed1818.csv"),
                                          ("hip_synth_tiktok_T5_B1024_seed1818_prec3.csv", "ref_cpu_synth_tiktok_T5_B1024_seed1818.csv"),
-                                         ("hip_synth_tiktok_T5_B1024_seed7_prec1.csv", "ref_cpu_synth_tiktok_T5_B1024_seed7.csv")])
+                                         ("hip_synth_tiktok_T5_B1024_seed7_prec1.csv", "ref_cpu_synth_tiktok_T5_B1024_seed7.csv"),
+                                         # the bench configuration: T = 40, batch 4096
+                                         ("hip_synth_tiktok_T40_B4096_seed1818_prec1.csv", "ref_cpu_synth_tiktok_T40_B4096_seed1818.csv"),
+                                         ("hip_synth_tiktok_T40_B4096_seed1818_prec3.csv", "ref_cpu_synth_tiktok_T40_B4096_seed1818.csv")])
 def test_training_curve_matches_reference(run, ref_run):
     """Plateau means (epochs 10-29) against the reference's own run with the SAME seed.  RNG streams differ (torch-CPU vs Philox), so the
     comparison is statistical; for scale, the reference's two seeds differ from each other by 0.0046 in Recall@20 and 0.0011 in NDCG@20."""
