@@ -123,12 +123,33 @@ __device__ __forceinline__ void p8_st_stream(__bf16* p, const float (&v)[4]) {
 
 // Interior tiles with 16-byte aligned operands: no bounds checks, running row pointers, and the residual rows of pass p+1 are
 // requested before pass p stores (loads and stores retire in order on one counter, so a load issued behind a store waits for it).
-template <int PASS, bool HAS_R, bool HAS_C, bool HAS_CB, int ACT>
+// EDGE = false: interior tiles, no bounds checks.  EDGE = true: the same pipeline for tiles that reach past M or N -- a row predicate and,
+// per lane, the number of valid columns among its four (`nv`, constant over the passes); partial lanes fall back to scalar accesses.
+__device__ __forceinline__ float4 p8_ld_edge(const float* p, int nv) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nv > 0) r.x = p[0];
+  if (nv > 1) r.y = p[1];
+  if (nv > 2) r.z = p[2];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void p8_st_edge(T* p, const float (&v)[4], int nv) {
+  if (nv > 0) p[0] = (T)v[0];
+  if (nv > 1) p[1] = (T)v[1];
+  if (nv > 2) p[2] = (T)v[2];
+}
+
+template <int PASS, bool HAS_R, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
 __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float*& pR,
-                                             float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8]) {
+                                             float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8], int mrow, int nv) {
   if (HAS_R && PASS < 2) {  // two passes ahead: 16 KiB of residual rows in flight per wave while a pass is being stored
 #pragma unroll
-    for (int it = 0; it < 8; ++it) rnext[it] = p8_ld_stream(pR + (long long)(64 + it * 4) * E.ldr);
+    for (int it = 0; it < 8; ++it) {
+      const float* p = pR + (long long)(64 + it * 4) * E.ldr;
+      if (!EDGE) rnext[it] = p8_ld_stream(p);
+      else if (mrow + PASS * 32 + 64 + it * 4 < E.M) rnext[it] = nv == 4 ? p8_ld_stream(p) : p8_ld_edge(p, nv);
+      else rnext[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   p8_acc_to_lds<(PASS >> 1), (PASS & 1)>(acc, tile, q, fr);
 #pragma unroll
@@ -144,8 +165,18 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
       const float4 r4 = rcur[it];
       v[0] = E.e1 * v[0] + E.e2 * r4.x; v[1] = E.e1 * v[1] + E.e2 * r4.y; v[2] = E.e1 * v[2] + E.e2 * r4.z; v[3] = E.e1 * v[3] + E.e2 * r4.w;
     }
-    if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-    if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, v);
+    if (!EDGE) {
+      if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
+      if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, v);
+    } else if (mrow + PASS * 32 + it * 4 < E.M && nv > 0) {
+      if (nv == 4) {
+        if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
+        if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, v);
+      } else {
+        if (HAS_C) p8_st_edge(pC + (long long)(it * 4) * E.ldc, v, nv);
+        if (HAS_CB) p8_st_edge(pCb + (long long)(it * 4) * E.ldcb, v, nv);
+      }
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
   __builtin_amdgcn_wave_barrier();
@@ -154,27 +185,38 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
   if (HAS_CB) pCb += 32 * E.ldcb;
 }
 
-template <bool HAS_R, bool HAS_C, bool HAS_CB, int ACT>
+template <bool HAS_R, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
 __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
   float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
   const int n = n0 + wc * 64 + fr * 4;
-  const long long m = m0 + wr * 128 + q;
-  const float4 b4 = E.bias ? *reinterpret_cast<const float4*>(E.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int mrow = m0 + wr * 128 + q;
+  const long long m = mrow;
+  const int nv = EDGE ? max(0, min(4, E.N - n)) : 4;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (E.bias) b4 = nv == 4 ? *reinterpret_cast<const float4*>(E.bias + n) : p8_ld_edge(E.bias + n, nv);
   const float* pR = HAS_R ? E.R + m * E.ldr + n : nullptr;
   float* pC = HAS_C ? E.C + m * E.ldc + n : nullptr;
   __bf16* pCb = HAS_CB ? E.Cb + m * E.ldcb + n : nullptr;
   float4 ra[8], rb[8], rc[8];
   if (HAS_R) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) ra[it] = p8_ld_stream(pR + (long long)(it * 4) * E.ldr);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) rb[it] = p8_ld_stream(pR + (long long)(32 + it * 4) * E.ldr);
+    for (int it = 0; it < 8; ++it) {
+      const float* p0 = pR + (long long)(it * 4) * E.ldr;
+      const float* p1 = pR + (long long)(32 + it * 4) * E.ldr;
+      if (!EDGE) {
+        ra[it] = p8_ld_stream(p0);
+        rb[it] = p8_ld_stream(p1);
+      } else {
+        ra[it] = mrow + it * 4 < E.M ? (nv == 4 ? p8_ld_stream(p0) : p8_ld_edge(p0, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[it] = mrow + 32 + it * 4 < E.M ? (nv == 4 ? p8_ld_stream(p1) : p8_ld_edge(p1, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   }
-  p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rc);  // uses ra, requests pass 2 into rc
-  p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra);  // uses rb, requests pass 3 into ra
-  p8_fast_pass<2, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, rc, rb);
-  p8_fast_pass<3, HAS_R, HAS_C, HAS_CB, ACT>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb);
+  p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
+  p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
+  p8_fast_pass<2, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, rc, rb, mrow, nv);
+  p8_fast_pass<3, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb, mrow, nv);
 }
 
 // Edge tiles, unaligned operands and the rarely used operand combinations: bounds-checked, element-wise where needed.
@@ -218,18 +260,24 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
   E.ldc = P.ldc; E.ldcb = P.ldcb; E.ldr = P.ldr; E.ldrb = P.ldrb;
   E.M = P.M; E.N = P.N; E.act = P.act; E.alpha = P.alpha; E.e1 = P.e1; E.e2 = P.e2;
   const bool vec_ok = (!E.C || (E.ldc % 4 == 0 && ((uintptr_t)E.C & 15) == 0)) && (!E.Cb || (E.ldcb % 4 == 0 && ((uintptr_t)E.Cb & 7) == 0));
-  const bool fast = vec_ok && m0 + 256 <= E.M && n0 + 256 <= E.N && !E.Rb && (!E.bias || ((uintptr_t)E.bias & 15) == 0) &&
-                    (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0));
+  const bool fast = vec_ok && !E.Rb && (!E.bias || ((uintptr_t)E.bias & 15) == 0) && (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0));
+  const bool interior = m0 + 256 <= E.M && n0 + 256 <= E.N;
+#define P8_FAST(R_, C_, CB_, ACT_)                                                                   \
+  do {                                                                                               \
+    if (interior) p8_epilogue_fast<R_, C_, CB_, ACT_, false>(E, acc, smem, m0, n0, wave, lane);      \
+    else p8_epilogue_fast<R_, C_, CB_, ACT_, true>(E, acc, smem, m0, n0, wave, lane);                \
+  } while (0)
   if (fast && !E.R && !E.C && E.Cb && E.act == DMM_ACT_TANH) {
-    p8_epilogue_fast<false, false, true, DMM_ACT_TANH>(E, acc, smem, m0, n0, wave, lane);
+    P8_FAST(false, false, true, DMM_ACT_TANH);
   } else if (fast && !E.R && !E.C && E.Cb && E.act == DMM_ACT_NONE) {
-    p8_epilogue_fast<false, false, true, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+    P8_FAST(false, false, true, DMM_ACT_NONE);
   } else if (fast && E.R && E.C && E.Cb && E.act == DMM_ACT_NONE) {
-    p8_epilogue_fast<true, true, true, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+    P8_FAST(true, true, true, DMM_ACT_NONE);
   } else if (fast && !E.R && E.C && !E.Cb && E.act == DMM_ACT_NONE) {
-    p8_epilogue_fast<false, true, false, DMM_ACT_NONE>(E, acc, smem, m0, n0, wave, lane);
+    P8_FAST(false, true, false, DMM_ACT_NONE);
   } else if (fast && !E.R && E.C && E.Cb && E.act == DMM_ACT_TANH) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
-    p8_epilogue_fast<false, true, true, DMM_ACT_TANH>(E, acc, smem, m0, n0, wave, lane);
+    P8_FAST(false, true, true, DMM_ACT_TANH);
+#undef P8_FAST
   } else {
     float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
     p8_generic_pass<0, 0>(E, acc, tile, m0, n0, wave, lane, vec_ok);
