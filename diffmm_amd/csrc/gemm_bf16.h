@@ -31,6 +31,12 @@ struct GemmBf16Batch {
   int n;
 };
 
+// tanh for outputs that are rounded to bf16 anyway: 1 - 2 / (2^(2x log2 e) + 1), two transcendental instructions
+__device__ __forceinline__ float tanh_fast_bf16(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 

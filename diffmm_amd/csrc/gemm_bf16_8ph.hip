@@ -100,12 +100,6 @@ __device__ __forceinline__ void p8_acc_to_lds(const P8Acc& acc, float* tile, int
   __builtin_amdgcn_wave_barrier();
 }
 
-// tanh for outputs that are rounded to bf16 anyway: 1 - 2 / (2^(2x log2 e) + 1), two transcendental instructions
-__device__ __forceinline__ float p8_tanh_fast(float x) {
-  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-}
-
 // The epilogue's streams (fp32 state in and out, bf16 copy out: 640 KiB per tile, each byte touched once per launch) are marked
 // non-temporal so they do not evict the A / B panels the other CUs of the XCD are re-reading from L2.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -158,7 +152,7 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
     float v[4] = {E.alpha * a4.x + b4.x, E.alpha * a4.y + b4.y, E.alpha * a4.z + b4.z, E.alpha * a4.w + b4.w};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (ACT == DMM_ACT_TANH) v[u] = HAS_C ? tanhf(v[u]) : p8_tanh_fast(v[u]);
+      if (ACT == DMM_ACT_TANH) v[u] = HAS_C ? tanhf(v[u]) : tanh_fast_bf16(v[u]);
       else if (ACT == DMM_ACT_SIGMOID) v[u] = 1.0f / (1.0f + expf(-v[u]));
     }
     if (HAS_R) {
