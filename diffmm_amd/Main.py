@@ -84,14 +84,19 @@ class Coach:
         self.model.engine.lr = lr
         self.diff_engine.lr = lr
 
-    def run(self) -> None:
+    def run(self, resume: Optional[str] = None, save: Optional[str] = None) -> None:
         self.prepareModel()
         _log("Model Initialized")
+        if resume:
+            self.load_checkpoint(resume)
+            _log(f"Resumed from {resume} at epoch {self.epoch_idx}")
         best = dict(Recall=0.0, NDCG=0.0, Precision=0.0, epoch=0)
         his_max = [0, 0, 0]
         try:
-            for epoch in range(int(self.config.train.epoch)):
+            for epoch in range(self.epoch_idx, int(self.config.train.epoch)):
                 result = self.trainEpoch()
+                if save:
+                    self.save_checkpoint(save)
                 _log(self.makePrint("Train", epoch, result))
                 if epoch % int(self.config.train.tstEpoch) == 0:
                     result = self.testEpoch()
@@ -104,6 +109,41 @@ class Coach:
         except KeyboardInterrupt:
             _log("Training interrupted by user!")
         self.best = best
+
+    # -- checkpoint / resume (absent in the reference) ----------------------------------------------------------------
+    def _flat_models(self):
+        return [("model", self.model.engine.P)] + [(f"denoise{m}", p) for m, p in enumerate(self.diff_engine.P)]
+
+    def save_checkpoint(self, path: str) -> None:
+        """Everything the next epoch depends on: weights and Adam state of the model and of every Denoise, the step / Philox counters,
+        the sampler and loader generators, the epoch index.  Tensors and plain numbers only (loads with weights_only=True)."""
+        h, J, DE = self.handler, self.model.engine, self.diff_engine
+        sd = {"epoch_idx": int(self.epoch_idx), "rng_step_joint": int(J.rng_step), "rng_step_diffusion": int(DE.rng_step),
+              "xT_calls": int(getattr(DE, "_xT_calls", 0)),
+              "gen": {"train_loader": h.trainLoader.gen.get_state(), "diffusion_loader": h.diffusionLoader.gen.get_state(),
+                      "neg_sampler": h.trainData.gen.get_state(), "torch_cpu": torch.get_rng_state(),
+                      "torch_device": torch.cuda.get_rng_state(self.device)}}  # the timestep draws use the global device generator
+        for name, P in self._flat_models():
+            sd[name] = {"data": P.data.clone(), "m": P.m.clone(), "v": P.v.clone(), "step": int(P.step)}
+        torch.save(sd, path)
+
+    def load_checkpoint(self, path: str) -> None:
+        """Call after prepareModel() on a Coach built from the same config and data."""
+        h, J, DE = self.handler, self.model.engine, self.diff_engine
+        sd = torch.load(path, map_location=self.device, weights_only=True)
+        for name, P in self._flat_models():
+            t = sd[name]
+            if t["data"].numel() != P.data.numel():
+                raise ValueError(f"checkpoint {path}: {name} has {t['data'].numel()} parameters, this model {P.data.numel()}")
+            P.data.copy_(t["data"]); P.m.copy_(t["m"]); P.v.copy_(t["v"]); P.step = int(t["step"])
+        self.epoch_idx, J.rng_step, DE.rng_step = int(sd["epoch_idx"]), int(sd["rng_step_joint"]), int(sd["rng_step_diffusion"])
+        if sd["xT_calls"]:
+            DE._xT_calls = int(sd["xT_calls"])
+        DE.w16_step = [-1] * DE.M  # bf16 weight copies of the reverse chain are stale
+        J._plans.clear()
+        h.trainLoader.gen.set_state(sd["gen"]["train_loader"].cpu()); h.diffusionLoader.gen.set_state(sd["gen"]["diffusion_loader"].cpu())
+        h.trainData.gen.set_state(sd["gen"]["neg_sampler"].cpu())
+        torch.set_rng_state(sd["gen"]["torch_cpu"].cpu()); torch.cuda.set_rng_state(sd["gen"]["torch_device"].cpu(), self.device)
 
     def makeTorchAdj(self, u_list, i_list, edge_list=None) -> graph.Adjacency:
         cfg = self.config
@@ -245,6 +285,8 @@ def main(argv=None) -> None:
     ap = argparse.ArgumentParser(description="Model Configs")
     ap.add_argument("--config", "-c", default="conf/tiktok.toml", type=str, help="config file path")
     ap.add_argument("--precision", type=int, default=1, choices=(1, 3), help="1: bf16 MFMA GEMMs, 3: hi/lo split (~fp32)")
+    ap.add_argument("--save", default=None, help="write a checkpoint to this path after every epoch")
+    ap.add_argument("--resume", default=None, help="continue from a checkpoint written by --save")
     args = ap.parse_args(argv)
     try:
         config = load_config(args.config)
@@ -261,7 +303,7 @@ def main(argv=None) -> None:
     handler = DataHandler(config)
     main_log.info("Load Data")
     handler.LoadData()
-    Coach(handler, config, precision=args.precision).run()
+    Coach(handler, config, precision=args.precision).run(resume=args.resume, save=args.save)
 
 
 if __name__ == "__main__":
