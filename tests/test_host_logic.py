@@ -136,3 +136,17 @@ def test_adjacency_uid_is_never_reused():
         del a
         gc.collect()
     assert len(ids) < 200, "this interpreter did reuse id() values, as the docstring says"
+
+
+def test_shipped_configs_load():
+    """conf/*.toml parse with the reference's strict dataclass loader (unknown keys raise, Conf.py:68-77)."""
+    from diffmm_amd.Conf import load_config
+    for name, M in (("tiktok", 3), ("baby", 2), ("sports", 2)):
+        cfg = load_config(os.path.join(REPO, "conf", f"{name}.toml"))
+        assert cfg.data.name == name and cfg.base.latdim == 64 and cfg.hyper.steps == 5
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".toml", delete=False) as fh:
+        fh.write("[hyper]\ne_loss = 0.01\n")  # a legacy key of the reference's own baby.toml
+    with pytest.raises(TypeError):
+        load_config(fh.name)
+    os.unlink(fh.name)
