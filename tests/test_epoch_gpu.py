@@ -161,3 +161,26 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
     for ea, eb in zip([a.image_adj, a.text_adj, a.audio_adj], [b.image_adj, b.text_adj, b.audio_adj]):
         same = float((ea.col == eb.col).float().mean())
         assert same > 0.99, f"rebuilt graphs agree on {same:.4f} of their entries"
+
+
+@pytest.mark.parametrize("fx", ["epoch_mid", "epoch_mid_M2"])
+def test_first_epoch_in_bf16_mode_tracks_the_reference(fx):
+    """The benchmark's arithmetic (precision 1: bf16 MFMA operands, fp32 accumulation) on the reference's own first epoch -- same
+    graph, weights, batches and draws: losses within 1 %, and the rebuilt modality graphs keep >= 97 % of the reference's edges
+    (the top-k of a bf16 reverse chain: near-ties at the k-th score flip)."""
+    need_gpu()
+    z = load(fx + ".npz")
+    coach, h, M = _coach(z)
+    coach.precision = 1
+    h.trainData.set_negs(z["ep0/negs"])
+    res = coach.trainEpoch(draws=_Draws(z))
+    for k, v in res.items():
+        ref = float(z[f"ep0/train/{k}"])
+        assert abs(v - ref) <= 1e-2 * abs(ref) + 1e-6, f"{k}: {v} vs reference {ref}"
+    for m, adj in enumerate([coach.image_adj, coach.text_adj] + ([coach.audio_adj] if M == 3 else [])):
+        rp, col = adj.rowptr.cpu().numpy(), adj.col.cpu().numpy()
+        row = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+        ref = set(zip(z[f"ep0/adj{m}_row"].tolist(), z[f"ep0/adj{m}_col"].tolist()))
+        inter = len(ref & set(zip(row.tolist(), col.tolist()))) / max(1, len(ref))
+        print(f"{fx} modality {m}: {inter:.4f} of the reference's rebuilt edges")
+        assert inter >= 0.97, f"modality {m}: only {inter:.4f} of the rebuilt edges agree"
