@@ -91,7 +91,9 @@ def roofline(coach, args):
     flops2 = 2.0 * rows * nb * H * I * (3 if args.precision == 3 else 1)
     A = J.adj
     emb = J.P.view("emb")
-    ts = timed_launches(lambda: ops.spmm_batched([ops.SpmmOp(A, emb, y=J.Bx)]), 50)
+    with L.Recorder() as spmm_plan:  # pre-marshalled launch, like the engines' steady state: the timed loop is kernel time, not Python
+        ops.spmm_batched([ops.SpmmOp(A, emb, y=J.Bx)])
+    ts = timed_launches(lambda: L.replay(spmm_plan), 200)
     sb = A.algorithmic_bytes(4)
     gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_8ph_kernel (256x256 LDS-DMA tile): Denoise layer 1 of the reverse chain, {nb} modalities x ({rows} x {Kp}) x ({H} x {Kp})^T per launch", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
             "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6,
