@@ -170,6 +170,8 @@ def check_plan(rowptr: np.ndarray, tasks: np.ndarray, D: int) -> None:
 
 
 _adjacency_uid = itertools.count(1)
+TASK_LEN = int(__import__("os").environ.get("DMM_TASK_LEN", "16"))  # non-zeros per SpMM task (DMM_TASK_LEN: tuning knob).  At TikTok size the joint
+# iteration takes 15.9 / 15.8 / 16.0 / 16.5 / 16.9 ms per epoch at 8 / 12 / 16 / 24 / 32: shorter tasks = more waves to hide the gather latency
 
 
 @dataclass
@@ -209,13 +211,13 @@ class Adjacency:
         return self.nnz * 8 + (self.n + 1) * 4 + 2 * self.n * self.D * elem_bytes
 
 
-def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = 32,
+def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
                    keep_host: bool = False) -> Adjacency:
     rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)
     return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host)
 
 
-def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = 32, keep_host: bool = False) -> Adjacency:
+def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = TASK_LEN, keep_host: bool = False) -> Adjacency:
     plan = plan_tasks(rowptr, D, task_len, full=True)
     tasks, head = plan.tasks, plan.head
     check_plan(rowptr, tasks, D)
@@ -239,7 +241,7 @@ class DeviceGraphBuilder:
     are user u's items, distinct and ascending.  Bit-identical to `make_adjacency` on the same edges (tests/test_host_logic.py);
     the only host read-back is the 32-byte size record."""
 
-    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = 32):
+    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = TASK_LEN):
         import ctypes as C
         from . import _lib as L
         self.U, self.I, self.N, self.D, self.task_len = users, items, users + items, D, task_len
