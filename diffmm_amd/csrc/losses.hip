@@ -5,6 +5,8 @@
 // InfoNCE never materialises the B x B logit matrix: one wave owns one anchor row, keeps its own normalised
 // row in LDS, streams the other view's rows out of L2 and folds them into an online log-sum-exp (forward) or
 // into a probability row held in LDS (backward).  [v1: fp32 VALU dot products; the MFMA tiling is the next step.]
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmm {
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
   const dmm_infonce_term term = T.t[t];
   const int own_slot = pass == 0 ? term.a : term.b, oth_slot = pass == 0 ? term.b : term.a;
   const int tiles = pk.Bp >> 5;
-  const int per = (tiles + INFONCE_KSPLIT - 1) / INFONCE_KSPLIT;
+  const int ksplit = gridDim.z >> 1;
+  const int per = (tiles + ksplit - 1) / ksplit;
   const int kt0 = slice * per, kt1 = min(tiles, kt0 + per);
   if (kt0 >= kt1) return;
   bf16x8 own_h[D / 16], own_l[D / 16];
@@ -602,7 +605,9 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
   if (bf16_pack && precision != 0 && mfma_ok(D)) {
     DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_bwd: precision must be 0 (fp32 VALU), 1 or 3");
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
-    DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2 * INFONCE_KSPLIT), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
+    static const int ks_env = [] { const char* e = getenv("DMM_INFONCE_KSPLIT"); return e ? atoi(e) : 0; }();  // tuning knob
+    const int ksplit = ks_env > 0 ? ks_env : INFONCE_KSPLIT;
+    DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2 * ksplit), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
     DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma)");
     return 0;
   }
