@@ -148,7 +148,7 @@ class JointEngine:
     # -- forward of gcn_MM (+ optionally the 3 perturbed CL layers) ---------------------------------
     def _project(self, precision: int):
         names = modality_names(self.M)
-        for m, n in enumerate(names):
+        for m, n in enumerate(names):  # (K split of this GEMM measured: no gain)
             ops.gemm(self.feats[m], self.P.view(f"{n}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{n}_layer.bias"),
                      precision=precision)
             ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
@@ -253,7 +253,7 @@ class JointEngine:
             ops.rownorm_bwd(self.T[m][U:], self.nf[m], self.fnorm[m], self.dfeat[m])
             gw = self.P.g(f"{n}_layer.weight")
             ops.zero_(gw)
-            ops.gemm(self.dfeat[m], self.feats[m], out=gw, trans_a=True, precision=precision, split_k=64)  # 64 x F output: K = I is the parallel axis
+            ops.gemm(self.dfeat[m], self.feats[m], out=gw, trans_a=True, precision=precision, split_k=128)  # 64 x F output: K = I is the parallel axis (32 / 64 / 128 / 256 measured)
             ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"))
         if update:
             if self.world > 1:
