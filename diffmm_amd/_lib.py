@@ -23,7 +23,8 @@ class SpmmProblem(C.Structure):
                 ("y", C.c_void_p), ("c1", C.c_void_p), ("c2", C.c_void_p), ("y_pert", C.c_void_p), ("noise", C.c_void_p),
                 ("y_mean", C.c_void_p), ("m1", C.c_void_p), ("m2", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("partial", C.c_void_p), ("fix", C.c_void_p), ("n_partial_blocks", C.c_int32), ("n_fix", C.c_int32), ("n_rows", C.c_int32), ("n_tasks", C.c_int32), ("n_head_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
-                ("noise_degree", C.c_float)]
+                ("noise_degree", C.c_float), ("raw", C.c_void_p), ("raw_from", C.c_int32), ("rng_row_split", C.c_int32), ("rng_row_add_lo", C.c_int32),
+                ("rng_row_add_hi", C.c_int32)]
 
 
 class GemmArgs(C.Structure):
@@ -56,6 +57,7 @@ _SIGS = {
     "dmm_last_error_string": (C.c_char_p, []),
     "dmm_spmm_tasks_per_block": (C.c_int, [_I]),
     "dmm_spmm_csr_f32": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
+    "dmm_spmm_epilogue_rows": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
     "dmm_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
     "dmm_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmBf16Args), _P]),
     "dmm_gemm_bf16_nt_batched": (C.c_int, [C.POINTER(GemmBf16Args), _I, _P]),
@@ -67,12 +69,16 @@ _SIGS = {
     "dmm_gcn_mix_fwd": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _L, _P]),
     "dmm_gcn_mix_partials": (C.c_int64, [_L]),
     "dmm_gcn_mix_bwd": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _I, _F, _P, _L, _P]),
+    "dmm_gcn_mix_bwd_counted": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _I, _F, _P, _L, _L, _L, _L, _P]),
     "dmm_infonce_pack_bytes": (C.c_int64, [_I, _I, _I]),
     "dmm_gather_normalize": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_infonce_fwd": (C.c_int, [_P, _P, _I, _I, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P]),
     "dmm_infonce_bwd": (C.c_int, [_P, _P, _I, _I, _P, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P]),
     "dmm_scatter_normalize_bwd": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_bpr_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "dmm_bpr_fwd_bwd_tables": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "dmm_gather_rows": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P]),
+    "dmm_scatter_add_rows": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P]),
     "dmm_segment_sum": (C.c_int, [_P, _I, _L, _F, _P, _P]),
     "dmm_sumsq_scratch": (C.c_int64, [_L]),
     "dmm_sumsq": (C.c_int, [_P, _L, _F, _P, _P, _P]),
@@ -92,6 +98,8 @@ _SIGS = {
     "dmm_graph_build_scratch_bytes": (C.c_int, [_I, _I, _L, _I, _P]),
     "dmm_graph_build_task_capacity": (C.c_int, [_I, _I, _L, _I, _I, _P, _P]),
     "dmm_graph_build": (C.c_int, [_P, _P, _P, _I, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dmm_count_items": (C.c_int, [_P, _L, _I, _P, _P]),
+    "dmm_graph_build_shard": (C.c_int, [_P, _P, _P, _I, _I, _L, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmm_eval_topk": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P]),
     "dmm_eval_metrics": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "dmm_fill_zero": (C.c_int, [_P, _L, _P]),
@@ -157,6 +165,15 @@ class Recorder:
         global _recording
         _recording = None
         return False
+
+
+def call_py(fn, *args) -> None:
+    """Run (or, inside `Recorder`, record) a host-side step of a launch sequence -- a torch.distributed collective between two
+    kernel launches.  Recorded entries are replayed in order with the C calls (fn must return None / 0)."""
+    if _recording is not None:
+        _recording.append([fn, list(args), "py:" + getattr(fn, "__name__", "fn")])
+        return
+    fn(*args)
 
 
 def replay(plan) -> None:

@@ -2,15 +2,12 @@
 // All are HBM/L2-bandwidth kernels: 16-byte accesses per lane, grid-stride, <= 2048 workgroups.
 #include <stdarg.h>
 
-#include <mutex>
-
 #include "common.h"
 
 namespace dmm {
-static std::mutex g_err_mu;
-static char g_err[512] = "";
+// last-error text of the CALLING thread (errno-style): the library keeps no mutable state shared between host threads
+static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
-  std::lock_guard<std::mutex> lk(g_err_mu);
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -107,7 +104,8 @@ __global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dmx, const float* __restrict__ bx, MixPtrs P,
                                                        const float* __restrict__ extra, float* __restrict__ dbx,
                                                        const float* __restrict__ logits, int M, float maw,
-                                                       float* __restrict__ partials, int64_t n4) {
+                                                       float* __restrict__ partials, int64_t n4, int64_t cnt0_end, int64_t cnt1_begin,
+                                                       int64_t cnt1_end) {
   __shared__ float sm4[4];
   float w[3];
   softmax3(logits, M, w);
@@ -124,7 +122,9 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ 
     reinterpret_cast<float4*>(dbx)[i] = o;
     for (int m = 0; m < M; ++m) {
       const float4 z = reinterpret_cast<const float4*>(P.z[m])[i];
-      acc[m] += g.x * (b.x + maw * z.x) + g.y * (b.y + maw * z.y) + g.z * (b.z + maw * z.z) + g.w * (b.w + maw * z.w);
+      // user-sharded layout: a replica counts its own users and its slice of the replicated item rows towards d(logits)
+      if (i < cnt0_end || (i >= cnt1_begin && i < cnt1_end))
+        acc[m] += g.x * (b.x + maw * z.x) + g.y * (b.y + maw * z.y) + g.z * (b.z + maw * z.z) + g.w * (b.w + maw * z.w);
       float4 d = reinterpret_cast<float4*>(P.dz[m])[i];
       const float c = maw * w[m];
       d.x += c * g.x; d.y += c * g.y; d.z += c * g.z; d.w += c * g.w;
@@ -302,15 +302,23 @@ extern "C" int64_t dmm_gcn_mix_partials(int64_t n) { return (int64_t)grid_for(n 
 extern "C" int dmm_gcn_mix_bwd(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
                                float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
                                void* stream) {
+  return dmm_gcn_mix_bwd_counted(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, n, n, n, stream);
+}
+extern "C" int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
+                                       float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
+                                       int64_t count0_end, int64_t count1_begin, int64_t count1_end, void* stream) {
   DMM_CHECK_ARG(dmx && bx && z && dz && dbx && w_logits && dw_logits && partials && (M == 2 || M == 3) && n % 4 == 0,
                 "dmm_gcn_mix_bwd: bad arguments");
+  DMM_CHECK_ARG(count0_end % 4 == 0 && count1_begin % 4 == 0 && count1_end % 4 == 0 && 0 <= count0_end && count0_end <= n && count1_begin <= count1_end && count1_end <= n,
+                "dmm_gcn_mix_bwd_counted: counted ranges must be multiples of 4 inside [0, n]");
   MixPtrs P = {};
   for (int m = 0; m < M; ++m) {
     P.z[m] = z[m];
     P.dz[m] = dz[m];
   }
   const unsigned grid = grid_for(n / 4, 256);
-  hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, w_logits, M, maw, partials, n / 4);
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, w_logits, M, maw, partials, n / 4,
+                     count0_end / 4, count1_begin / 4, count1_end / 4);
   hipLaunchKernelGGL(mix_bwd_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)grid, w_logits, M, dw_logits);
   DMM_LAUNCH_CHECK("dmm_gcn_mix_bwd");
   return 0;

@@ -24,11 +24,15 @@ constexpr int GB_SORT_CAP = 256;  // item-row entries ranked by counting in LDS 
 
 struct GbShape {
   int U, I, N, E, G, logG, task_len, seg_len, nch;  // nch = 1 + (logG + 2) + 1
+  // user-sharded block: U = the replica's own users, item i keeps its self loop here iff i % self_mod == self_rank, and the
+  // item degrees that scale the values are the GLOBAL ones (`gdeg`, summed over the replicas), not the local row lengths (`cnt`)
+  int self_mod, self_rank;
 };
+__device__ __forceinline__ int gb_own(const GbShape& S, int it) { return (it % S.self_mod) == S.self_rank ? 1 : 0; }
 
 // meta (device, int32[8]): 0 n_tasks, 1 n_head_tasks, 2 n_partial_blocks, 3 n_fix, 4 nnz
 __device__ __forceinline__ int gb_row_len(const GbShape& S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ cnt, int r) {
-  return (r < S.U ? user_ptr[r + 1] - user_ptr[r] : cnt[r - S.U]) + 1;
+  return r < S.U ? user_ptr[r + 1] - user_ptr[r] + 1 : cnt[r - S.U] + gb_own(S, r - S.U);
 }
 
 // class of a row and the number of task slots it reserves: 0 = giant (nseg * G), 1 .. logG = split rows with run size G .. 2,
@@ -256,11 +260,12 @@ __device__ __forceinline__ float gb_val(const double* __restrict__ dinv, int len
 
 __global__ __launch_bounds__(256) void gb_fill(GbShape S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ edge_user,
                                                const int32_t* __restrict__ item, const int32_t* __restrict__ cnt, const int32_t* __restrict__ rowptr,
-                                               const double* __restrict__ dinv, int32_t* __restrict__ fill, int32_t* __restrict__ col, float* __restrict__ val) {
+                                               const double* __restrict__ dinv, int32_t* __restrict__ fill, int32_t* __restrict__ col, float* __restrict__ val,
+                                               const int32_t* __restrict__ gdeg) {
   const int stride = gridDim.x * 256;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < S.E; e += stride) {
     const int u = edge_user[e], it = item[e];
-    const int lu = user_ptr[u + 1] - user_ptr[u] + 1, li = cnt[it] + 1;
+    const int lu = user_ptr[u + 1] - user_ptr[u] + 1, li = gdeg[it] + 1;
     const int p = rowptr[u] + 1 + (e - user_ptr[u]);  // a user's items keep their (ascending) top-k order, after the self loop
     col[p] = S.U + it;
     val[p] = gb_val(dinv, lu, li);
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256) void gb_fill(GbShape S, const int32_t* __restr
 __global__ __launch_bounds__(256) void gb_fill_lds(GbShape S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ edge_user,
                                                    const int32_t* __restrict__ item, const int32_t* __restrict__ cnt, const int32_t* __restrict__ rowptr,
                                                    const double* __restrict__ dinv, int32_t* __restrict__ fill, int32_t* __restrict__ col,
-                                                   float* __restrict__ val) {
+                                                   float* __restrict__ val, const int32_t* __restrict__ gdeg) {
   extern __shared__ int gb_h[];  // [I] local counts, then [I] bases
   int* hb = gb_h + S.I;
   for (int b = threadIdx.x; b < S.I; b += 256) gb_h[b] = 0;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void gb_fill_lds(GbShape S, const int32_t* __r
     const int e = e0 + q * 256 + threadIdx.x;
     if (e < e1) {
       const int u = edge_user[e], it = item[e];
-      const int lu = user_ptr[u + 1] - user_ptr[u] + 1, li = cnt[it] + 1;
+      const int lu = user_ptr[u + 1] - user_ptr[u] + 1, li = gdeg[it] + 1;
       const int p = rowptr[u] + 1 + (e - user_ptr[u]);
       col[p] = S.U + it;
       val[p] = gb_val(dinv, lu, li);
@@ -322,12 +327,13 @@ __global__ __launch_bounds__(256) void gb_fill_lds(GbShape S, const int32_t* __r
 // permutation.  Rows longer than GB_SORT_CAP take the bitmap path (one U-bit map per workgroup in `bitmaps`).
 __global__ __launch_bounds__(256) void gb_finish_item_rows(GbShape S, const int32_t* __restrict__ user_ptr, const int32_t* __restrict__ cnt,
                                                            const int32_t* __restrict__ rowptr, const double* __restrict__ dinv,
-                                                           int32_t* __restrict__ col, float* __restrict__ val, uint32_t* __restrict__ bitmaps, int long_rows) {
+                                                           int32_t* __restrict__ col, float* __restrict__ val, uint32_t* __restrict__ bitmaps, int long_rows,
+                                                           const int32_t* __restrict__ gdeg) {
   __shared__ int ent[GB_SORT_CAP];
   __shared__ int wsum[257];
   const int words = (S.U + 31) >> 5;
   for (int it = blockIdx.x; it < S.I; it += gridDim.x) {
-    const int L = cnt[it], rp = rowptr[S.U + it], li = L + 1;
+    const int L = cnt[it], rp = rowptr[S.U + it], li = gdeg[it] + 1;
     if ((L > GB_SORT_CAP) != (long_rows != 0)) continue;
     if (!long_rows) {
       for (int i = threadIdx.x; i < L; i += 256) ent[i] = col[rp + i];
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void gb_finish_item_rows(GbShape S, const int3
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && gb_own(S, it)) {
       col[rp + L] = S.U + it;
       val[rp + L] = gb_val(dinv, li, li);
     }
@@ -389,6 +395,7 @@ static int gb_shape(GbShape& S, int U, int I, int64_t E, int D, int task_len) {
   DMM_CHECK_ARG(D >= 4 && D <= 512 && 1024 % D == 0 && D % 4 == 0, "dmm_graph_build: D=%d unsupported (1024 %% D == 0, D %% 4 == 0)", D);
   DMM_CHECK_ARG(2 * E + U + I < (int64_t)0x7fffffff, "dmm_graph_build: nnz does not fit 32-bit indices");
   S.U = U; S.I = I; S.N = U + I; S.E = (int)E; S.G = 1024 / D; S.task_len = task_len;
+  S.self_mod = 1; S.self_rank = 0;
   S.logG = 0;
   while ((1 << S.logG) < S.G) ++S.logG;
   DMM_CHECK_ARG((1 << S.logG) == S.G, "dmm_graph_build: 1024 / D must be a power of two");
@@ -422,8 +429,35 @@ extern "C" int dmm_graph_build_task_capacity(int U, int I, int64_t E, int D, int
 extern "C" int dmm_graph_build(const int32_t* user_ptr, const int32_t* edge_user, const int32_t* item_idx, int U, int I, int64_t E, int D, int task_len,
                                const double* dinv_table, int32_t* rowptr, int32_t* col, float* val, void* tasks, void* fix, int32_t* meta,
                                void* scratch, void* stream) {
+  return dmm_graph_build_shard(user_ptr, edge_user, item_idx, U, I, E, D, task_len, dinv_table, nullptr, 1, 0, rowptr, col, val, tasks, fix, meta, scratch,
+                               stream);
+}
+
+extern "C" int dmm_count_items(const int32_t* item_idx, int64_t E, int I, int32_t* count, void* stream) {
+  DMM_CHECK_ARG(count && I > 0 && E >= 0 && E < (int64_t)0x7fffffff && (item_idx || E == 0), "dmm_count_items: bad arguments");
+  if (E == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (I <= GB_LDS_ITEMS) {
+    static bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gb_count_items_lds), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_ITEMS * 4);
+      return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(gb_count_items_lds, dim3((unsigned)((E + GB_CHUNK - 1) / GB_CHUNK)), dim3(256), (size_t)I * 4, s, item_idx, (int)E, I, count);
+  } else {
+    hipLaunchKernelGGL(gb_count_items, dim3((unsigned)std::min<int64_t>(4096, (E + 255) / 256)), dim3(256), 0, s, item_idx, (int)E, I, count);
+  }
+  DMM_LAUNCH_CHECK("dmm_count_items");
+  return 0;
+}
+
+extern "C" int dmm_graph_build_shard(const int32_t* user_ptr, const int32_t* edge_user, const int32_t* item_idx, int U, int I, int64_t E, int D,
+                                     int task_len, const double* dinv_table, const int32_t* item_count_global, int self_mod, int self_rank,
+                                     int32_t* rowptr, int32_t* col, float* val, void* tasks, void* fix, int32_t* meta, void* scratch, void* stream) {
   GbShape S;
   if (int rc = gb_shape(S, U, I, E, D, task_len)) return rc;
+  DMM_CHECK_ARG(self_mod >= 1 && self_rank >= 0 && self_rank < self_mod, "dmm_graph_build_shard: need 0 <= self_rank < self_mod");
+  S.self_mod = self_mod; S.self_rank = self_rank;
   DMM_CHECK_ARG(user_ptr && edge_user && (item_idx || E == 0) && dinv_table && rowptr && col && val && tasks && fix && meta && scratch,
                 "dmm_graph_build: null operand");
   hipStream_t s = (hipStream_t)stream;
@@ -433,6 +467,7 @@ extern "C" int dmm_graph_build(const int32_t* user_ptr, const int32_t* edge_user
   int32_t* blocksum = fill + I;
   int32_t* base = blocksum + (size_t)GB_MAXCH * nb;
   uint32_t* bitmaps = (uint32_t*)(base + GB_MAXCH);
+  const int32_t* gdeg = item_count_global ? item_count_global : cnt;  // unsharded: the local counts ARE the degrees
   if (hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * (size_t)I, s) != hipSuccess) {
     set_error("dmm_graph_build: hipMemsetAsync failed");
     return 2;
@@ -454,14 +489,14 @@ extern "C" int dmm_graph_build(const int32_t* user_ptr, const int32_t* edge_user
                      rowptr, (int4*)tasks, (int4*)fix);
   if (lds_path)
     hipLaunchKernelGGL(gb_fill_lds, dim3(cg), dim3(256), (size_t)I * 8, s, S, user_ptr, edge_user, item_idx, (const int32_t*)cnt, (const int32_t*)rowptr,
-                       dinv_table, fill, col, val);
+                       dinv_table, fill, col, val, gdeg);
   else
     hipLaunchKernelGGL(gb_fill, dim3(eg), dim3(256), 0, s, S, user_ptr, edge_user, item_idx, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table, fill,
-                       col, val);
+                       col, val, gdeg);
   hipLaunchKernelGGL(gb_finish_item_rows, dim3(std::min(I, 65535)), dim3(256), 0, s, S, user_ptr, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table,
-                     col, val, bitmaps, 0);
+                     col, val, bitmaps, 0, gdeg);
   hipLaunchKernelGGL(gb_finish_item_rows, dim3(GB_LONG_GROUPS), dim3(256), 0, s, S, user_ptr, (const int32_t*)cnt, (const int32_t*)rowptr, dinv_table, col,
-                     val, bitmaps, 1);
+                     val, bitmaps, 1, gdeg);
   DMM_LAUNCH_CHECK("dmm_graph_build");
   return 0;
 }

@@ -113,6 +113,31 @@ __global__ __launch_bounds__(256) void scatter_normalize_bwd_kernel(SlotTable S,
 }
 
 // ---------------------------------------------------------------------------------------------
+// User-sharded batch exchange: a replica owns the user rows of the batch positions [seg[0], seg[1]) only.
+//   gather_rows:       out[s][b] = src_s[idx_s[b]]            for b in the segment (the rest of `out` stays as the caller left it: zero,
+//                                                             so that a sum all-reduce over the replicas assembles the batch table)
+//   scatter_add_rows:  grad_s[idx_s[b]] += in[s][b]           for b in the segment (fp32 atomics: a user may repeat inside a batch)
+// seg is read on the device (the launch plan stays static while the segment moves from step to step); seg == NULL: all of [0, B).
+// ---------------------------------------------------------------------------------------------
+template <int D, bool SCATTER>
+__global__ __launch_bounds__(256) void rows_move_kernel(SlotTable S, int B, const int32_t* __restrict__ seg, float* __restrict__ buf) {
+  constexpr int LANES = D / 4, G = 256 / LANES;
+  const int s = blockIdx.y, l = threadIdx.x % LANES;
+  const int b0 = seg ? max(0, seg[0]) : 0, b1 = seg ? min(B, seg[1]) : B;
+  const int32_t* __restrict__ idx = S.idx[s];
+  for (int b = b0 + blockIdx.x * G + threadIdx.x / LANES; b < b1; b += gridDim.x * G) {
+    float* t = buf + ((size_t)s * B + b) * D + 4 * l;
+    if (SCATTER) {
+      float* dst = S.grad[s] + (size_t)idx[b] * D + 4 * l;
+      const float4 v = *reinterpret_cast<const float4*>(t);
+      atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+    } else {
+      *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(S.src[s] + (size_t)idx[b] * D + 4 * l);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // InfoNCE forward: one wave per anchor row.
 // ---------------------------------------------------------------------------------------------
 __global__ void infonce_fwd_kernel(const float* __restrict__ zhat, TermTable T, int B, int D, float* __restrict__ lse,
@@ -445,30 +470,32 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
 // ---------------------------------------------------------------------------------------------
 // BPR forward + backward
 // ---------------------------------------------------------------------------------------------
+// user rows come from fin_u (indexed by users[b]), item rows from fin_i (indexed by pos[b] / neg[b]): one [U + I, D] table in the
+// unsharded engine, the exchanged batch table + the replicated item rows in the user-sharded one
 template <int D>
-__global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ fin, const int32_t* __restrict__ users,
-                                                   const int32_t* __restrict__ pos, const int32_t* __restrict__ neg, int B, int U,
-                                                   float* __restrict__ row_loss, float* __restrict__ dfin) {
+__global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ fin_u, const float* __restrict__ fin_i, const int32_t* __restrict__ users,
+                                                   const int32_t* __restrict__ pos, const int32_t* __restrict__ neg, int B,
+                                                   float* __restrict__ row_loss, float* __restrict__ dfin_u, float* __restrict__ dfin_i) {
   constexpr int LANES = D / 4, G = 256 / LANES;
   const int l = threadIdx.x % LANES;
   const float invB = 1.0f / (float)B;
   for (int b = blockIdx.x * G + threadIdx.x / LANES; b < B; b += gridDim.x * G) {
-    const size_t ou = (size_t)users[b] * D + 4 * l, op = (size_t)(U + pos[b]) * D + 4 * l, on = (size_t)(U + neg[b]) * D + 4 * l;
-    const float4 u = *reinterpret_cast<const float4*>(fin + ou);
-    const float4 p = *reinterpret_cast<const float4*>(fin + op);
-    const float4 n = *reinterpret_cast<const float4*>(fin + on);
+    const size_t ou = (size_t)users[b] * D + 4 * l, op = (size_t)pos[b] * D + 4 * l, on = (size_t)neg[b] * D + 4 * l;
+    const float4 u = *reinterpret_cast<const float4*>(fin_u + ou);
+    const float4 p = *reinterpret_cast<const float4*>(fin_i + op);
+    const float4 n = *reinterpret_cast<const float4*>(fin_i + on);
     const float sp = group_sum<LANES>(u.x * p.x + u.y * p.y + u.z * p.z + u.w * p.w);
     const float sn = group_sum<LANES>(u.x * n.x + u.y * n.y + u.z * n.z + u.w * n.w);
     const float sg = 1.0f / (1.0f + expf(-(sp - sn)));
     if (l == 0) row_loss[b] = -logf(1e-5f + sg) * invB;
-    if (dfin) {
+    if (dfin_u) {
       const float g = -(sg * (1.0f - sg)) / (1e-5f + sg) * invB;  // d row_loss / d (sp - sn)
-      atomicAdd(dfin + ou + 0, g * (p.x - n.x)); atomicAdd(dfin + ou + 1, g * (p.y - n.y));
-      atomicAdd(dfin + ou + 2, g * (p.z - n.z)); atomicAdd(dfin + ou + 3, g * (p.w - n.w));
-      atomicAdd(dfin + op + 0, g * u.x); atomicAdd(dfin + op + 1, g * u.y);
-      atomicAdd(dfin + op + 2, g * u.z); atomicAdd(dfin + op + 3, g * u.w);
-      atomicAdd(dfin + on + 0, -g * u.x); atomicAdd(dfin + on + 1, -g * u.y);
-      atomicAdd(dfin + on + 2, -g * u.z); atomicAdd(dfin + on + 3, -g * u.w);
+      atomicAdd(dfin_u + ou + 0, g * (p.x - n.x)); atomicAdd(dfin_u + ou + 1, g * (p.y - n.y));
+      atomicAdd(dfin_u + ou + 2, g * (p.z - n.z)); atomicAdd(dfin_u + ou + 3, g * (p.w - n.w));
+      atomicAdd(dfin_i + op + 0, g * u.x); atomicAdd(dfin_i + op + 1, g * u.y);
+      atomicAdd(dfin_i + op + 2, g * u.z); atomicAdd(dfin_i + op + 3, g * u.w);
+      atomicAdd(dfin_i + on + 0, -g * u.x); atomicAdd(dfin_i + on + 1, -g * u.y);
+      atomicAdd(dfin_i + on + 2, -g * u.z); atomicAdd(dfin_i + on + 3, -g * u.w);
     }
   }
 }
@@ -619,12 +646,40 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
   return 0;
 }
 
-extern "C" int dmm_bpr_fwd_bwd(const float* fin, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D, int U,
-                               float* row_loss, float* dfin, void* stream) {
-  DMM_CHECK_ARG(fin && users && pos && neg && row_loss && B > 0 && d_ok(D), "dmm_bpr_fwd_bwd: bad arguments");
+extern "C" int dmm_bpr_fwd_bwd_tables(const float* fin_u, const float* fin_i, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D,
+                                      float* row_loss, float* dfin_u, float* dfin_i, void* stream) {
+  DMM_CHECK_ARG(fin_u && fin_i && users && pos && neg && row_loss && B > 0 && d_ok(D), "dmm_bpr_fwd_bwd: bad arguments");
+  DMM_CHECK_ARG((dfin_u == nullptr) == (dfin_i == nullptr), "dmm_bpr_fwd_bwd: give both gradient tables or none");
   const int G = 1024 / D;
   const unsigned grid = cdiv(B, G) > 1024 ? 1024 : cdiv(B, G);
-  DISPATCH_D(D, hipLaunchKernelGGL(bpr_kernel<DD>, dim3(grid), dim3(256), 0, (hipStream_t)stream, fin, users, pos, neg, B, U, row_loss, dfin));
+  DISPATCH_D(D, hipLaunchKernelGGL(bpr_kernel<DD>, dim3(grid), dim3(256), 0, (hipStream_t)stream, fin_u, fin_i, users, pos, neg, B, row_loss, dfin_u, dfin_i));
   DMM_LAUNCH_CHECK("dmm_bpr_fwd_bwd");
   return 0;
+}
+extern "C" int dmm_bpr_fwd_bwd(const float* fin, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D, int U,
+                               float* row_loss, float* dfin, void* stream) {
+  DMM_CHECK_ARG(fin && U >= 0, "dmm_bpr_fwd_bwd: bad arguments");
+  return dmm_bpr_fwd_bwd_tables(fin, fin + (size_t)U * D, users, pos, neg, B, D, row_loss, dfin, dfin ? dfin + (size_t)U * D : nullptr, stream);
+}
+
+static int rows_move(bool scatter, const dmm_gather_desc* slots, int n_slots, int B, int D, const int32_t* seg, float* buf, void* stream) {
+  SlotTable S;
+  if (int e = fill_slots(slots, n_slots, S)) return e;
+  DMM_CHECK_ARG(buf && B > 0 && d_ok(D), "dmm_gather_rows / dmm_scatter_add_rows: bad arguments (B=%d D=%d)", B, D);
+  for (int i = 0; i < n_slots; ++i) DMM_CHECK_ARG(!scatter || S.grad[i], "dmm_scatter_add_rows: slot %d has no grad table", i);
+  const int G = 1024 / D;
+  dim3 grid(cdiv(B, G) > 1024 ? 1024 : cdiv(B, G), n_slots);
+  if (scatter) {
+    DISPATCH_D(D, hipLaunchKernelGGL((rows_move_kernel<DD, true>), grid, dim3(256), 0, (hipStream_t)stream, S, B, seg, buf));
+  } else {
+    DISPATCH_D(D, hipLaunchKernelGGL((rows_move_kernel<DD, false>), grid, dim3(256), 0, (hipStream_t)stream, S, B, seg, buf));
+  }
+  DMM_LAUNCH_CHECK("dmm_gather_rows / dmm_scatter_add_rows");
+  return 0;
+}
+extern "C" int dmm_gather_rows(const dmm_gather_desc* slots, int n_slots, int B, int D, const int32_t* seg, float* out, void* stream) {
+  return rows_move(false, slots, n_slots, B, D, seg, out, stream);
+}
+extern "C" int dmm_scatter_add_rows(const dmm_gather_desc* slots, int n_slots, int B, int D, const int32_t* seg, const float* in, void* stream) {
+  return rows_move(true, slots, n_slots, B, D, seg, const_cast<float*>(in), stream);
 }

@@ -22,6 +22,8 @@
 //   y_mean = (y_pert + m1[row] + m2[row]) / 3                             (Main.py:325, mean of the 3 CL layers)
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace dmm {
@@ -52,7 +54,9 @@ __device__ __forceinline__ void spmm_epilogue(const dmm_spmm_problem& P, int row
     if (P.noise) {
       n = *reinterpret_cast<const float4*>(P.noise + off);
     } else {
-      const uint4 r = philox4(P.seed, P.offset + (unsigned long long)row * LANES + l, 0x5eedu);
+      // the counter uses the row's GLOBAL id, so a user-sharded replica draws exactly what the unsharded launch draws for that row
+      const unsigned long long grow = (unsigned long long)(row + (row < P.rng_row_split ? P.rng_row_add_lo : P.rng_row_add_hi));
+      const uint4 r = philox4(P.seed, P.offset + grow * LANES + l, 0x5eedu);
       n = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
     }
     float ss = n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w;
@@ -68,6 +72,30 @@ __device__ __forceinline__ void spmm_epilogue(const dmm_spmm_problem& P, int row
       *reinterpret_cast<float4*>(P.y_mean + off) =
           make_float4((yp.x + a.x + b.x) * t, (yp.y + a.y + b.y) * t, (yp.z + a.z + b.z) * t, (yp.w + a.w + b.w) * t);
     }
+  }
+}
+
+// User-sharded layout: rows >= raw_from (the replicated item rows) are only PARTIAL sums on a replica -- the kernel parks the
+// raw accumulator in `raw` ([n_rows - raw_from, D]); after the replicas' partials are summed (one all-reduce per launch),
+// spmm_epilogue_rows_kernel applies the epilogue to those rows.
+template <int D>
+__device__ __forceinline__ void spmm_finish(const dmm_spmm_problem& P, int row, int l, float4 acc) {
+  if (P.raw && row >= P.raw_from) {
+    *reinterpret_cast<float4*>(P.raw + (size_t)(row - P.raw_from) * D + 4 * l) = acc;
+    return;
+  }
+  spmm_epilogue<D>(P, row, l, acc);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void spmm_epilogue_rows_kernel(const SpmmBatch batch) {
+  constexpr int LANES = D / 4, G = 256 / LANES;
+  const dmm_spmm_problem& P = batch.p[blockIdx.y];
+  if (!P.raw) return;
+  const int l = threadIdx.x % LANES;
+  for (int row = P.raw_from + blockIdx.x * G + threadIdx.x / LANES; row < P.n_rows; row += gridDim.x * G) {
+    const float4 acc = *reinterpret_cast<const float4*>(P.raw + (size_t)(row - P.raw_from) * D + 4 * l);
+    spmm_epilogue<D>(P, row, l, acc);
   }
 }
 
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
     *reinterpret_cast<float4*>(P.partial + (size_t)lb * D + 4 * l) = acc;
     return;
   }
-  spmm_epilogue<D>(P, row, l, acc);
+  spmm_finish<D>(P, row, l, acc);
 }
 
 // Rows longer than one workgroup's worth of tasks are cut into segments (one workgroup each, planned first in the task list).
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) 
     const float4 o = *reinterpret_cast<const float4*>(P.partial + (size_t)(f.y + sidx) * D + 4 * l);
     acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
   }
-  spmm_epilogue<D>(P, f.x, l, acc);
+  spmm_finish<D>(P, f.x, l, acc);
 }
 
 template <int D>
@@ -187,37 +215,41 @@ extern "C" int dmm_spmm_tasks_per_block(int D) {
   return 1024 / D;
 }
 
-extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int D, void* stream) {
-  DMM_CHECK_ARG(probs && n_probs >= 1 && n_probs <= DMM_SPMM_MAX_BATCH, "dmm_spmm_csr_f32: n_probs must be 1..%d", DMM_SPMM_MAX_BATCH);
+static int spmm_fill_batch(const char* who, const dmm_spmm_problem* probs, int n_probs, int D, dmm::SpmmBatch& b, int& blocks) {
+  DMM_CHECK_ARG(probs && n_probs >= 1 && n_probs <= DMM_SPMM_MAX_BATCH, "%s: n_probs must be 1..%d", who, DMM_SPMM_MAX_BATCH);
   const int G = dmm_spmm_tasks_per_block(D);
-  DMM_CHECK_ARG(G > 0, "dmm_spmm_csr_f32: D=%d unsupported (8,16,32,64,128,256)", D);
-  dmm::SpmmBatch b;
+  DMM_CHECK_ARG(G > 0, "%s: D=%d unsupported (8,16,32,64,128,256)", who, D);
   memset(&b, 0, sizeof(b));
   b.n = n_probs;
-  {
-    // XCD-contiguous placement of the single-task tail is opt-in (DMM_SPMM_REMAP=1): measured neutral on the 4 MB TikTok operand
-    // (X sits in every XCD's L2 + the Infinity Cache) and 20-30 % SLOWER on a 1M-user shard (contiguous slices of the row-sorted
-    // task list give the XCDs unequal work: user rows are short, item rows long), so the dispatcher's round-robin order is kept.
-    const char* e = getenv("DMM_SPMM_REMAP");
-    b.remap = e ? (e[0] == '1') : 0;
-  }
-  int blocks = 0;
+  // XCD-contiguous placement of the single-task tail is opt-in (DMM_SPMM_REMAP=1, read once): measured neutral on the 4 MB TikTok operand
+  // (X sits in every XCD's L2 + the Infinity Cache) and 20-30 % SLOWER on a 1M-user shard (contiguous slices of the row-sorted
+  // task list give the XCDs unequal work: user rows are short, item rows long), so the dispatcher's round-robin order is kept.
+  static const int remap_env = [] { const char* e = getenv("DMM_SPMM_REMAP"); return e ? (e[0] == '1') : 0; }();
+  b.remap = remap_env;
+  blocks = 0;
   for (int i = 0; i < n_probs; ++i) {
     const dmm_spmm_problem& p = probs[i];
-    DMM_CHECK_ARG(p.tasks && p.col && p.val && p.x_lo, "dmm_spmm_csr_f32: problem %d has a null operand", i);
-    DMM_CHECK_ARG(p.n_tasks > 0 && p.n_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: n_tasks=%d is not a multiple of %d", i, p.n_tasks, G);
-    DMM_CHECK_ARG(p.n_head_tasks >= 0 && p.n_head_tasks <= p.n_tasks && p.n_head_tasks % G == 0, "dmm_spmm_csr_f32: problem %d: bad n_head_tasks", i);
-    DMM_CHECK_ARG(p.y || p.y_pert, "dmm_spmm_csr_f32: problem %d has no output", i);
-    DMM_CHECK_ARG(p.n_partial_blocks >= 0 && p.n_partial_blocks * G <= p.n_head_tasks && p.n_fix >= 0, "dmm_spmm_csr_f32: problem %d: bad giant-row fields", i);
-    DMM_CHECK_ARG(p.n_partial_blocks == 0 || (p.partial && p.fix && p.n_fix > 0), "dmm_spmm_csr_f32: problem %d: giant rows need partial + fix buffers", i);
-    DMM_CHECK_ARG(!p.y_mean || (p.y_pert && p.m1 && p.m2), "dmm_spmm_csr_f32: problem %d: y_mean needs y_pert, m1, m2", i);
-    DMM_CHECK_ARG(p.x_hi || p.split >= (1 << 30), "dmm_spmm_csr_f32: problem %d: x_hi missing", i);
+    DMM_CHECK_ARG(p.tasks && p.col && p.val && p.x_lo, "%s: problem %d has a null operand", who, i);
+    DMM_CHECK_ARG(p.n_tasks > 0 && p.n_tasks % G == 0, "%s: problem %d: n_tasks=%d is not a multiple of %d", who, i, p.n_tasks, G);
+    DMM_CHECK_ARG(p.n_head_tasks >= 0 && p.n_head_tasks <= p.n_tasks && p.n_head_tasks % G == 0, "%s: problem %d: bad n_head_tasks", who, i);
+    DMM_CHECK_ARG(p.y || p.y_pert, "%s: problem %d has no output", who, i);
+    DMM_CHECK_ARG(p.n_partial_blocks >= 0 && p.n_partial_blocks * G <= p.n_head_tasks && p.n_fix >= 0, "%s: problem %d: bad giant-row fields", who, i);
+    DMM_CHECK_ARG(p.n_partial_blocks == 0 || (p.partial && p.fix && p.n_fix > 0), "%s: problem %d: giant rows need partial + fix buffers", who, i);
+    DMM_CHECK_ARG(!p.y_mean || (p.y_pert && p.m1 && p.m2), "%s: problem %d: y_mean needs y_pert, m1, m2", who, i);
+    DMM_CHECK_ARG(p.x_hi || p.split >= (1 << 30), "%s: problem %d: x_hi missing", who, i);
+    DMM_CHECK_ARG(!p.raw || (p.raw_from >= 0 && p.raw_from <= p.n_rows && p.n_rows > 0), "%s: problem %d: raw rows need 0 <= raw_from <= n_rows", who, i);
     b.p[i] = p;
     b.block_begin[i] = blocks;
     blocks += p.n_tasks / G;
   }
   for (int i = n_probs; i <= DMM_SPMM_MAX_BATCH; ++i) b.block_begin[i] = blocks;
+  return 0;
+}
 
+extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int D, void* stream) {
+  dmm::SpmmBatch b;
+  int blocks = 0;
+  if (int rc = spmm_fill_batch("dmm_spmm_csr_f32", probs, n_probs, D, b, blocks)) return rc;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
     case 8: return dmm::launch<8>(b, blocks, s);
@@ -228,4 +260,30 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
     case 256: return dmm::launch<256>(b, blocks, s);
   }
   return DMM_ERR_INVALID_ARG;
+}
+
+// Second half of a user-sharded SpMM: the epilogue of the rows >= raw_from (the replicated item rows), run after the replicas'
+// raw partial rows in `raw` have been summed.  Problems without `raw` are skipped.
+extern "C" int dmm_spmm_epilogue_rows(const dmm_spmm_problem* probs, int n_probs, int D, void* stream) {
+  dmm::SpmmBatch b;
+  int blocks = 0;
+  if (int rc = spmm_fill_batch("dmm_spmm_epilogue_rows", probs, n_probs, D, b, blocks)) return rc;
+  int rows = 0;
+  for (int i = 0; i < n_probs; ++i)
+    if (probs[i].raw) rows = std::max(rows, probs[i].n_rows - probs[i].raw_from);
+  if (rows == 0) return 0;
+  const int G = 1024 / D;
+  const dim3 grid(std::min<unsigned>(dmm::cdiv(rows, G), 2048u), n_probs);
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 8: hipLaunchKernelGGL(dmm::spmm_epilogue_rows_kernel<8>, grid, dim3(256), 0, s, b); break;
+    case 16: hipLaunchKernelGGL(dmm::spmm_epilogue_rows_kernel<16>, grid, dim3(256), 0, s, b); break;
+    case 32: hipLaunchKernelGGL(dmm::spmm_epilogue_rows_kernel<32>, grid, dim3(256), 0, s, b); break;
+    case 64: hipLaunchKernelGGL(dmm::spmm_epilogue_rows_kernel<64>, grid, dim3(256), 0, s, b); break;
+    case 128: hipLaunchKernelGGL(dmm::spmm_epilogue_rows_kernel<128>, grid, dim3(256), 0, s, b); break;
+    case 256: hipLaunchKernelGGL(dmm::spmm_epilogue_rows_kernel<256>, grid, dim3(256), 0, s, b); break;
+    default: return DMM_ERR_INVALID_ARG;
+  }
+  DMM_LAUNCH_CHECK("dmm_spmm_epilogue_rows");
+  return 0;
 }

@@ -37,7 +37,10 @@ class SpmmOp:
     def __init__(self, adj: Adjacency, x_lo: Tensor, y: Optional[Tensor] = None, x_hi: Optional[Tensor] = None, split: Optional[int] = None,
                  alpha: float = 1.0, c1: Optional[Tensor] = None, beta: float = 0.0, c2: Optional[Tensor] = None, gamma: float = 0.0,
                  y_pert: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_degree: float = 0.0, seed: int = 0, offset: int = 0,
-                 y_mean: Optional[Tensor] = None, m1: Optional[Tensor] = None, m2: Optional[Tensor] = None, partial: Optional[Tensor] = None):
+                 y_mean: Optional[Tensor] = None, m1: Optional[Tensor] = None, m2: Optional[Tensor] = None, partial: Optional[Tensor] = None,
+                 raw: Optional[Tensor] = None, raw_from: int = 0, rng_rows: Optional[tuple] = None):
+        """raw / raw_from: user-sharded launch -- rows >= raw_from park their raw partial sums in raw [n - raw_from, D] (all-reduce it over
+        the replicas, then spmm_epilogue_rows finishes those rows).  rng_rows = (split, add_lo, add_hi): global row ids of the Philox draws."""
         D = adj.D
         n = adj.n
         if x_hi is None:
@@ -69,6 +72,14 @@ class SpmmOp:
         self.adj = adj
         p.n_tasks = adj.n_tasks
         p.n_head_tasks = adj.n_head_tasks
+        if raw is not None:
+            _f32c(raw, "raw")
+            if not 0 <= raw_from <= n or tuple(raw.shape) != (n - raw_from, D):
+                raise ValueError(f"SpMM raw must be [{n - raw_from}, {D}], got {tuple(raw.shape)}")
+            p.raw, p.raw_from = L.ptr(raw), raw_from
+            self.keep += (raw,)
+        if rng_rows is not None:
+            p.rng_row_split, p.rng_row_add_lo, p.rng_row_add_hi = (int(v) for v in rng_rows)
         self.p, self.D = p, D
 
 
@@ -85,6 +96,11 @@ def spmm_batched(ops: Sequence[SpmmOp]):
     arr = (L.SpmmProblem * len(ops))(*[o.p for o in ops])
     L.call("dmm_spmm_csr_f32", arr, len(ops), D, L.stream())
     return arr  # the launch's argument block (plans patch the Philox offsets in place)
+
+
+def spmm_epilogue_rows(arr, n: int, D: int) -> None:
+    """Second half of a user-sharded SpMM launch (`arr` = what spmm_batched returned): epilogue of the raw rows after their all-reduce."""
+    L.call("dmm_spmm_epilogue_rows", arr, n, D, L.stream())
 
 
 def spmm(adj: Adjacency, x: Tensor, y: Optional[Tensor] = None, **kw) -> Tensor:
@@ -242,14 +258,16 @@ def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, m
 
 
 def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tensor], dbx_extra: Optional[Tensor], w_logits: Tensor, maw: float,
-                dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None):
+                dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None, count: Optional[tuple] = None):
+    """count = (end0, begin1, end1) in elements: only [0, end0) and [begin1, end1) enter dw (user-sharded replicas); None = everything."""
     n = dmx.numel()
     dbx = torch.empty_like(dmx) if dbx is None else dbx
     dw = torch.empty(len(z), dtype=torch.float32, device=dmx.device) if dw is None else dw
     if partials is None:
         partials = torch.empty(int(L.lib().dmm_gcn_mix_partials(n)), dtype=torch.float32, device=dmx.device)
-    L.call("dmm_gcn_mix_bwd", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
-                                    L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, L.stream())
+    c = (n, n, n) if count is None else tuple(int(v) for v in count)
+    L.call("dmm_gcn_mix_bwd_counted", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
+           L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, c[0], c[1], c[2], L.stream())
     return dbx, dw
 
 
@@ -302,6 +320,24 @@ def bpr_fwd_bwd(fin: Tensor, users: Tensor, pos: Tensor, neg: Tensor, U: int, ro
     B, D = users.shape[0], fin.shape[1]
     L.call("dmm_bpr_fwd_bwd", L.ptr(_f32c(fin, "fin")), L.ptr(_i32c(users, "users")), L.ptr(_i32c(pos, "pos")), L.ptr(_i32c(neg, "neg")),
                                     B, D, U, L.ptr(row_loss), L.ptr(dfin), L.stream())
+
+
+def bpr_fwd_bwd_tables(fin_u: Tensor, fin_i: Tensor, users: Tensor, pos: Tensor, neg: Tensor, row_loss: Tensor, dfin_u: Optional[Tensor],
+                       dfin_i: Optional[Tensor]) -> None:
+    """BPR with the user rows and the item rows in two tables (users index fin_u, pos / neg index fin_i)."""
+    B, D = users.shape[0], fin_u.shape[1]
+    L.call("dmm_bpr_fwd_bwd_tables", L.ptr(_f32c(fin_u, "fin_u")), L.ptr(_f32c(fin_i, "fin_i")), L.ptr(_i32c(users, "users")), L.ptr(_i32c(pos, "pos")),
+           L.ptr(_i32c(neg, "neg")), B, D, L.ptr(row_loss), L.ptr(dfin_u), L.ptr(dfin_i), L.stream())
+
+
+def gather_rows(slots: "Slots", B: int, D: int, seg: Optional[Tensor], out: Tensor) -> None:
+    """out[s][b] = slots[s].src[idx[b]] for b in [seg[0], seg[1]) (seg: device int32[2]; None = every b)."""
+    L.call("dmm_gather_rows", slots.arr, slots.n, B, D, L.ptr(seg), L.ptr(_f32c(out, "out")), L.stream())
+
+
+def scatter_add_rows(slots: "Slots", B: int, D: int, seg: Optional[Tensor], src: Tensor) -> None:
+    """slots[s].grad[idx[b]] += src[s][b] for b in [seg[0], seg[1])."""
+    L.call("dmm_scatter_add_rows", slots.arr, slots.n, B, D, L.ptr(seg), L.ptr(_f32c(src, "src")), L.stream())
 
 
 def segment_sum(x: Tensor, n_seg: int, seg_len: int, scale: float, out: Tensor) -> None:

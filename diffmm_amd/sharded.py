@@ -1,0 +1,422 @@
+"""User-sharded training engines (BASELINE.json north_star: "DataHandler shards users across the 8 GPUs ... gradient
+all-reduce on RCCL over xGMI overlapped with the backward SpMM").  The reference is single-process; the call sites that get
+sharded are the SpMMs of Model.py:90,93,105,111,114,123,130 and Main.py:319, the minibatch gathers of Main.py:305-307 and the
+per-user loops of Main.py:145-253.
+
+Layout.  Replica g owns a contiguous user range [u0, u1) (balanced by edges, shard.user_ranges): the rows u_embs[u0:u1], their
+Adam state, the user rows of every adjacency and the matching columns of the item rows, as ONE local CSR over the node order
+[own users ; all items].  Items -- i_embs, features, projections, modal_weight -- are replicated and stay bit-identical: every
+replicated parameter only ever receives all-reduced gradients.
+
+One joint step (same arithmetic, same number of optimiser steps as the single-GPU engine; the minibatch is the reference's
+B shuffled interactions, every replica holds the user rows of the triples whose user it owns):
+  * every SpMM launch  = local dmm_spmm_csr_f32 (own user rows finished in place, item rows parked raw) -> ONE all-reduce of the
+    [problems, I, d] raw item partials -> dmm_spmm_epilogue_rows (scale / residual / perturbation / mean on the summed item rows);
+    forward and backward alike (A is symmetric), 6 launches per step;
+  * the minibatch: each replica gathers its segment of the B user rows of the 3 + M user-side views (dmm_gather_rows), ONE all-reduce
+    assembles the [views, B, d] batch table everywhere; InfoNCE (global in-batch negatives, exactly the reference's B x B logits) and
+    BPR then run on every replica against the replicated item rows -- their item-row gradients are complete without communication,
+    the user-row gradients of the own segment are scattered back (dmm_scatter_add_rows);
+  * replicated-parameter gradients: i_embs = item rows of the last backward SpMM (already all-reduced); each replica runs the
+    modality projections' backward on ITS slice of the items and counts its own users + that slice towards d(modal_weight);
+    ONE all-reduce of the small tail of the flat gradient buffer sums them;
+  * Adam: own user rows + replicated rows, identical on every replica.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import graph, ops, shard
+from .engine import FlatParams, modality_names
+
+Tensor = torch.Tensor
+
+
+# ======================================================================================================
+@dataclass
+class ShardLayout:
+    """Who owns what: contiguous user ranges balanced by edges; a contiguous slice of the (replicated) items per replica for the
+    work that is split rather than repeated (projection backward, d(modal_weight))."""
+    world: int
+    rank: int
+    users: int
+    items: int
+    cuts: np.ndarray  # int64 [world + 1]: replica g owns users cuts[g] .. cuts[g+1]
+
+    @staticmethod
+    def make(trn_rows: np.ndarray, users: int, items: int, world: int, rank: int) -> "ShardLayout":
+        r = shard.user_ranges(trn_rows, users, world)
+        cuts = np.asarray([a for a, _ in r] + [r[-1][1]], dtype=np.int64)
+        return ShardLayout(world, rank, users, items, cuts)
+
+    @property
+    def u0(self) -> int:
+        return int(self.cuts[self.rank])
+
+    @property
+    def u1(self) -> int:
+        return int(self.cuts[self.rank + 1])
+
+    @property
+    def nu(self) -> int:
+        return self.u1 - self.u0
+
+    @property
+    def n_local(self) -> int:
+        return self.nu + self.items
+
+    def item_slice(self, rank: Optional[int] = None):
+        g = self.rank if rank is None else rank
+        return (self.items * g) // self.world, (self.items * (g + 1)) // self.world
+
+    def owner_of(self, users: Tensor) -> Tensor:
+        """Replica that owns each user id (device op)."""
+        inner = torch.as_tensor(self.cuts[1:-1], device=users.device, dtype=users.dtype)
+        return torch.bucketize(users, inner, right=True)
+
+    def owner_of_np(self, users: np.ndarray) -> np.ndarray:
+        return np.searchsorted(self.cuts[1:-1], users, side="right")
+
+    def local_rows(self, full: Tensor) -> Tensor:
+        """[N, d] node tensor -> this replica's [own users ; all items] rows."""
+        return torch.cat([full[self.u0:self.u1], full[self.users:]], dim=0).contiguous()
+
+
+def sort_batch_by_owner(layout: ShardLayout, users: Tensor, pos: Tensor, neg: Tensor):
+    """Stable reorder of one minibatch so that every replica's triples are contiguous (all replicas compute the same order from the same
+    batch).  Returns (users, pos, neg, bounds) with bounds int32 [world + 1]: replica g owns positions bounds[g] .. bounds[g+1]."""
+    owner = layout.owner_of(users.long())
+    order = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=layout.world)
+    bounds = torch.zeros(layout.world + 1, dtype=torch.int32, device=users.device)
+    bounds[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return users[order].contiguous(), pos[order].contiguous(), neg[order].contiguous(), bounds
+
+
+def _all_reduce(t: Tensor, group=None) -> None:
+    import torch.distributed as dist
+    dist.all_reduce(t, group=group)
+
+
+# ======================================================================================================
+class ShardedJointEngine:
+    """JointEngine (engine.py) on the user-sharded layout.  world == 1 runs the same code without communication."""
+
+    def __init__(self, layout: ShardLayout, D: int, feats: Sequence[Tensor], hp: dict, device, B_max: int, group=None):
+        self.layout, self.group = layout, group
+        self.world, self.rank = layout.world, layout.rank
+        self.U, self.I, self.N = layout.users, layout.items, layout.users + layout.items  # global sizes
+        self.nu, self.n = layout.nu, layout.n_local
+        self.D, self.M = D, len(feats)
+        self.hp = dict(hp)
+        self.dev = torch.device(device)
+        self.feats = [f.to(self.dev, torch.float32).contiguous() for f in feats]
+        names = modality_names(self.M)
+        shapes = [("emb", (self.n, D))]
+        for nm, f in zip(names, self.feats):
+            shapes += [(f"{nm}_layer.weight", (D, f.shape[1])), (f"{nm}_layer.bias", (D,))]
+        shapes += [("modal_weight", (self.M,))]
+        self.P = FlatParams(shapes, self.dev)
+        n, M, I = self.n, self.M, self.I
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+        self.feat = [z(I, D) for _ in range(M)]
+        self.nf = [z(I, D) for _ in range(M)]
+        self.fnorm = [z(I) for _ in range(M)]
+        self.Z = [z(n, D) for _ in range(M)]
+        self.Bx, self.X1p, self.Mx, self.Fin, self.X2p, self.X3p, self.CL1 = (z(n, D) for _ in range(7))
+        self.gblock = z(M + 3, n, D)
+        self.dFin, self.dCl1, self.dCl2 = self.gblock[0], self.gblock[1], self.gblock[2]
+        self.dZ = [self.gblock[3 + m] for m in range(M)]
+        self.dMx, self.dX2p, self.dX1p, self.dBx = (z(n, D) for _ in range(4))
+        self.T = [z(n, D) for _ in range(M)]
+        self.dfeat = [z(I, D) for _ in range(M)]
+        self.mix_partials = z(int(L.lib().dmm_gcn_mix_partials(n * D)))
+        self.sumsq_scratch = z(int(L.lib().dmm_sumsq_scratch(n * D)))
+        self.xraw = z(L.SPMM_MAX_BATCH, I, D)  # raw item partials of one SpMM launch: the all-reduce buffer
+        self.B_max = B_max
+        self.n_slots = 2 + 2 * M + 4
+        self.n_uslots = self.n_slots // 2
+        self.ub, self.dub = z(self.n_uslots, B_max, D), z(self.n_uslots, B_max, D)  # batch table of the user-side views and its gradient
+        self.zhat, self.znorm, self.dzhat = z(self.n_slots, B_max, D), z(self.n_slots, B_max), z(self.n_slots, B_max, D)
+        self.mfma_cl = D in (32, 64, 128, 256)
+        self.pack = ops.infonce_pack(self.n_slots, B_max, D, self.dev) if self.mfma_cl else None
+        pairs = M * (M - 1) // 2
+        self.n_terms = 2 + (2 * pairs if self.hp["cl_method"] == 1 else 2 * M)
+        self.lse = z(self.n_terms, B_max)
+        self.row_loss = z(self.n_terms + 1, B_max)
+        self.loss_parts = z(self.n_terms + 3)  # per-term InfoNCE, bpr, reg over the own users (a partial sum), reg over the items
+        self.lr = float(hp["lr"])
+        self.adj: Optional[graph.Adjacency] = None
+        self.modal_adj: List[graph.Adjacency] = []
+        self.rng_step = 0
+        zi = lambda k: torch.zeros(k, dtype=torch.int32, device=self.dev)
+        # static index buffers of the recorded launch plans: users as LOCAL row ids (valid inside the own segment), items global
+        self.users_s, self.pos_s, self.neg_s, self.seg_s = zi(B_max), zi(B_max), zi(B_max), zi(2)
+        self.arange = torch.arange(B_max, dtype=torch.int32, device=self.dev)
+        self._plans: Dict[tuple, dict] = {}
+        self._philox_refs: Optional[list] = None
+
+    # -- parameters ------------------------------------------------------------------------------------
+    @property
+    def u_embs(self) -> Tensor:
+        return self.P.view("emb")[: self.nu]
+
+    @property
+    def i_embs(self) -> Tensor:
+        return self.P.view("emb")[self.nu:]
+
+    def load_reference_state(self, sd: Dict[str, Tensor]):
+        """`sd` holds the FULL model (as the reference names it); the replica keeps its own user rows."""
+        t = {k: torch.as_tensor(v) for k, v in sd.items()}
+        u = t.pop("u_embs")[self.layout.u0:self.layout.u1]
+        t["emb"] = torch.cat([u, t.pop("i_embs")], dim=0)
+        self.P.load(t)
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        """Local view: u_embs are the replica's OWN rows (users u0..u1)."""
+        sd = self.P.state_dict()
+        emb = sd.pop("emb")
+        sd["u_embs"], sd["i_embs"] = emb[: self.nu].clone(), emb[self.nu:].clone()
+        return sd
+
+    def set_adjacency(self, adj: graph.Adjacency, modal_adj: Sequence[graph.Adjacency]):
+        assert adj.n == self.n and adj.D == self.D and len(modal_adj) == self.M and all(a.n == self.n for a in modal_adj)
+        self.adj, self.modal_adj = adj, list(modal_adj)
+        live = (adj.uid, tuple(a.uid for a in self.modal_adj))
+        for k in [k for k in self._plans if (k[2], k[3]) != live]:
+            del self._plans[k]
+
+    # -- one SpMM launch on the sharded layout -------------------------------------------------------------
+    def _ar(self, t: Tensor):
+        if self.world > 1:
+            L.call_py(_all_reduce, t, self.group)
+
+    def _spmm(self, batch: List[dict]):
+        """batch: SpmmOp keyword dicts (with adj, x_lo).  Local launch -> all-reduce of the raw item partials -> item-row epilogue."""
+        k = len(batch)
+        opl = [ops.SpmmOp(raw=self.xraw[i], raw_from=self.nu, **b) for i, b in enumerate(batch)]
+        arr = ops.spmm_batched(opl)
+        self._ar(self.xraw[:k])
+        ops.spmm_epilogue_rows(arr, k, self.D)
+        return arr
+
+    def _rng(self, k: int, noise) -> dict:
+        lanes = self.D // 4
+        if noise is not None:
+            return dict(noise=noise[k])
+        seed, base = self.hp.get("seed", 1818), self.rng_step * 3 * self.N * lanes
+        return dict(noise=None, seed=seed, offset=base + k * self.N * lanes, rng_rows=(self.nu, self.layout.u0, self.U - self.nu))
+
+    # -- forward of gcn_MM (+ the 3 perturbed CL layers) ---------------------------------------------------
+    def _project(self, precision: int):
+        for m, nm in enumerate(modality_names(self.M)):  # replicated: every replica needs all normalised item features as SpMM operand
+            ops.gemm(self.feats[m], self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
+                     precision=precision)
+            ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
+
+    def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3):
+        """noise (parity tests): 3 tensors already in the LOCAL row order [own users ; items]."""
+        hp, A, emb = self.hp, self.adj, self.P.view("emb")
+        nd = hp["noise_degree"]
+        self._project(precision)
+        refs = self._philox_refs
+        batch = [dict(adj=self.modal_adj[m], x_lo=self.u_embs, y=self.Z[m], x_hi=self.nf[m], split=self.nu) for m in range(self.M)]
+        if with_cl:
+            batch.append(dict(adj=A, x_lo=emb, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **self._rng(0, noise)))
+        else:
+            batch.append(dict(adj=A, x_lo=emb, y=self.Bx))
+        arr = self._spmm(batch)
+        if refs is not None and with_cl:
+            refs.append((arr, len(batch) - 1, 0))
+        ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx)
+        s = 1.0 + hp["residual_weight"]
+        batch = [dict(adj=A, x_lo=self.Mx, y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
+        if with_cl:
+            batch.append(dict(adj=A, x_lo=self.X1p, y_pert=self.X2p, noise_degree=nd, **self._rng(1, noise)))
+        arr = self._spmm(batch)
+        if refs is not None and with_cl:
+            refs.append((arr, 1, 1))
+        if with_cl:
+            arr = self._spmm([dict(adj=A, x_lo=self.X2p, y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **self._rng(2, noise))])
+            if refs is not None:
+                refs.append((arr, 0, 2))
+
+    def gcn_output(self) -> Dict[str, Tensor]:
+        nu = self.nu
+        out = {"u_final_embs": self.Fin[:nu], "i_final_embs": self.Fin[nu:]}
+        for m, nm in enumerate(modality_names(self.M)):
+            out[f"u_{nm}_embs"], out[f"i_{nm}_embs"] = self.Z[m][:nu], self.Z[m][nu:]
+        return out
+
+    # -- one optimiser step ------------------------------------------------------------------------------
+    def _views(self):
+        """(user-side source, user-side gradient, item-side source, item-side gradient) of every contrasted view, in JointEngine's slot order."""
+        nu = self.nu
+        v = [(self.Fin, self.dFin)] + [(self.Z[m], self.dZ[m]) for m in range(self.M)] + [(self.CL1, self.dCl1), (self.X1p, self.dCl2)]
+        return [(s[:nu], g[:nu], s[nu:], g[nu:]) for s, g in v]
+
+    def _terms(self):
+        M, hp = self.M, self.hp
+        c = 2 + 2 * M
+        terms = [(c, c + 2, hp["cross_cl_temp"], hp["cross_cl_rate"]), (c + 1, c + 3, hp["cross_cl_temp"], hp["cross_cl_rate"])]
+        tm, rm = hp["modal_cl_temp"], hp["modal_cl_rate"]
+        if hp["cl_method"] == 1:
+            for a in range(M):
+                for b in range(a + 1, M):
+                    terms += [(2 + 2 * a, 2 + 2 * b, tm, rm), (3 + 2 * a, 3 + 2 * b, tm, rm)]
+        else:
+            for m in range(M):
+                terms += [(0, 2 + 2 * m, tm, rm), (1, 3 + 2 * m, tm, rm)]
+        assert len(terms) == self.n_terms
+        return ops.make_terms(terms)
+
+    def set_batch(self, users: Tensor, pos: Tensor, neg: Tensor, bounds: Optional[Tensor] = None):
+        """Install one minibatch (global user / item ids).  Without `bounds` the batch is first sorted by owner (sort_batch_by_owner)."""
+        if bounds is None:
+            users, pos, neg, bounds = sort_batch_by_owner(self.layout, users, pos, neg)
+        B = int(users.shape[0])
+        assert B <= self.B_max
+        self.users_s[:B].copy_(users.to(torch.int32) - self.layout.u0)  # local ids; only the own segment is ever dereferenced
+        self.pos_s[:B].copy_(pos)
+        self.neg_s[:B].copy_(neg)
+        self.seg_s.copy_(bounds[self.rank:self.rank + 2])
+        return B
+
+    def step(self, users: Tensor, pos: Tensor, neg: Tensor, noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True,
+             bounds: Optional[Tensor] = None) -> Tensor:
+        """Forward + backward (+ Adam) of one minibatch of GLOBAL (user, pos, neg) ids -- the same call on every replica.
+        Returns loss_parts = [InfoNCE terms..., bpr, reg(own users), reg(items)] (device tensor; no host synchronisation)."""
+        B = self.set_batch(users, pos, neg, bounds)
+        if noise is None and update:
+            return self._step_planned(B, precision)
+        return self._step_body(B, noise, precision, update)
+
+    def _step_body(self, B: int, noise, precision: int, update: bool) -> Tensor:
+        D, nu, M, hp, I = self.D, self.nu, self.M, self.hp, self.I
+        nS, nU, nT = self.n_slots, self.n_uslots, self.n_terms
+        cview = lambda t, lead, *rest: t.view(-1)[: lead * B * int(np.prod(rest) if rest else 1)].view(lead, B, *rest)
+        zhat, dzhat, znorm = cview(self.zhat, nS, D), cview(self.dzhat, nS, D), cview(self.znorm, nS)
+        ub, dub = cview(self.ub, nU, D), cview(self.dub, nU, D)
+        lse, row_loss = cview(self.lse, nT), cview(self.row_loss, nT + 1)
+        users, pos, neg, ar = self.users_s[:B], self.pos_s[:B], self.neg_s[:B], self.arange[:B]
+        ops.zero_(self.gblock)
+        ops.zero_(dzhat)
+        ops.zero_(ub)
+        ops.zero_(dub)
+        self.forward(noise=noise, with_cl=True, precision=precision)
+        views = self._views()
+        # ---- the minibatch: own segment of the user rows -> batch table on every replica ----
+        ops.gather_rows(ops.Slots([(v[0], users, None) for v in views]), B, D, self.seg_s, ub)
+        self._ar(ub)
+        entries = []
+        for j, v in enumerate(views):
+            entries += [(ub[j], ar, dub[j]), (v[2], pos, v[3])]
+        slots = ops.Slots(entries)
+        terms = self._terms()
+        pk = dict(pack=self.pack, n_slots=nS, precision=precision) if self.mfma_cl else {}
+        ops.gather_normalize(slots, B, D, zhat, znorm, self.pack)
+        ops.infonce_fwd(zhat, terms, nT, B, D, lse, row_loss, **pk)
+        ops.bpr_fwd_bwd_tables(ub[0], views[0][2], ar, pos, neg, row_loss[nT], dub[0], views[0][3])
+        ops.segment_sum(row_loss, nT + 1, B, 1.0, self.loss_parts)
+        emb = self.P.view("emb")
+        if nu:
+            ops.sumsq(emb[:nu], hp["reg"], self.loss_parts[nT + 1:], self.sumsq_scratch)
+        else:
+            ops.zero_(self.loss_parts[nT + 1:nT + 2])
+        ops.sumsq(emb[nu:], hp["reg"], self.loss_parts[nT + 2:], self.sumsq_scratch)
+        # ---- backward ----
+        ops.infonce_bwd(zhat, lse, terms, nT, B, D, dzhat, **pk)
+        ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
+        ops.scatter_add_rows(ops.Slots([(v[0], users, v[1]) for v in views]), B, D, self.seg_s, dub)
+        A = self.adj
+        s = 1.0 + hp["residual_weight"]
+        self._spmm([dict(adj=A, x_lo=self.dFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
+                    dict(adj=A, x_lo=self.dCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0)])
+        self._spmm([dict(adj=A, x_lo=self.dX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
+        i0, i1 = self.layout.item_slice()
+        ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
+                        dw=self.P.g("modal_weight"), partials=self.mix_partials, count=(nu * D, (nu + i0) * D, (nu + i1) * D))
+        self._spmm([dict(adj=A, x_lo=self.dBx, y=self.P.g("emb"))] + [dict(adj=self.modal_adj[m], x_lo=self.dZ[m], y=self.T[m]) for m in range(M)])
+        for m, nm in enumerate(modality_names(M)):  # projection backward: this replica's slice of the items
+            gw, gb = self.P.g(f"{nm}_layer.weight"), self.P.g(f"{nm}_layer.bias")
+            ops.zero_(gw)
+            if i1 > i0:
+                ops.rownorm_bwd(self.T[m][nu + i0:nu + i1], self.nf[m][i0:i1], self.fnorm[m][i0:i1], self.dfeat[m][i0:i1])
+                ops.gemm(self.dfeat[m][i0:i1], self.feats[m][i0:i1], out=gw, trans_a=True, precision=precision, split_k=128)
+                ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, gb)
+            else:
+                ops.zero_(gb)
+        ne = self.n * D
+        self._ar(self.P.grad[ne:])  # projections + modal_weight: partial sums over disjoint node sets
+        if update:
+            self.apply_adam()
+        self.rng_step += 1
+        return self.loss_parts
+
+    def _step_planned(self, B: int, precision: int) -> Tensor:
+        """The step as a recorded launch plan (kernel launches and collectives in order), replayed with fresh Philox offsets and Adam
+        (lr, step).  The batch lives in the static index buffers set_batch() fills."""
+        key = (B, precision, self.adj.uid, tuple(a.uid for a in self.modal_adj))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            self._philox_refs = []
+            try:
+                with L.Recorder() as calls:
+                    self._step_body(B, None, precision, True)
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] == "dmm_adam_step"])
+            finally:
+                self._philox_refs = None
+            self.rng_step -= 1  # recording ran the bookkeeping once without launching anything
+            self.P.step -= 1
+            self._plans[key] = plan
+        lanes = self.D // 4
+        base = self.rng_step * 3 * self.N * lanes
+        for arr, i, k in plan["philox"]:
+            arr[i].offset = base + k * self.N * lanes
+        self.P.step += 1
+        for c in plan["adam"]:
+            c[1][9], c[1][13] = self.lr, self.P.step
+        L.replay(plan["calls"])
+        self.rng_step += 1
+        return self.loss_parts
+
+    def apply_adam(self):
+        P, nu, D = self.P, self.nu, self.D
+        P.step += 1
+        ne = self.n * D
+        ops.adam_step(P.data[:ne], P.grad[:ne], P.m[:ne], P.v[:ne], self.lr, P.step, extra=list(self.T), extra_n=[nu * D] * self.M,
+                      l2_coef=2.0 * self.hp["reg"])
+        ops.adam_step(P.data[ne:], P.grad[ne:], P.m[ne:], P.v[ne:], self.lr, P.step)
+
+    def full_grads(self) -> Dict[str, Tensor]:
+        """Gradients as autograd reports them on the unsharded model (parity tests): u_embs = the replica's OWN rows."""
+        nu = self.nu
+        g = {k: self.P.g(k).clone() for k in self.P.names}
+        emb = g.pop("emb") + 2.0 * self.hp["reg"] * self.P.view("emb")
+        for t in self.T:
+            emb[:nu] += t[:nu]
+        g["u_embs"], g["i_embs"] = emb[:nu], emb[nu:]
+        return g
+
+    def losses(self) -> Dict[str, float]:
+        """Loss values of the last step (global: the partial user-side L2 term is summed over the replicas here -- a host sync)."""
+        lp = self.loss_parts.double().clone()
+        nT = self.n_terms
+        if self.world > 1:
+            _all_reduce(lp[nT + 1:nT + 2], self.group)
+        lp = lp.cpu()
+        cl, bpr, reg = float(lp[:nT].sum()), float(lp[nT]), float(lp[nT + 1] + lp[nT + 2])
+        return {"loss": bpr + reg + cl, "bpr": bpr, "reg": reg, "cl": cl}
+
+
+def make_sharded_adjacency(layout: ShardLayout, trn_rows: np.ndarray, trn_cols: np.ndarray, D: int, device, task_len: int = graph.TASK_LEN) -> graph.Adjacency:
+    """The replica's local block of the normalised bipartite adjacency of (trn_rows, trn_cols): host build (base graph, once per run)."""
+    rowptr, col, val = shard.local_block_csr(trn_rows, trn_cols, layout.users, layout.items, layout.u0, layout.u1, layout.rank, layout.world)
+    return graph.adjacency_from_csr(rowptr, col, val, D, device, task_len)

@@ -8,7 +8,7 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator) unless marked "host";
  *   - every launch is asynchronous on the given hipStream_t (passed as void*); no hidden allocation,
- *     no hidden synchronisation, no global mutable state besides the last-error string;
+ *     no hidden synchronisation, no global mutable state (the last-error string is thread-local, like errno);
  *   - return value 0 = ok; >0 = hipError_t of a failed launch; <0 = DMM_ERR_*; text via
  *     dmm_last_error_string();
  *   - matrices are row-major fp32 unless stated; indices are int32.
@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 100
+#define DMM_VERSION 200
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -69,10 +69,21 @@ typedef struct dmm_spmm_problem {
   int32_t split;
   float alpha, beta, gamma;
   float noise_degree;
+  /* User-sharded layout (one replica owns a user range, items replicated: SURVEY 8e).  When raw != NULL, rows >= raw_from (the item
+   * rows of the local block [own users ; all items]) are only a replica's PARTIAL sums: the launch parks their raw accumulators in
+   * raw [n_rows - raw_from, D] and applies no epilogue to them; the caller sums `raw` over the replicas (one all-reduce per launch)
+   * and then calls dmm_spmm_epilogue_rows on the same problem array.  Rows < raw_from (own users) are complete and finished in place. */
+  float* raw;
+  int32_t raw_from;
+  /* In-kernel Philox draws are keyed by the row's GLOBAL id: row + (row < rng_row_split ? rng_row_add_lo : rng_row_add_hi), so a
+   * replica draws what the unsharded launch draws for that row (all zero = local ids, the unsharded case). */
+  int32_t rng_row_split, rng_row_add_lo, rng_row_add_hi;
 } dmm_spmm_problem;
 
 int dmm_spmm_tasks_per_block(int D);
 int dmm_spmm_csr_f32(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
+/* epilogue of the rows >= raw_from from the (all-reduced) raw partial rows; problems with raw == NULL are skipped */
+int dmm_spmm_epilogue_rows(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense GEMM on the matrix cores (bf16 MFMA 32x32x16, fp32 accumulate; operands stay fp32 in HBM and are
@@ -143,6 +154,12 @@ int64_t dmm_gcn_mix_partials(int64_t n);
 int dmm_gcn_mix_bwd(const float* dmx, const float* bx, const float* const* z /*host*/, float* const* dz /*host, in/out*/,
                     const float* dbx_extra, float* dbx, const float* w_logits, float* dw_logits, int M, float maw,
                     float* partials, int64_t n, void* stream);
+/* The same, but only elements [0, count0_end) and [count1_begin, count1_end) enter d(logits): a user-sharded replica counts its own
+ * user rows and its slice of the replicated item rows, and the replicas' dw_logits add up (the softmax backward is linear in the
+ * per-modality dot products) to the unsharded gradient. */
+int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const float* const* z /*host*/, float* const* dz /*host, in/out*/,
+                            const float* dbx_extra, float* dbx, const float* w_logits, float* dw_logits, int M, float maw,
+                            float* partials, int64_t n, int64_t count0_end, int64_t count1_begin, int64_t count1_end, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Contrastive + ranking losses.  Utils/Utils.py:57-75 (InfoNCE), :78-98 (bpr_loss), :45-54 (l2_reg_loss).
@@ -178,6 +195,18 @@ int dmm_scatter_normalize_bwd(const dmm_gather_desc* slots /*host*/, int n_slots
  * dfin[user/pos/neg rows] += d(row_loss) (atomics).  `fin` is [U + I, D]; item i lives at row U + i. */
 int dmm_bpr_fwd_bwd(const float* fin, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D, int U,
                     float* row_loss, float* dfin, void* stream);
+/* The same with the user rows and the item rows in two tables (users[b] indexes fin_u / dfin_u, pos[b] and neg[b] index fin_i / dfin_i):
+ * the user-sharded engine scores the exchanged batch table of user rows against its replicated item rows. */
+int dmm_bpr_fwd_bwd_tables(const float* fin_u, const float* fin_i, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D,
+                           float* row_loss, float* dfin_u, float* dfin_i, void* stream);
+/* User-sharded batch exchange (replaces nothing in the reference, which is single-process: Main.py:305-307 gathers whole
+ * tables).  A replica owns the user rows of the batch positions [seg[0], seg[1]) (seg: DEVICE int32[2], read by the kernel so the launch
+ * is the same every step; NULL = all of [0, B)).
+ *   dmm_gather_rows       out[s][b] = slots[s].src[slots[s].idx[b]]   for b in the segment; other rows of out [n_slots, B, D] untouched
+ *                         (zero them first: a sum all-reduce over the replicas then assembles every replica's copy of the table)
+ *   dmm_scatter_add_rows  slots[s].grad[slots[s].idx[b]] += in[s][b]  for b in the segment (fp32 atomics; repeated users are legal) */
+int dmm_gather_rows(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const int32_t* seg, float* out, void* stream);
+int dmm_scatter_add_rows(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const int32_t* seg, const float* in, void* stream);
 /* out[s] = scale * sum(in[s*len .. (s+1)*len)) in a fixed order (deterministic loss reduction). */
 int dmm_segment_sum(const float* in, int n_seg, int64_t len, float scale, float* out, void* stream);
 /* out[0] = scale * sum(x^2) (l2_reg_loss, Utils.py:45-54); scratch: dmm_sumsq_scratch(n) floats. */
@@ -260,6 +289,15 @@ int dmm_graph_build_task_capacity(int U, int I, int64_t E, int D, int task_len, 
 int dmm_graph_build(const int32_t* user_ptr, const int32_t* edge_user, const int32_t* item_idx, int U, int I, int64_t E, int D, int task_len,
                     const double* dinv_table, int32_t* rowptr, int32_t* col, float* val, void* tasks, void* fix, int32_t* meta, void* scratch,
                     void* stream);
+/* User-sharded variant: builds a replica's local block over the node order [own users (U of them) ; all items].  user_ptr /
+ * edge_user / item_idx describe the replica's OWN users only; item_count_global int32 [I] = number of users, over ALL replicas, that
+ * selected each item (dmm_count_items on every replica, then a sum all-reduce) -- it sets the D^-1/2 factors, so the block carries the
+ * values of the full graph; item i's self loop is emitted only where i % self_mod == self_rank (so the replicas' blocks add up to the
+ * full matrix, each entry exactly once).  nnz <= 2E + U + I.  item_count_global == NULL, self_mod = 1: identical to dmm_graph_build. */
+int dmm_count_items(const int32_t* item_idx, int64_t E, int I, int32_t* count /*[I], accumulated: zero it first*/, void* stream);
+int dmm_graph_build_shard(const int32_t* user_ptr, const int32_t* edge_user, const int32_t* item_idx, int U, int I, int64_t E, int D, int task_len,
+                          const double* dinv_table, const int32_t* item_count_global, int self_mod, int self_rank, int32_t* rowptr, int32_t* col,
+                          float* val, void* tasks, void* fix, int32_t* meta, void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Evaluation: Coach.testEpoch (Main.py:403-411).  score [rows, cols] holds usrEmbeds[users] @ itmEmbeds^T (dmm_gemm); every
