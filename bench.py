@@ -9,9 +9,11 @@ section 8(d):  value = (n_diff + n_joint) * K / wall_seconds, B-sized minibatche
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU over RCCL; every rank holds the (small) graph, the minibatches of an epoch are dealt
-round-robin to the ranks, gradients are averaged with all-reduce before Adam, the rebuild's user batches are sharded
-and their edges all-gathered.  The data set is fixed, so this is strong scaling.
+N > 1: one process per GPU over RCCL, users sharded over the ranks (diffmm_amd/sharded.py): every rank owns a
+contiguous user range (its embedding rows, Adam state, adjacency rows), items are replicated; every SpMM is a local launch
++ one all-reduce of the item partials, every minibatch is the reference's minibatch with its rows split by owner, the
+reverse chain and the top-k run on the own users only.  The number of optimiser steps per epoch is the reference's at
+every N; the data set is fixed, so this is strong scaling.
 """
 from __future__ import annotations
 
@@ -42,10 +44,8 @@ def make_coach(args, rank: int, world: int):
     seed_it(cfg.base.seed)
     h = DataHandler(cfg)
     h.LoadData()
-    coach = Coach(h, cfg, precision=args.precision)
+    coach = Coach(h, cfg, precision=args.precision, rank=rank, world=world)
     coach.prepareModel()
-    if world > 1:
-        coach.enable_distributed(rank, world)
     return coach, h, cfg
 
 
@@ -204,9 +204,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     replicas_identical = None
-    if world > 1:  # data-parallel replicas must hold bit-identical weights after the same sequence of averaged updates
+    if world > 1:  # the replicated parameters (items, projections, Denoise weights) must stay bit-identical: they only receive all-reduced gradients
         import torch.distributed as dist
-        flat = torch.cat([coach.model.engine.P.data] + [p.data for p in coach.diff_engine.P])
+        J = coach.model.engine
+        flat = torch.cat([J.P.data[J.nu * J.D:]] + [p.data for p in coach.diff_engine.P])
         lo, hi = flat.clone(), flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
@@ -218,12 +219,12 @@ def main():
            "data": "synthetic",
            "config": {"workload": f"synthetic {args.workload}-shape graph: U={h.graph.users} I={h.graph.items} E={h.graph.nnz}, M={len(h.graph.feats)} modalities, "
                                   f"d={args.latdim}, T={args.T}, batch={args.batch}; step = 1 epoch = {n_diff} diffusion iters + rebuild + {n_joint} joint iters",
-                      "parallelism": f"dp{world}", "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
+                      "parallelism": f"user-shard{world}" if world > 1 else "single", "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
                       "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3},
                       # the two per-phase rates next to the blended headline (`value`); host-side phase boundaries of rank 0
                       "phase_iters_per_s": {"diffusion": n_diff * args.steps / max(phases[0], 1e-9), "joint": n_joint * args.steps / max(phases[2], 1e-9)}}}
     if replicas_identical is not None:
-        out["replicas_identical"] = replicas_identical
+        out["replicated_params_identical"] = replicas_identical
     if not args.no_roofline:
         g, s = roofline(coach, args)
         out["roofline"], out["roofline_spmm"] = g, s

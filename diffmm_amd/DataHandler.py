@@ -37,6 +37,18 @@ class BatchLoader:
     def __len__(self) -> int:
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
+    def index_batches(self) -> List[torch.Tensor]:
+        """The epoch's batches as index tensors only (one permutation draw, nothing materialised): what the rebuild and the user-sharded
+        trainer consume -- they densify / slice only the rows they own."""
+        n = len(self.dataset)
+        if self.fixed_perm is not None:
+            perm = self.fixed_perm.to(self.device)
+        elif self.shuffle:
+            perm = torch.randperm(n, device=self.device, generator=self.gen)
+        else:
+            perm = torch.arange(n, device=self.device)
+        return [perm[s:s + self.batch_size] for s in range(0, n, self.batch_size)]
+
     def __iter__(self) -> Iterator:
         n = len(self.dataset)
         if self.fixed_perm is not None:

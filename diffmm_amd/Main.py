@@ -2,7 +2,8 @@
 .trainEpoch() / .testEpoch() / .calcRes() / .makePrint() / .save_max(), seed_it(seed), CLI `-c/--config`.
 
 The three phases of an epoch (diffusion training, reverse-chain rebuild of the modality graphs, joint BPR +
-contrastive training) run on diffmm_amd.engine (HIP kernels only).  Host synchronisation points per epoch: one per
+contrastive training) run on diffmm_amd.engine (HIP kernels only); with several GPUs on diffmm_amd.sharded (users sharded over
+the replicas, one process per GPU).  Host synchronisation points per epoch: one per
 diffusion iteration (the loss normalisation needs host values, as in the reference), one per modality for the
 rebuilt edge list, one at the end of the joint phase for the logged losses.
 """
@@ -32,23 +33,23 @@ def _log(msg: str) -> None:
 
 
 class Coach:
-    def __init__(self, handler: DataHandler, config: Config, precision: int = 1):
-        """precision: 1 = single bf16 MFMA product in the dense GEMMs (fast path), 3 = hi/lo split (~fp32, parity tests)."""
+    def __init__(self, handler: DataHandler, config: Config, precision: int = 1, rank: int = 0, world: int = 1, group=None):
+        """precision: 1 = single bf16 MFMA product in the dense GEMMs (fast path), 3 = hi/lo split (~fp32, parity tests).
+        world > 1: one process per GPU (torch.distributed initialised by the caller; backend 'nccl' == RCCL); the users are sharded over
+        the replicas (diffmm_amd/sharded.py), every epoch makes exactly the reference's optimiser steps on the reference's minibatches."""
         self.handler, self.config, self.precision = handler, config, precision
         self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
         _log(f"USER: {config.data.user_num}, ITEM: {config.data.item_num}")
         _log(f"NUM OF INTERACTIONS: {len(handler.trainData)}")
         self.epoch_idx = 0
-        self.world, self.rank = 1, 0
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self.layout = None
+        if self.world > 1:
+            from .sharded import ShardLayout
+            self.layout = ShardLayout.make(handler.graph.trn_rows, int(config.data.user_num), int(config.data.item_num), self.world, self.rank)
         self.phase_seconds = [0.0, 0.0, 0.0]
-
-    def enable_distributed(self, rank: int, world: int) -> None:
-        """Data-parallel replicas (one process per GPU, torch.distributed 'nccl' == RCCL): minibatches are dealt round-robin,
-        gradients averaged by all-reduce, rebuild user batches sharded.  Call after prepareModel()."""
-        self.rank, self.world = rank, world
-        for e in (self.model.engine, self.diff_engine):
-            e.world, e.rank = world, rank
-            e.hp["seed"] = int(e.hp.get("seed", 1818)) + 7919 * rank  # decorrelate the in-kernel Philox streams
+        self.best = dict(Recall=0.0, NDCG=0.0, Precision=0.0, epoch=0)
+        self.his_max = [0.0, 0.0, 0.0]
 
     def makePrint(self, name, epoch, results: dict) -> str:
         body = ", ".join(f"{k}={v:.5f}" for k, v in results.items())
@@ -63,18 +64,31 @@ class Coach:
         M = h.modalities()
         feats = [h.image_feats, h.text_feats] + ([h.audio_feats] if M == 3 else [])
         self.M = M
-        self.model = Model(cfg, *feats, precision=self.precision)
+        lay = self.layout
+        self.model = Model(cfg, *feats, precision=self.precision, layout=lay, group=self.group)
         self.diffusion_model = GaussianDiffusion(cfg)
         in_dims, out_dims = denoise_dims(cfg)
+        own_users = lay.nu if lay is not None else int(cfg.data.user_num)
         self.diff_engine = DiffusionEngine(int(cfg.data.item_num), int(cfg.base.latdim), int(in_dims[1]), int(cfg.base.d_emb_size), M,
                                            int(cfg.hyper.steps), hyper_dict(cfg), self.device, int(cfg.train.batch),
-                                           chain_rows=min(int(cfg.data.user_num), 16384))
+                                           chain_rows=min(max(own_users, 1), 16384))
         dens = [Denoise(in_dims, out_dims, cfg, _engine=self.diff_engine, _slot=m, precision=self.precision) for m in range(M)]
         self.image_denoise_model, self.text_denoise_model = dens[0], dens[1]
         if M == 3:
             self.audio_denoise_model = dens[2]
         self.base_lr = float(cfg.train.lr)
         self.image_adj = self.text_adj = self.audio_adj = None
+        self.base_adj = h.torchBiAdj
+        if lay is not None:
+            from .sharded import make_sharded_adjacency
+            DE, dd = self.diff_engine, h.diffusionData
+            DE.shard_world, DE.shard_rank, DE.shard_group = self.world, self.rank, self.group
+            DE.hp["seed"] = int(DE.hp.get("seed", 1818)) + 7919 * self.rank  # the replicas' rows draw from different Philox streams
+            DE.t_gen = torch.Generator(device=self.device)
+            DE.t_gen.manual_seed(int(cfg.base.seed) + 101 * (self.rank + 1))
+            self.base_adj = make_sharded_adjacency(lay, h.graph.trn_rows, h.graph.trn_cols, int(cfg.base.latdim), self.device)
+            self.local_ptr = (dd.ptr[lay.u0:lay.u1 + 1] - dd.ptr[lay.u0]).contiguous()  # CSR of the own users' train items
+            self.local_ptr32 = self.local_ptr.to(torch.int32)
 
     def _set_lr(self) -> None:
         """CosineAnnealingLR(T_max=train.epoch, eta_min=1e-4), stepped once per epoch (Main.py:59-65,93,101,105,110)."""
@@ -90,60 +104,72 @@ class Coach:
         if resume:
             self.load_checkpoint(resume)
             _log(f"Resumed from {resume} at epoch {self.epoch_idx}")
-        best = dict(Recall=0.0, NDCG=0.0, Precision=0.0, epoch=0)
-        his_max = [0, 0, 0]
         try:
             for epoch in range(self.epoch_idx, int(self.config.train.epoch)):
                 result = self.trainEpoch()
-                if save:
-                    self.save_checkpoint(save)
                 _log(self.makePrint("Train", epoch, result))
                 if epoch % int(self.config.train.tstEpoch) == 0:
                     result = self.testEpoch()
-                    his_max = self.save_max([result["Recall"], result["NDCG"], result["Precision"]], his_max)
-                    if result["Recall"] > best["Recall"]:
-                        best = dict(result, epoch=epoch)
+                    self.his_max = self.save_max([result["Recall"], result["NDCG"], result["Precision"]], self.his_max)
+                    if result["Recall"] > self.best["Recall"]:
+                        self.best = dict(result, epoch=epoch)
                     _log(self.makePrint("Test", epoch, result))
+                if save:
+                    self.save_checkpoint(save)
+                best, his_max = self.best, self.his_max
                 _log(f"Current best: Epoch: {best['epoch']}, Recall: {best['Recall']:.5f}({his_max[0]:.5f}), NDCG: {best['NDCG']:.5f}"
                      f"({his_max[1]:.5f}), Precision: {best['Precision']:.5f}({his_max[2]:.5f})")
         except KeyboardInterrupt:
             _log("Training interrupted by user!")
-        self.best = best
 
     # -- checkpoint / resume (absent in the reference) ----------------------------------------------------------------
     def _flat_models(self):
         return [("model", self.model.engine.P)] + [(f"denoise{m}", p) for m, p in enumerate(self.diff_engine.P)]
 
+    def _ckpt_path(self, path: str) -> str:
+        """User-sharded runs write one file per replica (each holds its own user rows and their Adam state)."""
+        return path if self.world == 1 else f"{path}.rank{self.rank}of{self.world}"
+
     def save_checkpoint(self, path: str) -> None:
         """Everything the next epoch depends on: weights and Adam state of the model and of every Denoise, the step / Philox counters,
-        the sampler and loader generators, the epoch index.  Tensors and plain numbers only (loads with weights_only=True)."""
+        the sampler and loader generators, the epoch index, the best metrics so far.  Tensors and plain numbers only (loads with
+        weights_only=True)."""
         h, J, DE = self.handler, self.model.engine, self.diff_engine
         sd = {"epoch_idx": int(self.epoch_idx), "rng_step_joint": int(J.rng_step), "rng_step_diffusion": int(DE.rng_step),
-              "xT_calls": int(getattr(DE, "_xT_calls", 0)),
+              "xT_calls": int(DE._xT_calls), "world": int(self.world),
+              "best": {k: float(v) for k, v in self.best.items()}, "his_max": [float(v) for v in self.his_max],
               "gen": {"train_loader": h.trainLoader.gen.get_state(), "diffusion_loader": h.diffusionLoader.gen.get_state(),
                       "neg_sampler": h.trainData.gen.get_state(), "torch_cpu": torch.get_rng_state(),
                       "torch_device": torch.cuda.get_rng_state(self.device)}}  # the timestep draws use the global device generator
+        if DE.t_gen is not None:
+            sd["gen"]["timesteps"] = DE.t_gen.get_state()
         for name, P in self._flat_models():
             sd[name] = {"data": P.data.clone(), "m": P.m.clone(), "v": P.v.clone(), "step": int(P.step)}
-        torch.save(sd, path)
+        torch.save(sd, self._ckpt_path(path))
 
     def load_checkpoint(self, path: str) -> None:
-        """Call after prepareModel() on a Coach built from the same config and data."""
+        """Call after prepareModel() on a Coach built from the same config, data and number of replicas."""
         h, J, DE = self.handler, self.model.engine, self.diff_engine
-        sd = torch.load(path, map_location=self.device, weights_only=True)
+        sd = torch.load(self._ckpt_path(path), map_location=self.device, weights_only=True)
+        if int(sd.get("world", 1)) != self.world:
+            raise ValueError(f"checkpoint {path} was written by {sd.get('world', 1)} replica(s), this run has {self.world}")
         for name, P in self._flat_models():
             t = sd[name]
             if t["data"].numel() != P.data.numel():
                 raise ValueError(f"checkpoint {path}: {name} has {t['data'].numel()} parameters, this model {P.data.numel()}")
             P.data.copy_(t["data"]); P.m.copy_(t["m"]); P.v.copy_(t["v"]); P.step = int(t["step"])
         self.epoch_idx, J.rng_step, DE.rng_step = int(sd["epoch_idx"]), int(sd["rng_step_joint"]), int(sd["rng_step_diffusion"])
-        if sd["xT_calls"]:
-            DE._xT_calls = int(sd["xT_calls"])
+        DE._xT_calls = int(sd["xT_calls"])
+        if "best" in sd:
+            self.best = {k: (int(v) if k == "epoch" else float(v)) for k, v in sd["best"].items()}
+            self.his_max = [float(v) for v in sd["his_max"]]
         DE.w16_step = [-1] * DE.M  # bf16 weight copies of the reverse chain are stale
         J._plans.clear()
         h.trainLoader.gen.set_state(sd["gen"]["train_loader"].cpu()); h.diffusionLoader.gen.set_state(sd["gen"]["diffusion_loader"].cpu())
         h.trainData.gen.set_state(sd["gen"]["neg_sampler"].cpu())
         torch.set_rng_state(sd["gen"]["torch_cpu"].cpu()); torch.cuda.set_rng_state(sd["gen"]["torch_device"].cpu(), self.device)
+        if DE.t_gen is not None and "timesteps" in sd["gen"]:
+            DE.t_gen.set_state(sd["gen"]["timesteps"].cpu())
 
     def makeTorchAdj(self, u_list, i_list, edge_list=None) -> graph.Adjacency:
         cfg = self.config
@@ -152,39 +178,38 @@ class Coach:
 
     # ---------------------------------------------------------------------------------------------
     def trainEpoch(self, draws=None, modal_adj_override: Optional[List[graph.Adjacency]] = None) -> Dict[str, float]:
-        """One epoch (Main.py:136-388).  `draws` (tests only) supplies the random draws in the reference's call order."""
+        """One epoch (Main.py:136-388).  `draws` (tests only, single replica) supplies the random draws in the reference's call order."""
         cfg, h, M, dev = self.config, self.handler, self.M, self.device
-        J, DE, prec = self.model.engine, self.diff_engine, self.precision
+        J, DE, prec, lay = self.model.engine, self.diff_engine, self.precision, self.layout
+        if draws is not None and lay is not None:
+            raise ValueError("recorded draws drive the single-replica path only")
         self._set_lr()
         if draws is None:
-            h.trainData.negSampling()
+            h.trainData.negSampling()  # own generator, identically seeded on every replica: the same negatives everywhere
         B = int(cfg.train.batch)
         train_steps = max(1, len(h.trainData) // B)
         diffusion_steps = max(1, len(h.diffusionData) // B)
         T = int(cfg.hyper.steps)
+        dd = h.diffusionData
 
         import time
-        W, R = self.world, self.rank
         t_start = time.perf_counter()
         # ---- phase 1: diffusion training (Main.py:145-192) ----
         J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
         feats = [J.feat[m] for m in range(M)]
+        reg_term = DE.reg_term(J.i_embs)  # i_embs does not move in this phase either
         dl = [0.0] * M
-        from . import dist as D_
-        batches = list(h.diffusionLoader)
-        diff_batches = [idx for _, idx in batches]
-        for n_contrib, mine in D_.deal(batches, W, R):  # one global step = up to W minibatches, one per replica
-            if mine is None:
-                DE.idle_step(n_contrib)
-                continue
-            x0, idx = mine
+        diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
+        for idx in diff_batches:
+            own = idx if lay is None else idx[(idx >= lay.u0) & (idx < lay.u1)]
+            x0 = dd.rows(own)
             t = noise = None
             if draws is not None:
                 t, noise = [], []
                 for m in range(M):
                     t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
                     noise.append(draws.randn(tuple(x0.shape)).to(dev))
-            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, n_contrib=n_contrib)
+            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]))
             tot = sum(means)
             for m in range(M):  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
                 dl[m] += means[m]
@@ -194,35 +219,38 @@ class Coach:
 
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
         if modal_adj_override is None:
-            dd = h.diffusionData
-            n_edges = int(dd.ptr[-1])
-            edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, n_edges, precision=prec, sampling_step=int(cfg.hyper.sampling_step))
-            if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
-                self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim))
+            sstep = int(cfg.hyper.sampling_step)
+            if lay is None:
+                edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep)
+                if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
+                    self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim))
+            else:  # own users only (local ids index the local CSR; the data rows are looked up by global id)
+                if getattr(self, "graph_builder", None) is None:
+                    self.graph_builder = graph.ShardedGraphBuilder(self.local_ptr, lay.nu, lay.users, lay.items, int(cfg.base.latdim), self.rank, self.world,
+                                                                   group=self.group)
+                    self._own_local = torch.arange(lay.nu, device=dev)
+                edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [self._own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
+                                         sampling_step=sstep)
             adjs = self.graph_builder.build_all(edges)
         else:
             adjs = list(modal_adj_override)
         self.image_adj, self.text_adj = adjs[0], adjs[1]
         self.audio_adj = adjs[2] if M == 3 else None
-        J.set_adjacency(h.torchBiAdj, adjs)
+        J.set_adjacency(self.base_adj, adjs)
         t_reb = time.perf_counter()
 
         # ---- phase 3: joint training (Main.py:292-377) ----
-        acc = torch.zeros(J.n_terms + 2, dtype=torch.float64, device=dev)
-        for n_contrib, mine in D_.deal(list(h.trainLoader), W, R):
-            if mine is None:
-                J.allreduce_grads(contributing=False, n_contrib=n_contrib)
-                J.apply_adam(fold_extras=False)
-                continue
-            users, pos, neg = mine
+        acc = torch.zeros(J.loss_parts.numel(), dtype=torch.float64, device=dev)
+        for users, pos, neg in h.trainLoader:  # the same shuffled minibatches on every replica (identically seeded loader generator)
             noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
-            acc += J.step(users, pos, neg, noise=noise, precision=prec, n_contrib=n_contrib)
-        if W > 1:
+            acc += J.step(users, pos, neg, noise=noise, precision=prec)
+        nT = J.n_terms
+        if lay is not None:  # [terms..., bpr, reg over the own users, reg over the items]: only the user part is a partial sum
             import torch.distributed as dist
-            dist.all_reduce(acc)
+            dist.all_reduce(acc[nT + 1:nT + 2], group=self.group)
+            acc = torch.cat([acc[:nT + 1], acc[nT + 1:nT + 2] + acc[nT + 2:nT + 3]])
         a = acc.cpu().numpy()
         self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]
-        nT = J.n_terms
         cl, bpr, reg = float(a[:nT].sum()), float(a[nT]), float(a[nT + 1])
         result = {"Loss": (bpr + reg + cl) / train_steps, "BPR Loss": bpr / train_steps, "reg loss": reg / train_steps, "CL loss": cl / train_steps}
         for m, n in enumerate(modality_names(M)):
@@ -233,24 +261,35 @@ class Coach:
     # ---------------------------------------------------------------------------------------------
     def testEpoch(self) -> Dict[str, float]:
         """Full-ranking evaluation (Main.py:390-420): propagate once, then per user batch score = U_b I^T (dmm_gemm, split-bf16
-        ~fp32), train items masked to -1e8 and top-k selected in one launch (dmm_eval_topk); only the [batch, topk] ids leave the GPU."""
-        h, J = self.handler, self.model.engine
+        ~fp32), train items masked to -1e8 and top-k selected in one launch (dmm_eval_topk); only the [batch, topk] ids leave the GPU.
+        User-sharded: every replica ranks the test users it owns; the metric sums are all-reduced."""
+        h, J, lay = self.handler, self.model.engine, self.layout
         adjs = [self.image_adj, self.text_adj] + ([self.audio_adj] if self.M == 3 else [])
-        J.set_adjacency(h.torchBiAdj, adjs)
+        J.set_adjacency(self.base_adj, adjs)
         J.forward(with_cl=False, precision=self.precision)
-        U = J.U
-        uf, itf = J.Fin[:U], J.Fin[U:]
+        nu = J.nu if lay is not None else J.U
+        u0 = lay.u0 if lay is not None else 0
+        uf, itf = J.Fin[:nu], J.Fin[nu:]
         td, k = h.testData, int(self.config.base.topk)
         tb = int(self.config.train.test_batch)
-        score = torch.empty(min(tb, len(td)), J.I, dtype=torch.float32, device=uf.device)
+        users_all, u32_all = td._users_d, td._users_i32
+        if lay is not None:
+            keep = (users_all >= lay.u0) & (users_all < lay.u1)
+            users_all, u32_all = users_all[keep], u32_all[keep]
+        n_own = int(users_all.shape[0])
         total = torch.zeros(3, dtype=torch.float64, device=uf.device)
-        for lo in range(0, len(td), tb):
-            usr, u32 = td._users_d[lo:lo + tb], td._users_i32[lo:lo + tb]
-            ub = uf.index_select(0, usr)
+        if n_own:
+            score = torch.empty(min(tb, n_own), J.I, dtype=torch.float32, device=uf.device)
+        for lo in range(0, n_own, tb):
+            usr, u32 = users_all[lo:lo + tb], u32_all[lo:lo + tb]
+            ub = uf.index_select(0, usr - u0)
             sc = score[:usr.shape[0]]
             ops.gemm(ub, itf, out=sc, trans_b=True, precision=3)
             top = ops.eval_topk(sc, u32, td._trn_ptr, td._trn_col, k)
             total += ops.eval_metrics(top, u32, td._tst_ptr, td._tst_col).sum(0)  # calcRes on the device; one host read at the end
+        if lay is not None:
+            import torch.distributed as dist
+            dist.all_reduce(total, group=self.group)
         rec, ndcg, prec = (total / len(td)).tolist()
         return {"Recall": rec, "NDCG": ndcg, "Precision": prec}
 
@@ -300,10 +339,18 @@ def main(argv=None) -> None:
     main_log.info("Start")
     for section, options in vars(config).items():
         main_log.info(f"{section}: {options}")
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    if world > 1:  # python -m torch.distributed.run --nproc-per-node N -m diffmm_amd.Main -c ...: one process per GPU, users sharded
+        import torch.distributed as dist
+        config.base.gpu = str(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(int(config.base.gpu))
+        dist.init_process_group(os.environ.get("DMM_BACKEND", "nccl"))
+        if rank != 0:
+            main_log = None  # one log
     handler = DataHandler(config)
-    main_log.info("Load Data")
+    _log("Load Data")
     handler.LoadData()
-    Coach(handler, config, precision=args.precision).run(resume=args.resume, save=args.save)
+    Coach(handler, config, precision=args.precision, rank=rank, world=world).run(resume=args.resume, save=args.save)
 
 
 if __name__ == "__main__":

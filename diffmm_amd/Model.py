@@ -52,12 +52,19 @@ class Model:
     """Multi-modal graph encoder (Model.py:15-134).  `gcn_MM` returns views into the engine's HBM buffers."""
 
     def __init__(self, config: Config, image_embedding: Tensor, text_embedding: Tensor, audio_embedding: Optional[Tensor] = None,
-                 batch_max: Optional[int] = None, precision: int = 1):
+                 batch_max: Optional[int] = None, precision: int = 1, layout=None, group=None):
+        """layout (diffmm_amd.sharded.ShardLayout, world > 1): user-sharded replica -- the engine keeps this replica's user rows and the
+        replicated item side; the initial weights are drawn for the FULL model from the (identically seeded) host generator on every
+        replica, so the replicas start from the same model the single-GPU run starts from."""
         self.config = config
         self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
         feats = [image_embedding, text_embedding] + ([audio_embedding] if audio_embedding is not None else [])
         U, I, D = int(config.data.user_num), int(config.data.item_num), int(config.base.latdim)
-        self.engine = JointEngine(U, I, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch))
+        if layout is not None and layout.world > 1:
+            from .sharded import ShardedJointEngine
+            self.engine = ShardedJointEngine(layout, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch), group=group)
+        else:
+            self.engine = JointEngine(U, I, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch))
         self.precision = precision
         self.image_embedding, self.text_embedding, self.audio_embedding = image_embedding, text_embedding, audio_embedding
         sd = {"u_embs": torch.nn.init.xavier_uniform_(torch.empty(U, D)), "i_embs": torch.nn.init.xavier_uniform_(torch.empty(I, D))}

@@ -111,7 +111,6 @@ class JointEngine:
         self.adj: Optional[Adjacency] = None
         self.modal_adj: List[Adjacency] = []
         self.rng_step = 0
-        self.world, self.rank = 1, 0  # data-parallel replicas (gradient all-reduce over RCCL) when world > 1
         zi = lambda: torch.zeros(B_max, dtype=torch.int32, device=self.dev)
         self.users_s, self.pos_s, self.neg_s = zi(), zi(), zi()  # static index buffers of the recorded launch plans
         self._plans: Dict[tuple, dict] = {}
@@ -211,13 +210,13 @@ class JointEngine:
         return ops.Slots(e), ops.make_terms(terms)
 
     def step(self, users: Tensor, pos: Tensor, neg: Tensor, noise: Optional[Sequence[Tensor]] = None, precision: int = 3,
-             update: bool = True, n_contrib: Optional[int] = None) -> Tensor:
+             update: bool = True) -> Tensor:
         """Runs forward + backward (+ Adam).  Returns the device tensor loss_parts = [InfoNCE terms..., bpr, reg]
         (weights folded in); no host synchronisation happens here."""
         B, D, U, N, M, hp = int(users.shape[0]), self.D, self.U, self.N, self.M, self.hp
         assert B <= self.B_max
         if noise is None and update and self._philox_refs is None:
-            return self._step_planned(users, pos, neg, precision, n_contrib)
+            return self._step_planned(users, pos, neg, precision)
         ops.zero_(self.gblock)
         ops.zero_(self.dzhat)
         self.forward(noise=noise, with_cl=True, precision=precision)
@@ -256,19 +255,17 @@ class JointEngine:
             ops.gemm(self.dfeat[m], self.feats[m], out=gw, trans_a=True, precision=precision, split_k=128)  # 64 x F output: K = I is the parallel axis (32 / 64 / 128 / 256 measured)
             ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"))
         if update:
-            if self.world > 1:
-                self.allreduce_grads(contributing=True, n_contrib=n_contrib)
-            self.apply_adam(fold_extras=self.world == 1)
+            self.apply_adam()
         self.rng_step += 1
         return self.loss_parts
 
     # -- steady state: the step as a recorded launch plan ------------------------------------------------
-    def _step_planned(self, users: Tensor, pos: Tensor, neg: Tensor, precision: int, n_contrib: Optional[int]) -> Tensor:
+    def _step_planned(self, users: Tensor, pos: Tensor, neg: Tensor, precision: int) -> Tensor:
         """Same launches as step(), replayed from a plan recorded once per (batch size, graph set): no per-launch Python
         marshalling.  Per step only the batch indices (copied into static buffers), the Philox offsets and Adam's (lr, step)
-        change."""
+        change.  (Several GPUs: diffmm_amd/sharded.py -- the user-sharded engine, same plan mechanism with the collectives in it.)"""
         B = int(users.shape[0])
-        key = (B, precision, self.adj.uid, tuple(a.uid for a in self.modal_adj), self.world)
+        key = (B, precision, self.adj.uid, tuple(a.uid for a in self.modal_adj))
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 8:
@@ -276,79 +273,30 @@ class JointEngine:
             self._philox_refs = []
             try:
                 with L.Recorder() as calls:
-                    # recorded with update=False when gradients are exchanged between replicas (the all-reduce is not a C-ABI call)
-                    self.step(self.users_s[:B], self.pos_s[:B], self.neg_s[:B], noise=None, precision=precision, update=False)
-                    if self.world == 1:
-                        self.apply_adam(fold_extras=True)
+                    self.step(self.users_s[:B], self.pos_s[:B], self.neg_s[:B], noise=None, precision=precision, update=True)
                 plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] == "dmm_adam_step"])
             finally:
                 self._philox_refs = None
             self.rng_step -= 1  # recording ran step()'s bookkeeping once without launching anything
-            if self.world == 1:
-                self.P.step -= 1
+            self.P.step -= 1
             self._plans[key] = plan
         self.users_s[:B].copy_(users); self.pos_s[:B].copy_(pos); self.neg_s[:B].copy_(neg)
         lanes = self.D // 4
         base = self.rng_step * 3 * self.N * lanes
         for arr, i, k in plan["philox"]:
             arr[i].offset = base + k * self.N * lanes
-        if self.world == 1:
-            self.P.step += 1
-            for c in plan["adam"]:
-                c[1][9], c[1][13] = self.lr, self.P.step
-        if self.world > 1:
-            # the embedding gradient is final after the last backward SpMM: its all-reduce (bucket 1) runs on a side stream under the
-            # modality projections' backward (the rest of the plan); bucket 2 (projection / mixing weights) follows on this stream.
-            if "split" not in plan:
-                last = max(i for i, c in enumerate(plan["calls"]) if c[2].startswith("dmm_spmm"))
-                plan["split"] = last + 1
-            k = plan["split"]
-            L.replay(plan["calls"][:k])
-            work = self._exchange_embedding_grads_async(n_contrib)
-            L.replay(plan["calls"][k:])
-            self._exchange_tail_grads(work, n_contrib)
-            self.apply_adam(fold_extras=False)
-        else:
-            L.replay(plan["calls"])
+        self.P.step += 1
+        for c in plan["adam"]:
+            c[1][9], c[1][13] = self.lr, self.P.step
+        L.replay(plan["calls"])
         self.rng_step += 1
         return self.loss_parts
 
-    # -- gradient exchange between replicas: ALWAYS two collectives, bucket 1 = embedding table, bucket 2 = everything behind it -------
-    def _exchange_embedding_grads_async(self, n_contrib: Optional[int], contributing: bool = True):
-        import torch.distributed as dist
-        ne, nu = self.N * self.D, self.U * self.D
-        g = self.P.grad
-        if contributing:
-            for t in self.T:  # fold the user-row parts of the modal SpMM backward into the flat buffer first
-                ops.add_inplace(g[:nu], t.view(-1)[:nu], 1.0)
-        else:
-            g.zero_()
-        if not hasattr(self, "_comm_stream"):
-            self._comm_stream, self._comm_event = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
-        self._comm_event.record(torch.cuda.current_stream())
-        self._comm_stream.wait_event(self._comm_event)
-        with torch.cuda.stream(self._comm_stream):
-            return dist.all_reduce(g[:ne], async_op=True)
-
-    def _exchange_tail_grads(self, work, n_contrib: Optional[int]):
-        import torch.distributed as dist
-        ne = self.N * self.D
-        dist.all_reduce(self.P.grad[ne:])
-        work.wait()  # the current stream waits for bucket 1
-        torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self.P.grad.mul_(1.0 / float(n_contrib or self.world))
-
-    def allreduce_grads(self, contributing: bool, n_contrib: Optional[int] = None):
-        """Data-parallel step: average the local gradients of the replicas that hold a minibatch (RCCL all-reduce on the
-        flat gradient buffer).  A replica without a minibatch in this global step contributes zeros."""
-        work = self._exchange_embedding_grads_async(n_contrib, contributing)  # same two collectives as the overlapped path of _step_planned
-        self._exchange_tail_grads(work, n_contrib)
-
-    def apply_adam(self, fold_extras: bool = True):
+    def apply_adam(self):
         P, U, D = self.P, self.U, self.D
         P.step += 1
         ne = self.N * D
-        extra = [t for t in self.T] if fold_extras else []
+        extra = list(self.T)
         ops.adam_step(P.data[:ne], P.grad[:ne], P.m[:ne], P.v[:ne], self.lr, P.step, extra=extra, extra_n=[U * D] * len(extra),
                       l2_coef=2.0 * self.hp["reg"])
         ops.adam_step(P.data[ne:], P.grad[ne:], P.m[ne:], P.v[ne:], self.lr, P.step)
@@ -435,13 +383,17 @@ class DiffusionEngine:
         self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
         self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
+        self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
         self.dpre16, self.doutT16, self.hT16, self.dpreT16 = zb(B_max, H), zb(items, Bp8), zb(H, Bp8), zb(H, Bp8)
         self.xcatT16, self.w1T16, self.w2T16 = zb(Kp, Bp8), zb(Kp, H), zb(H, Kp)
         self._ws = None  # per-modality workspaces of the batched training step (allocated on first use)
         self.rng_step = 0
-        self.world, self.rank = 1, 0
+        # user-sharded training (diffmm_amd/sharded.py): every replica holds the rows of a minibatch whose users it owns; the Denoise
+        # weights are replicated and their gradients SUMMED over the replicas (the loss scale already carries 1 / global batch)
+        self.shard_world, self.shard_rank, self.shard_group = 1, 0, None
+        self.t_gen: Optional[torch.Generator] = None  # timestep draws (per-replica generator when sharded; torch's global one otherwise)
 
     def load_reference_state(self, m: int, sd: Dict[str, Tensor]):
         t = {k: torch.as_tensor(v).float() for k, v in sd.items()}
@@ -653,43 +605,64 @@ class DiffusionEngine:
             ops.gemm(w["dgate"][:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=1, split_k=32)
             ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))
 
+    def reg_term(self, i_embs: Tensor) -> float:
+        """l2_reg_loss(reg, [i_embs]) * reg (Model.py:421,425) as a host value.  i_embs does not move during the diffusion phase (only the
+        Denoise optimisers step there, Main.py:187-192), so the trainer computes this once per epoch."""
+        reg = float(self.hp["reg"])
+        if not hasattr(self, "_reg_buf"):
+            self._reg_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            self._reg_scratch = torch.zeros(int(L.lib().dmm_sumsq_scratch(i_embs.numel())), dtype=torch.float32, device=self.dev)
+        ops.sumsq(i_embs.reshape(-1), 1.0, self._reg_buf, self._reg_scratch)
+        return reg * reg * float(self._reg_buf)
+
     def train_step(self, x0: Tensor, feats: Sequence[Tensor], i_embs: Tensor, t: Optional[Sequence[Tensor]] = None,
-                   noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True, n_contrib: Optional[int] = None) -> List[float]:
-        """One iteration of Main.py:145-192 over all modalities.  `feats` are the projected, detached modality features."""
+                   noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True, reg_term: Optional[float] = None,
+                   global_rows: Optional[int] = None) -> List[float]:
+        """One iteration of Main.py:145-192 over all modalities.  `feats` are the projected, detached modality features.
+        User-sharded (shard_world > 1): x0 holds only the minibatch rows of the users this replica owns (possibly none) and
+        `global_rows` is the size of the whole minibatch; the per-modality loss means and the gradients are summed over the replicas."""
         B, M = x0.shape[0], self.M
-        x0p = self._set_x0(x0)
-        reg = self.hp["reg"]
-        reg_term = float(reg) * float(reg) * float((i_embs.double() ** 2).sum())  # l2_reg_loss(reg,[i_embs]) * reg (Model.py:421,425) -- host value
-        ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32)).to(torch.int32) for m in range(M)]
-        if precision == 1:  # the modalities' large GEMMs go out as one batched launch each (enough 256 x 256 tiles to fill the chip)
-            self._forward_batched(x0p, ts, noise, feats, i_embs, reg_term)
+        Bg = int(global_rows) if global_rows is not None else B
+        if reg_term is None:
+            reg_term = self.reg_term(i_embs)
+        sums = torch.zeros(M, dtype=torch.float64, device=self.dev)
+        if B:
+            x0p = self._set_x0(x0)
+            ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32, generator=self.t_gen)).to(torch.int32)
+                  for m in range(M)]
+            if precision == 1:  # the modalities' large GEMMs go out as one batched launch each (enough 256 x 256 tiles to fill the chip)
+                self._forward_batched(x0p, ts, noise, feats, i_embs, reg_term)
+            else:
+                for m in range(M):
+                    self.loss_forward(m, x0p, ts[m], noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
+            sums = torch.stack([self.act[m]["loss"][:B].sum() for m in range(M)])
+        if self.shard_world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=self.shard_group)
+        means = (sums / Bg).tolist()  # ONE host read per iteration (the reference syncs per modality: .item(), Main.py:155,159,172)
+        total = sum(means)
+        if B:
+            if precision == 1:
+                self._backward_batched(x0p, feats, reg_term, 1.0 / (Bg * total))
+            else:
+                for m in range(M):
+                    self.loss_backward(m, x0p, feats[m], reg_term, 1.0 / (Bg * total), precision)
         else:
             for m in range(M):
-                self.loss_forward(m, x0p, ts[m], noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
-        means = [float(self.act[m]["loss"][:B].mean()) for m in range(M)]  # the reference syncs here too (.item(), Main.py:155,159,172)
-        total = sum(means)
-        if precision == 1:
-            self._backward_batched(x0p, feats, reg_term, 1.0 / (B * total))
-        for m in range(M):
-            if precision != 1:
-                self.loss_backward(m, x0p, feats[m], reg_term, 1.0 / (B * total), precision)
-            if update:
-                self.reduce_and_step(m, contributing=True, n_contrib=n_contrib)
+                ops.zero_(self.P[m].grad)
+        if update:
+            for m in range(M):
+                self.reduce_and_step(m)
         self.rng_step += 1
         return means
 
-    def reduce_and_step(self, m: int, contributing: bool, n_contrib: Optional[int] = None):
+    def reduce_and_step(self, m: int):
         P = self.P[m]
-        if self.world > 1:
-            from . import dist as D_
-            D_.allreduce_mean_(P.grad, contributing, n_contrib or self.world)
+        if self.shard_world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(P.grad, group=self.shard_group)  # sum: every replica's rows carry the 1 / (global batch) scale already
         P.step += 1
         ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step)
-
-    def idle_step(self, n_contrib: int):
-        """A replica with no user batch in this global step still joins the gradient all-reduces."""
-        for m in range(self.M):
-            self.reduce_and_step(m, contributing=False, n_contrib=n_contrib)
 
     # -- reverse chain (generate_view, Model.py:300-322) ------------------------------------------------
     def _refresh_bf16_weights(self, m: int):
@@ -821,7 +794,6 @@ class DiffusionEngine:
         B, I = x0.shape[0], self.I
         if not hasattr(self, "_xT"):
             self._xT = torch.zeros(self.chain_rows, self.Kp, dtype=torch.float32, device=self.dev)
-            self._xT_calls = 0
         ops.noised_start(x0, noise, float(np.float32(self.sched["sqrt_alphas_cumprod"][sampling_step - 1])),
                          float(np.float32(self.sched["sqrt_one_minus_alphas_cumprod"][sampling_step - 1])), self._xT[:B], I,
                          seed=self.hp.get("seed", 1818) + 1,  # its own Philox stream, apart from the training draws
@@ -832,17 +804,18 @@ class DiffusionEngine:
     def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1,
                       sampling_step: int = 0) -> List[Tensor]:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
-        int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]]).
+        int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]]).  The ids in `user_batches`
+        index deg_ptr and are what `dense_rows` receives (a user-sharded replica passes LOCAL ids and maps them itself).
         sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
-        if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow, evenly over the replicas
+        if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow
             all_users = torch.cat([b.reshape(-1) for b in user_batches])
             n = int(all_users.numel())
-            n_chunks = self.world * max(1, -(-n // (self.world * self.chain_rows)))
-            per = -(-n // n_chunks)
+            n_chunks = max(1, -(-n // self.chain_rows))
+            per = max(1, -(-n // n_chunks))
             user_batches = [all_users[s:s + per] for s in range(0, n, per)]
-        for i, ub in enumerate(user_batches):
-            if i % self.world != self.rank:  # user chunks are sharded over the replicas (dist.shard_owner)
+        for ub in user_batches:
+            if ub.numel() == 0:
                 continue
             x0 = dense_rows(ub)
             if precision == 1 and sampling_step == 0:
@@ -853,8 +826,4 @@ class DiffusionEngine:
             for m in range(self.M):
                 den = self.generate_view(m, self.noised_start(m, x0, sampling_step) if sampling_step else x0, precision)
                 ops.topk_rows(den, ub.to(torch.int32), deg_ptr, out[m], self.I)
-        if self.world > 1:  # every edge slot is written by exactly one replica: a sum all-reduce is an all-gather
-            from . import dist as D_
-            for o in out:
-                D_.allgather_disjoint_(o)
         return out

@@ -291,3 +291,72 @@ class DeviceGraphBuilder:
             adjs.append(Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr, col=col, val=val, tasks=tasks, n_head_tasks=head, n_partial_blocks=n_partial,
                                   fix=fix[:n_fix] if n_partial else None))
         return adjs
+
+
+class ShardedGraphBuilder:
+    """DeviceGraphBuilder for ONE replica of the user-sharded layout (csrc/graph_build.hip: dmm_graph_build_shard): builds the
+    replica's local block over [own users ; all items] from the top-k item lists of its own users.  The item degrees that scale the values
+    are global -- every replica counts how often its users picked each item (dmm_count_items), ONE integer all-reduce of the [M, I] counts
+    sums them ("item-side degrees need one I-length integer all-reduce per modality") -- so the blocks carry the full graph's values and
+    add up to it, each item self loop on exactly one replica (i % world == rank)."""
+
+    def __init__(self, user_ptr_local: torch.Tensor, users_local: int, users_global: int, items: int, D: int, rank: int, world: int, group=None,
+                 task_len: int = TASK_LEN):
+        import ctypes as C
+        from . import _lib as L
+        self.nu, self.U, self.I, self.D, self.task_len = users_local, users_global, items, D, task_len
+        self.rank, self.world, self.group = rank, world, group
+        self.n = users_local + items
+        self.dev = user_ptr_local.device
+        up = user_ptr_local.long()
+        self.E = int(up[-1])
+        self.user_ptr32 = up.to(torch.int32).contiguous()
+        self.edge_user = torch.repeat_interleave(torch.arange(users_local, device=self.dev, dtype=torch.int32), (up[1:] - up[:-1]),
+                                                 output_size=self.E).contiguous()
+        with np.errstate(divide="ignore"):  # an item can be picked by every user of the FULL graph: the table covers the global degrees
+            self.dinv = torch.from_numpy(np.power(np.arange(users_global + items + 2, dtype=np.float64), -0.5)).to(self.dev)
+        nu_q = max(1, users_local)  # the C ABI wants U > 0; a replica without users still holds the item rows
+        sb, tc, fc = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().dmm_graph_build_scratch_bytes(nu_q, items, self.E, D, C.byref(sb)), "dmm_graph_build_scratch_bytes")
+        L.check(L.lib().dmm_graph_build_task_capacity(nu_q, items, self.E, D, task_len, C.byref(tc), C.byref(fc)), "dmm_graph_build_task_capacity")
+        self.scratch = torch.empty(sb.value, dtype=torch.uint8, device=self.dev)
+        self.task_cap, self.fix_cap = int(tc.value), int(fc.value)
+        self.nnz_cap = 2 * self.E + self.n
+
+    def build_all(self, item_lists, validate: bool = False):
+        from . import _lib as L
+        if self.nu == 0:
+            raise NotImplementedError("a replica without users: use fewer replicas than users")
+        dev, n = self.dev, self.n
+        M = len(item_lists)
+        counts = torch.zeros((M, self.I), dtype=torch.int32, device=dev)
+        for i, item_idx in enumerate(item_lists):
+            if item_idx.dtype != torch.int32 or not item_idx.is_contiguous() or item_idx.numel() < self.E:
+                raise ValueError("ShardedGraphBuilder.build_all: item_idx must be a contiguous int32 tensor with one entry per local edge")
+            L.call("dmm_count_items", L.ptr(item_idx), self.E, self.I, L.ptr(counts[i]), L.stream())
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(counts, group=self.group)
+        metas = torch.zeros((M, 8), dtype=torch.int32, device=dev)
+        outs = []
+        for i, item_idx in enumerate(item_lists):
+            rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            col = torch.empty(self.nnz_cap, dtype=torch.int32, device=dev)
+            val = torch.empty(self.nnz_cap, dtype=torch.float32, device=dev)
+            tasks = torch.empty((self.task_cap, 4), dtype=torch.int32, device=dev)
+            fix = torch.empty((self.fix_cap, 4), dtype=torch.int32, device=dev)
+            L.call("dmm_graph_build_shard", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.nu, self.I, self.E, self.D, self.task_len,
+                   L.ptr(self.dinv), L.ptr(counts[i]), self.world, self.rank, L.ptr(rowptr), L.ptr(col), L.ptr(val), L.ptr(tasks), L.ptr(fix),
+                   L.ptr(metas[i]), L.ptr(self.scratch), L.stream())
+            outs.append((rowptr, col, val, tasks, fix))
+        adjs = []
+        for (rowptr, col, val, tasks, fix), m in zip(outs, metas.tolist()):
+            n_tasks, head, n_partial, n_fix, nnz_d = m[:5]
+            if nnz_d > self.nnz_cap or n_tasks > self.task_cap or n_fix > self.fix_cap:
+                raise RuntimeError(f"dmm_graph_build_shard: inconsistent sizes (nnz {nnz_d}/{self.nnz_cap}, tasks {n_tasks}/{self.task_cap}, fix {n_fix}/{self.fix_cap})")
+            tasks = tasks[:n_tasks]
+            if validate:
+                check_plan(rowptr.cpu().numpy().astype(np.int64), tasks.cpu().numpy(), self.D)
+            adjs.append(Adjacency(n=n, nnz=nnz_d, D=self.D, rowptr=rowptr, col=col[:nnz_d], val=val[:nnz_d], tasks=tasks, n_head_tasks=head,
+                                  n_partial_blocks=n_partial, fix=fix[:n_fix] if n_partial else None))
+        return adjs

@@ -1,5 +1,6 @@
-"""bench.py end to end on a small synthetic graph: the JSON contract of the driver, and the N = 2 path (two replicas sharing this GPU
-over gloo: minibatches dealt round-robin, gradients averaged, rebuild sharded) ending with bit-identical replicas."""
+"""bench.py end to end on a small synthetic graph: the JSON contract of the driver, and the N = 2 path (two user-sharded replicas sharing
+this GPU over gloo: SpMM item partials all-reduced, minibatch rows split by owner, own-user rebuild) ending with bit-identical replicated
+parameters."""
 import json
 import os
 import subprocess
@@ -39,5 +40,5 @@ def test_two_replicas_on_one_gpu_stay_identical():
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     j = _json_line(p.stdout)
-    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["scaling"] == "strong"
-    assert j["replicas_identical"] is True
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "user-shard2" and j["scaling"] == "strong"
+    assert j["replicated_params_identical"] is True

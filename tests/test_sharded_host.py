@@ -1,0 +1,127 @@
+"""Host logic of the user-sharded layout (diffmm_amd/sharded.py) -- runs without a GPU:
+  * ShardLayout: contiguous user ranges, ownership lookup (device op == numpy), item slices partition the items;
+  * sort_batch_by_owner: a stable permutation of the minibatch whose segments are exactly each replica's triples;
+  * the exchange algebra of one sharded SpMM launch + item-row epilogue, emulated with scipy over 2 gloo processes: own user rows need
+    no communication, the all-reduced raw item partials followed by the epilogue reproduce the unsharded epilogue;
+  * the row-split diffusion step: per-replica sums over disjoint rows, scaled by the GLOBAL batch, add up to the single-process mean."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+from diffmm_amd import graph, shard, synth
+from diffmm_amd.sharded import ShardLayout, sort_batch_by_owner
+
+
+@pytest.mark.parametrize("name,world", [("toy", 1), ("toy", 3), ("mid", 2), ("mid", 8), ("tiktok", 8)])
+def test_layout_partitions_users_and_items(name, world):
+    g = synth.named(name)
+    lays = [ShardLayout.make(g.trn_rows, g.users, g.items, world, r) for r in range(world)]
+    assert lays[0].u0 == 0 and lays[-1].u1 == g.users
+    assert all(a.u1 == b.u0 for a, b in zip(lays, lays[1:])) and sum(l.nu for l in lays) == g.users
+    sl = [l.item_slice() for l in lays]
+    assert sl[0][0] == 0 and sl[-1][1] == g.items and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+    users = torch.arange(g.users)
+    own = lays[0].owner_of(users).numpy()
+    assert np.array_equal(own, lays[0].owner_of_np(np.arange(g.users)))
+    for r, l in enumerate(lays):
+        assert (own[l.u0:l.u1] == r).all()
+    x = torch.arange((g.users + g.items) * 2, dtype=torch.float32).view(-1, 2)
+    loc = lays[-1].local_rows(x)
+    assert loc.shape[0] == lays[-1].n_local and torch.equal(loc[lays[-1].nu:], x[g.users:]) and torch.equal(loc[:lays[-1].nu], x[lays[-1].u0:lays[-1].u1])
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_sort_batch_by_owner_is_a_stable_partition(world):
+    g = synth.named("mid")
+    lay = ShardLayout.make(g.trn_rows, g.users, g.items, world, 0)
+    rng = np.random.default_rng(5)
+    e = rng.integers(0, g.nnz, size=257)
+    users, pos = torch.from_numpy(g.trn_rows[e].astype(np.int32)), torch.from_numpy(g.trn_cols[e].astype(np.int32))
+    neg = torch.from_numpy(rng.integers(0, g.items, size=257).astype(np.int32))
+    su, sp_, sn, bounds = sort_batch_by_owner(lay, users, pos, neg)
+    b = bounds.numpy()
+    assert b[0] == 0 and b[-1] == 257 and (np.diff(b) >= 0).all()
+    trip = sorted(zip(users.tolist(), pos.tolist(), neg.tolist()))
+    assert sorted(zip(su.tolist(), sp_.tolist(), sn.tolist())) == trip, "a permutation of the triples"
+    own = lay.owner_of_np(su.numpy())
+    for r in range(world):
+        assert (own[b[r]:b[r + 1]] == r).all(), "segment r holds exactly replica r's triples"
+    # stable: inside a segment the triples keep their order of appearance in the batch
+    orig_pos = {}
+    for i, t in enumerate(zip(users.tolist(), pos.tolist(), neg.tolist())):
+        orig_pos.setdefault(t, []).append(i)
+    last = -1
+    for r in range(world):
+        last = -1
+        seen = {}
+        for t in zip(su[b[r]:b[r + 1]].tolist(), sp_[b[r]:b[r + 1]].tolist(), sn[b[r]:b[r + 1]].tolist()):
+            k = seen.get(t, 0)
+            seen[t] = k + 1
+            assert orig_pos[t][k] > last
+            last = orig_pos[t][k]
+
+
+def _epilogue(y, c1, noise, alpha, beta, nd):
+    """y = alpha acc + beta c1 ; y_pert = y + sign(y) * normalize(noise) * nd  (include/diffmm_hip.h: dmm_spmm_problem)"""
+    y = alpha * y + beta * c1
+    nrm = np.maximum(np.linalg.norm(noise, axis=1, keepdims=True), 1e-12)
+    return y, y + np.sign(y) * noise / nrm * nd
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth.named("mid")
+        U, I, d = g.users, g.items, 8
+        rng = np.random.default_rng(3)
+        X, C1, NZ = (rng.standard_normal((U + I, d)) for _ in range(3))  # the same on every rank (seeded)
+        lay = ShardLayout.make(g.trn_rows, U, I, world, rank)
+        rp, col, val = shard.local_block_csr(g.trn_rows, g.trn_cols, U, I, lay.u0, lay.u1, rank, world)
+        nu = lay.nu
+        A = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(nu + I, nu + I))
+        loc = lambda t: np.concatenate([t[lay.u0:lay.u1], t[U:]])
+        acc = A @ loc(X)
+        # own user rows: finished in place; item rows: raw partials -> all-reduce -> epilogue
+        yu, ypu = _epilogue(acc[:nu], loc(C1)[:nu], loc(NZ)[:nu], 1.5, 0.5, 0.7)
+        raw = torch.from_numpy(acc[nu:].copy())
+        tdist.all_reduce(raw)
+        yi, ypi = _epilogue(raw.numpy(), C1[U:], NZ[U:], 1.5, 0.5, 0.7)
+        # row-split diffusion step: loss sums over the own rows of a global batch, gradient scaled by 1 / (global rows * total)
+        batch = np.random.default_rng(9).permutation(U)[:64]
+        own = batch[(batch >= lay.u0) & (batch < lay.u1)]
+        per_row = np.square(X[own]).sum(1)  # stand-in for the per-row loss
+        s = torch.tensor([per_row.sum()], dtype=torch.float64)
+        tdist.all_reduce(s)
+        mean = float(s) / len(batch)
+        gpart = torch.from_numpy((2 * X[own]).sum(0) / (len(batch) * mean))
+        tdist.all_reduce(gpart)
+        out[rank] = (lay.u0, lay.u1, yu, ypu, yi, ypi, mean, gpart.numpy())
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_two_replicas_reproduce_epilogue_and_row_split_step():
+    world, port = 2, 32500 + (os.getpid() % 2000)
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g = synth.named("mid")
+    U, I, d = g.users, g.items, 8
+    rng = np.random.default_rng(3)
+    X, C1, NZ = (rng.standard_normal((U + I, d)) for _ in range(3))
+    rp, col, val = graph.normalized_bipartite_csr(g.trn_rows, g.trn_cols, U, I)
+    A = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(U + I, U + I))
+    y, yp = _epilogue(A @ X, C1, NZ, 1.5, 0.5, 0.7)
+    batch = np.random.default_rng(9).permutation(U)[:64]
+    mean = np.square(X[batch]).sum(1).mean()
+    grad = (2 * X[batch]).sum(0) / (len(batch) * mean)
+    for r in range(world):
+        u0, u1, yu, ypu, yi, ypi, m, gsum = out[r]
+        assert np.allclose(yu, y[u0:u1], rtol=1e-12, atol=1e-12) and np.allclose(ypu, yp[u0:u1], rtol=1e-12, atol=1e-12)
+        assert np.allclose(yi, y[U:], rtol=1e-12, atol=1e-12) and np.allclose(ypi, yp[U:], rtol=1e-12, atol=1e-12)
+        assert abs(m - mean) <= 1e-12 * mean and np.allclose(gsum, grad, rtol=1e-12, atol=1e-12)
