@@ -152,6 +152,13 @@ class Denoise:
     def state_dict(self):
         return self.engine.state_dict(self.slot)
 
+    def grads(self):
+        """Gradients the last backward pass left for this Denoise (views into the engine's flat buffer, reference parameter names)."""
+        P = self.engine.P[self.slot]
+        g = {k: P.g(k) for k in P.names}
+        g["in_layers.0.weight"] = g["in_layers.0.weight"][:, : self.engine.I + self.engine.te]
+        return g
+
 
 class GaussianDiffusion:
     """Noise schedule + forward / reverse process arithmetic (Model.py:222-428)."""
@@ -190,18 +197,33 @@ class GaussianDiffusion:
     def SNR(self, t: Tensor) -> Tensor:
         return self._snr[t.long()]
 
+    def _f32_table(self, name: str) -> Tensor:
+        """fp32 device copy of a schedule table (the reference extracts with .float(), Model.py:352)."""
+        cache = self.__dict__.setdefault("_f32_tables", {})
+        if name not in cache:
+            cache[name] = getattr(self, name).float().contiguous()
+        return cache[name]
+
     def forward_cal_xt(self, x_0: Tensor, timesteps: Tensor, noise: Optional[Tensor] = None) -> Tensor:
+        """x_t = sqrt(alpha_bar_t) x_0 + sqrt(1 - alpha_bar_t) noise (Model.py:324-341) on dmm_rows_axpby; noise=None draws the
+        reference's default noise sign(x_0) * normalize(randn) with dmm_noised_start (in-kernel Philox)."""
+        x_0 = x_0.contiguous().float()
+        t32 = timesteps.to(torch.int32).contiguous()
         if noise is None:
-            noise = torch.sign(x_0) * torch.nn.functional.normalize(torch.randn_like(x_0))
-        a = self._extract_into_tensor(self.sqrt_alphas_cumprod, timesteps, x_0.shape)
-        b = self._extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, timesteps, x_0.shape)
-        return a * x_0 + b * noise
+            self._default_noise_calls = getattr(self, "_default_noise_calls", 0) + 1
+            noise = torch.empty_like(x_0)
+            ops.noised_start(x_0, None, 0.0, 1.0, noise, x_0.shape[1], seed=int(self.config.base.seed) + 2,
+                             offset=self._default_noise_calls * x_0.shape[0] * ((x_0.shape[1] + 3) // 4))
+        return ops.rows_axpby(x_0, noise.contiguous().float(), t32, self._f32_table("sqrt_alphas_cumprod"), self._f32_table("sqrt_one_minus_alphas_cumprod"))
 
     def p_mean_variance(self, denoise: Denoise, x_t: Tensor, timesteps: Tensor, noise: Optional[Tensor] = None):
-        pred = denoise.forward(x_t, timesteps)
-        c1 = self._extract_into_tensor(self.posterior_mean_coef1, timesteps, x_t.shape)
-        c2 = self._extract_into_tensor(self.posterior_mean_coef2, timesteps, x_t.shape)
-        return c1 * pred + c2 * x_t, self._extract_into_tensor(self.posterior_log_variance_clipped, timesteps, x_t.shape)
+        """(posterior mean, clipped log-variance) of Model.py:357-378: Denoise.forward without modal features, then
+        coef1[t] * pred + coef2[t] * x_t (dmm_rows_axpby)."""
+        x_t = x_t.contiguous().float()
+        t32 = timesteps.to(torch.int32).contiguous()
+        pred = denoise.forward(x_t, t32)
+        mean = ops.rows_axpby(pred, x_t, t32, self._f32_table("posterior_mean_coef1"), self._f32_table("posterior_mean_coef2"))
+        return mean, self._extract_into_tensor(self.posterior_log_variance_clipped, timesteps, x_t.shape)
 
     def generate_view(self, model: Denoise, x_start: Tensor, sampling_step: int) -> Tensor:
         if sampling_step != 0:
@@ -209,15 +231,47 @@ class GaussianDiffusion:
             x_start = self.forward_cal_xt(x_start, ts)
         return model.engine.generate_view(model.slot, x_start.contiguous(), precision=model.precision).clone()
 
-    def training_losses(self, model: Denoise, x_start: Tensor, i_embs: Tensor, modal_feat: Tensor) -> Tensor:
-        """Per-row loss vector (float64, like the reference).  Forward only: the optimiser step of the diffusion phase is
-        DiffusionEngine.train_step, which also needs the other modalities' losses (Main.py:175-176)."""
+    def training_losses(self, model: Denoise, x_start: Tensor, i_embs: Tensor, modal_feat: Tensor, timesteps: Optional[Tensor] = None,
+                        noise: Optional[Tensor] = None) -> Tensor:
+        """Per-row loss vector (float64, like the reference; Model.py:385-428).  Differentiable for a UNIFORM upstream gradient -- the
+        reference only ever reduces it with .mean() and scalar factors (Main.py:155-176): `.backward()` then leaves the Denoise
+        gradients in `model.grads()` (the engine's flat gradient buffer) and returns d/d i_embs through autograd; a non-uniform
+        upstream gradient raises.  (The training loop itself uses DiffusionEngine.train_step, which batches the modalities.)
+        `timesteps` / `noise` (optional) replace the random draws."""
+        B = x_start.shape[0]
+        t = (torch.randint(0, self.steps, (B,), device=x_start.device) if timesteps is None else timesteps).to(torch.int32).contiguous()
+        return _TrainingLosses.apply(i_embs, self, model, x_start, modal_feat, t, noise)
+
+
+class _TrainingLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, i_embs: Tensor, gd: "GaussianDiffusion", model: Denoise, x_start: Tensor, modal_feat: Tensor, t: Tensor, noise):
         E, m, B = model.engine, model.slot, x_start.shape[0]
-        t = torch.randint(0, self.steps, (B,), device=x_start.device, dtype=torch.int32)
-        reg = float(self.config.train.reg)
-        reg_term = reg * reg * float((i_embs.double() ** 2).sum())
-        E.loss_forward(m, E._set_x0(x_start.contiguous()), t, None, modal_feat.contiguous(), i_embs.contiguous(), reg_term, model.precision)
+        ie, feat = i_embs.detach().contiguous().float(), modal_feat.detach().contiguous().float()
+        x0p = E._set_x0(x_start.detach().contiguous().float())
+        reg_term = E.reg_term(ie)
+        E.loss_forward(m, x0p, t, noise.contiguous().float() if noise is not None else None, feat, ie, reg_term, model.precision)
+        ctx.args = (E, m, B, ie, feat, reg_term, model.precision)
         return E.act[m]["loss"][:B].clone()
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        E, m, B, ie, feat, reg_term, precision = ctx.args
+        g0 = float(gout[0])
+        if not bool((gout == gout[0]).all()):
+            raise NotImplementedError("training_losses: only uniform upstream gradients (loss.mean(), scalar factors) are supported")
+        x0p = E.x0p[:B]  # still holds x_start: nothing ran on the engine between forward and backward
+        E.loss_backward(m, x0p, feat, reg_term, g0, precision)
+        # d/d i_embs: through ui = x_0 @ i_embs in the cosine term (symmetric in um / ui: the same kernel with the roles swapped) and
+        # through the reg^2 * ||i_embs||^2 term every row carries
+        a = E.act[m]
+        dui = torch.empty_like(E.ui[:B])
+        scratch = torch.empty(B, dtype=torch.float64, device=ie.device)
+        ops.diff_loss(a["out"][:B], x0p, a["w"], E.ui[:B], a["um"][:B], E.I, E.hp["sim_weight"], reg_term, g0, scratch, None, dui)
+        g_ie = ops.gemm(x0p, dui, trans_a=True, precision=3, M=E.I)
+        reg = float(E.hp["reg"])
+        g_ie = g_ie + (2.0 * reg * reg * g0 * B) * ie
+        return g_ie, None, None, None, None, None, None
 
 
 def denoise_dims(config: Config):

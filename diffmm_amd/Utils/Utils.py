@@ -17,18 +17,21 @@ from .. import ops
 
 class _InfoNCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v1: Tensor, v2: Tensor, idx: Tensor, temperature: float):
+    def forward(ctx, v1: Tensor, v2: Tensor, idx: Tensor, temperature: float, b_cos: bool):
         v1c, v2c, idx32 = v1.contiguous(), v2.contiguous(), idx.to(torch.int32).contiguous()
         B, D, dev = idx32.shape[0], v1c.shape[1], v1c.device
         slots = ops.Slots([(v1c, idx32, None), (v2c, idx32, None)])
         terms = ops.make_terms([(0, 1, float(temperature), 1.0)])
         zhat, nrm = torch.empty(2, B, D, device=dev), torch.empty(2, B, device=dev)
         lse, rl, out = torch.empty(1, B, device=dev), torch.empty(1, B, device=dev), torch.empty(1, device=dev)
-        ops.gather_normalize(slots, B, D, zhat, nrm)
+        if b_cos:
+            ops.gather_normalize(slots, B, D, zhat, nrm)
+        else:  # raw dot products (Utils.py:71 skipped): the gathered rows enter the logits as they are
+            ops.gather_rows(slots, B, D, None, zhat)
         ops.infonce_fwd(zhat, terms, 1, B, D, lse, rl)
         ops.segment_sum(rl, 1, B, 1.0, out)
         ctx.save_for_backward(v1c, v2c, idx32, zhat, nrm, lse)
-        ctx.temperature = float(temperature)
+        ctx.temperature, ctx.b_cos = float(temperature), bool(b_cos)
         return out[0]
 
     @staticmethod
@@ -39,18 +42,21 @@ class _InfoNCE(torch.autograd.Function):
         dz = torch.zeros_like(zhat)
         terms = ops.make_terms([(0, 1, ctx.temperature, 1.0)])
         ops.infonce_bwd(zhat, lse, terms, 1, B, D, dz)
-        ops.scatter_normalize_bwd(ops.Slots([(v1c, idx32, g1), (v2c, idx32, g2)]), B, D, zhat, nrm, dz)
-        return g1 * gout, g2 * gout, None, None
+        slots = ops.Slots([(v1c, idx32, g1), (v2c, idx32, g2)])
+        if ctx.b_cos:
+            ops.scatter_normalize_bwd(slots, B, D, zhat, nrm, dz)
+        else:
+            ops.scatter_add_rows(slots, B, D, None, dz)
+        return g1 * gout, g2 * gout, None, None, None
 
 
 def InfoNCE(batch_view1: Tensor, batch_view2: Tensor, idx: Tensor, temperature: float, b_cos: bool = True) -> Tensor:
-    """-mean(diag(log_softmax(normalize(v1[idx]) normalize(v2[idx])^T / temperature))) (Utils.py:57-75)."""
+    """-mean(diag(log_softmax(normalize(v1[idx]) normalize(v2[idx])^T / temperature))) (Utils.py:57-75); b_cos=False skips the
+    normalisation (Utils.py:71-72)."""
     if batch_view1.shape[1] != batch_view2.shape[1]:
         raise ValueError(f"InfoNCE expected the same shape for two views. But got view1.shape={batch_view1[idx].shape} and "
                          f"view2.shape={batch_view2[idx].shape}.")
-    if not b_cos:
-        raise NotImplementedError("the HIP InfoNCE kernel always cosine-normalises (b_cos=True is the only mode the reference uses)")
-    return _InfoNCE.apply(batch_view1, batch_view2, idx, temperature)
+    return _InfoNCE.apply(batch_view1, batch_view2, idx, temperature, b_cos)
 
 
 class _BPR(torch.autograd.Function):

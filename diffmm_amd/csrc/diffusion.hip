@@ -69,6 +69,20 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
   }
 }
 
+// out[b, :] = a[t_b] * x[b, :] + c[t_b] * y[b, :] with per-row timesteps: GaussianDiffusion.forward_cal_xt with explicit noise
+// (Model.py:339-341: x = x_0, y = noise, tables sqrt(alpha_bar), sqrt(1 - alpha_bar)) and the posterior mean of p_mean_variance
+// (Model.py:375: x = Denoise output, y = x_t, tables posterior_mean_coef1 / coef2) for callers of the reference-named API.
+__global__ __launch_bounds__(256) void rows_axpby_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ y, long long ldy,
+                                                         const int32_t* __restrict__ t, const float* __restrict__ a, const float* __restrict__ c,
+                                                         float* __restrict__ out, long long ldo, int I) {
+  const int b = blockIdx.x;
+  const float ab = a[t[b]], cb = c[t[b]];
+  const float* __restrict__ xr = x + (long long)b * ldx;
+  const float* __restrict__ yr = y + (long long)b * ldy;
+  float* __restrict__ o = out + (long long)b * ldo;
+  for (int j = threadIdx.x; j < I; j += 256) o[j] = ab * xr[j] + cb * yr[j];
+}
+
 // Start of a reverse chain with sampling_step > 0 (GaussianDiffusion.generate_view -> forward_cal_xt without a noise argument,
 // Model.py:310-313,336-341): x_T = sqrt_ac[s] * x_0 + sqrt_1mac[s] * sign(x_0) * randn / max(||randn_row||, 1e-12) -- the noise is
 // row-normalised over ALL I columns and then kept only where x_0 is non-zero.  One workgroup per row; the row's normals are drawn
@@ -581,6 +595,15 @@ extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* nois
   hipLaunchKernelGGL(qsample_temb_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)ldx0, noise, t, sqrt_ac, sqrt_1mac, w_emb,
                      b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out);
   DMM_LAUNCH_CHECK("dmm_qsample_temb");
+  return 0;
+}
+
+extern "C" int dmm_rows_axpby(const float* x, int64_t ldx, const float* y, int64_t ldy, const int32_t* t, const float* a_table, const float* c_table,
+                              float* out, int64_t ldo, int B, int I, void* stream) {
+  DMM_CHECK_ARG(x && y && t && a_table && c_table && out && B > 0 && I > 0 && ldx >= I && ldy >= I && ldo >= I, "dmm_rows_axpby: bad arguments");
+  hipLaunchKernelGGL(rows_axpby_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, y, (long long)ldy, t, a_table, c_table, out,
+                     (long long)ldo, I);
+  DMM_LAUNCH_CHECK("dmm_rows_axpby");
   return 0;
 }
 

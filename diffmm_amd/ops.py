@@ -373,6 +373,18 @@ def qsample_temb(x0: Optional[Tensor], noise: Optional[Tensor], t: Tensor, sqrt_
                                      offset, L.ptr(eps_out), L.stream())
 
 
+def rows_axpby(x: Tensor, y: Tensor, t: Tensor, a_table: Tensor, c_table: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[b] = a_table[t_b] * x[b] + c_table[t_b] * y[b]  (fp32 tables on the device; x, y, out row-strided [B, I] views)."""
+    B, I = x.shape
+    out = torch.empty((B, I), dtype=torch.float32, device=x.device) if out is None else out
+    for nm, v in (("x", x), ("y", y), ("out", out)):
+        if v.dtype != torch.float32 or v.stride(1) != 1 or tuple(v.shape) != (B, I):
+            raise ValueError(f"rows_axpby {nm}: need fp32 [{B}, {I}] with unit inner stride")
+    L.call("dmm_rows_axpby", L.ptr(x), x.stride(0), L.ptr(y), y.stride(0), L.ptr(_i32c(t, "t")), L.ptr(_f32c(a_table, "a_table")),
+           L.ptr(_f32c(c_table, "c_table")), L.ptr(out), out.stride(0), B, I, L.stream())
+    return out
+
+
 def temb_bwd(t: Tensor, dxcat: Tensor, I: int, te: int, dw: Tensor, db: Tensor) -> None:
     L.call("dmm_temb_bwd", L.ptr(t), L.ptr(dxcat), dxcat.stride(0), I, te, t.shape[0], L.ptr(dw), L.ptr(db), L.stream())
 

@@ -233,6 +233,11 @@ int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const in
                      const float* sqrt_1mac, const float* w_emb /*[te,te]*/, const float* b_emb /*[te]*/, int te,
                      float* xcat, int64_t ldx, int B, int I, int draw_noise, uint64_t seed, uint64_t offset,
                      float* eps_out, void* stream);
+/* out[b, :I] = a_table[t_b] * x[b, :I] + c_table[t_b] * y[b, :I] (per-row timesteps): forward_cal_xt with explicit noise (Model.py:339-341)
+ * and the posterior mean c1[t] * Denoise(x_t, t) + c2[t] * x_t of p_mean_variance (Model.py:375), for the reference-named Python API
+ * (the training / rebuild engines fuse both into their GEMM operands and epilogues). */
+int dmm_rows_axpby(const float* x, int64_t ldx, const float* y, int64_t ldy, const int32_t* t, const float* a_table, const float* c_table,
+                   float* out, int64_t ldo, int B, int I, void* stream);
 /* Backward of the time-embedding linear layer: d w_emb += temb_in^T d(temb), d b_emb += colsum (one block). */
 int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, int I, int te, int B, float* dw_emb, float* db_emb,
                  void* stream);

@@ -172,9 +172,10 @@ def bpr(u: Tensor, p: Tensor, n: Tensor) -> Tensor:
     return (-torch.log(1e-5 + torch.sigmoid(diff))).mean()  # "10e-6" in the source, Utils.py:96
 
 
-def infonce(v1: Tensor, v2: Tensor, idx: Tensor, temp: float) -> Tensor:
-    a = F.normalize(v1[idx], p=2, dim=1)
-    b = F.normalize(v2[idx], p=2, dim=1)
+def infonce(v1: Tensor, v2: Tensor, idx: Tensor, temp: float, b_cos: bool = True) -> Tensor:
+    a, b = v1[idx], v2[idx]
+    if b_cos:  # Utils.py:71-72
+        a, b = F.normalize(a, p=2, dim=1), F.normalize(b, p=2, dim=1)
     logits = (a @ b.t()) / temp
     return -(torch.diagonal(F.log_softmax(logits, dim=1))).mean()
 
