@@ -35,42 +35,95 @@ struct SpmmBatch {
   int remap;
 };
 
-template <int D>
-__device__ __forceinline__ void spmm_epilogue(const dmm_spmm_problem& P, int row, int l, float4 acc) {
-  constexpr int LANES = D / 4;
-  const size_t off = (size_t)row * D + 4 * l;
-  float4 y = make_float4(P.alpha * acc.x, P.alpha * acc.y, P.alpha * acc.z, P.alpha * acc.w);
+// A lane owns VEC consecutive columns of a row = one 16-byte piece of the X row it gathers: VEC = 4 for fp32 operands, 8 for bf16
+// operands (dmm_spmm_csr_bf16: half the gather bytes, twice the tasks per wave).  Everything after the gather is fp32.
+template <int VEC>
+struct Acc {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Acc<VEC> load_f32(const float* p) {
+  Acc<VEC> a;
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) {
+    const float4 t = reinterpret_cast<const float4*>(p)[q];
+    a.v[4 * q] = t.x; a.v[4 * q + 1] = t.y; a.v[4 * q + 2] = t.z; a.v[4 * q + 3] = t.w;
+  }
+  return a;
+}
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* p, const Acc<VEC>& a) {
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) reinterpret_cast<float4*>(p)[q] = make_float4(a.v[4 * q], a.v[4 * q + 1], a.v[4 * q + 2], a.v[4 * q + 3]);
+}
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void store_bf16(void* base, size_t elem, const Acc<VEC>& a) {
+  __bf16* p = reinterpret_cast<__bf16*>(base) + elem;
+  if (VEC == 8) {
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)a.v[j % VEC];
+    *reinterpret_cast<bf16x8_t*>(p) = o;
+  } else {
+    bf16x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (__bf16)a.v[j];
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+  }
+}
+
+template <int D, int VEC>
+__device__ __forceinline__ void spmm_epilogue(const dmm_spmm_problem& P, int row, int l, const Acc<VEC>& acc) {
+  constexpr int LANES = D / VEC;
+  const size_t off = (size_t)row * D + VEC * l;
+  Acc<VEC> y;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) y.v[j] = P.alpha * acc.v[j];
   if (P.c1) {
-    const float4 c = *reinterpret_cast<const float4*>(P.c1 + off);
-    y.x = fmaf(P.beta, c.x, y.x); y.y = fmaf(P.beta, c.y, y.y); y.z = fmaf(P.beta, c.z, y.z); y.w = fmaf(P.beta, c.w, y.w);
+    const Acc<VEC> c = load_f32<VEC>(P.c1 + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) y.v[j] = fmaf(P.beta, c.v[j], y.v[j]);
   }
   if (P.c2) {
-    const float4 c = *reinterpret_cast<const float4*>(P.c2 + off);
-    y.x = fmaf(P.gamma, c.x, y.x); y.y = fmaf(P.gamma, c.y, y.y); y.z = fmaf(P.gamma, c.z, y.z); y.w = fmaf(P.gamma, c.w, y.w);
+    const Acc<VEC> c = load_f32<VEC>(P.c2 + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) y.v[j] = fmaf(P.gamma, c.v[j], y.v[j]);
   }
-  if (P.y) *reinterpret_cast<float4*>(P.y + off) = y;
-  if (P.y_pert) {
-    float4 n;
+  if (P.y) store_f32<VEC>(P.y + off, y);
+  if (P.y16) store_bf16<VEC>(P.y16, off, y);
+  if (P.y_pert || P.y_pert16) {
+    Acc<VEC> n;
     if (P.noise) {
-      n = *reinterpret_cast<const float4*>(P.noise + off);
+      n = load_f32<VEC>(P.noise + off);
     } else {
-      // the counter uses the row's GLOBAL id, so a user-sharded replica draws exactly what the unsharded launch draws for that row
+      // the counter uses the row's GLOBAL id, so a user-sharded replica draws exactly what the unsharded launch draws for that row;
+      // element c of the row <-> counter grow * D/4 + c/4, component c % 4, whatever the lane width
       const unsigned long long grow = (unsigned long long)(row + (row < P.rng_row_split ? P.rng_row_add_lo : P.rng_row_add_hi));
-      const uint4 r = philox4(P.seed, P.offset + grow * LANES + l, 0x5eedu);
-      n = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const uint4 r = philox4(P.seed, P.offset + grow * (D / 4) + (VEC / 4) * l + q, 0x5eedu);
+        n.v[4 * q] = u01(r.x); n.v[4 * q + 1] = u01(r.y); n.v[4 * q + 2] = u01(r.z); n.v[4 * q + 3] = u01(r.w);
+      }
     }
-    float ss = n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ss = fmaf(n.v[j], n.v[j], ss);
     ss = group_sum<LANES>(ss);
     const float sc = P.noise_degree / fmaxf(sqrtf(ss), 1e-12f);
-    float4 yp = make_float4(y.x + sgn(y.x) * (n.x * sc), y.y + sgn(y.y) * (n.y * sc), y.z + sgn(y.z) * (n.z * sc),
-                            y.w + sgn(y.w) * (n.w * sc));
-    *reinterpret_cast<float4*>(P.y_pert + off) = yp;
+    Acc<VEC> yp;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) yp.v[j] = y.v[j] + sgn(y.v[j]) * (n.v[j] * sc);
+    if (P.y_pert) store_f32<VEC>(P.y_pert + off, yp);
+    if (P.y_pert16) store_bf16<VEC>(P.y_pert16, off, yp);
     if (P.y_mean) {
-      const float4 a = *reinterpret_cast<const float4*>(P.m1 + off);
-      const float4 b = *reinterpret_cast<const float4*>(P.m2 + off);
+      const Acc<VEC> a = load_f32<VEC>(P.m1 + off), b = load_f32<VEC>(P.m2 + off);
       const float t = 1.0f / 3.0f;
-      *reinterpret_cast<float4*>(P.y_mean + off) =
-          make_float4((yp.x + a.x + b.x) * t, (yp.y + a.y + b.y) * t, (yp.z + a.z + b.z) * t, (yp.w + a.w + b.w) * t);
+      Acc<VEC> m;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) m.v[j] = (yp.v[j] + a.v[j] + b.v[j]) * t;
+      store_f32<VEC>(P.y_mean + off, m);
     }
   }
 }
@@ -78,13 +131,13 @@ __device__ __forceinline__ void spmm_epilogue(const dmm_spmm_problem& P, int row
 // User-sharded layout: rows >= raw_from (the replicated item rows) are only PARTIAL sums on a replica -- the kernel parks the
 // raw accumulator in `raw` ([n_rows - raw_from, D]); after the replicas' partials are summed (one all-reduce per launch),
 // spmm_epilogue_rows_kernel applies the epilogue to those rows.
-template <int D>
-__device__ __forceinline__ void spmm_finish(const dmm_spmm_problem& P, int row, int l, float4 acc) {
+template <int D, int VEC>
+__device__ __forceinline__ void spmm_finish(const dmm_spmm_problem& P, int row, int l, const Acc<VEC>& acc) {
   if (P.raw && row >= P.raw_from) {
-    *reinterpret_cast<float4*>(P.raw + (size_t)(row - P.raw_from) * D + 4 * l) = acc;
+    store_f32<VEC>(P.raw + (size_t)(row - P.raw_from) * D + VEC * l, acc);
     return;
   }
-  spmm_epilogue<D>(P, row, l, acc);
+  spmm_epilogue<D, VEC>(P, row, l, acc);
 }
 
 template <int D>
@@ -94,16 +147,17 @@ __global__ __launch_bounds__(256) void spmm_epilogue_rows_kernel(const SpmmBatch
   if (!P.raw) return;
   const int l = threadIdx.x % LANES;
   for (int row = P.raw_from + blockIdx.x * G + threadIdx.x / LANES; row < P.n_rows; row += gridDim.x * G) {
-    const float4 acc = *reinterpret_cast<const float4*>(P.raw + (size_t)(row - P.raw_from) * D + 4 * l);
-    spmm_epilogue<D>(P, row, l, acc);
+    const Acc<4> acc = load_f32<4>(P.raw + (size_t)(row - P.raw_from) * D + 4 * l);
+    spmm_epilogue<D, 4>(P, row, l, acc);
   }
 }
 
-template <int D>
+// XT = float (VEC 4) or __bf16 (VEC 8)
+template <int D, int VEC>
 __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
-  constexpr int LANES = D / 4;      // lanes per task group
+  constexpr int LANES = D / VEC;    // lanes per task group
   constexpr int G = 256 / LANES;    // task groups per workgroup
-  __shared__ float4 part[256];
+  __shared__ float part[256 * VEC];
 
   // which problem does this workgroup belong to (n <= 4: a short uniform scan)
   int pi = 0;
@@ -122,13 +176,16 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
   const int row = task.x, beg = task.y, end = task.z;
   const int run_len = task.w & 0xffff, run_pos = task.w >> 16;
 
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  Acc<VEC> acc;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
   if (row >= 0) {
     const int* __restrict__ col = P.col;
     const float* __restrict__ val = P.val;
-    const float* __restrict__ xlo = P.x_lo;
-    const float* __restrict__ xhi = P.x_hi;
+    const char* __restrict__ xlo = reinterpret_cast<const char*>(P.x_lo);
+    const char* __restrict__ xhi = reinterpret_cast<const char*>(P.x_hi);
     const int split = P.split;
+    constexpr size_t ROWB = (size_t)D * (16 / VEC);  // bytes per X row
     // The group's lanes fetch LANES (column, value) pairs with one coalesced load each, then every pair is broadcast
     // inside the group (ds_bpermute) and 8 independent X-row gathers are kept in flight per lane: a 32-non-zero task costs
     // ~5 dependent memory round trips instead of 16.
@@ -141,70 +198,91 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
         myv = val[base + l];
       }
       for (int j0 = 0; j0 < cnt; j0 += 8) {
-        float4 x[8];
+        uint4 x[8];
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = __shfl(myc, j0 + j, LANES);
           v[j] = __shfl(myv, j0 + j, LANES);
-          x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          x[j] = make_uint4(0u, 0u, 0u, 0u);
           if (j0 + j < cnt) {
-            const float* src = c < split ? xlo + (size_t)c * D : xhi + (size_t)(c - split) * D;
-            x[j] = *reinterpret_cast<const float4*>(src + 4 * l);
+            const char* src = c < split ? xlo + (size_t)c * ROWB : xhi + (size_t)(c - split) * ROWB;
+            x[j] = reinterpret_cast<const uint4*>(src)[l];
           } else {
             v[j] = 0.f;
           }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          acc.x = fmaf(v[j], x[j].x, acc.x);
-          acc.y = fmaf(v[j], x[j].y, acc.y);
-          acc.z = fmaf(v[j], x[j].z, acc.z);
-          acc.w = fmaf(v[j], x[j].w, acc.w);
+          if (VEC == 4) {
+            acc.v[0] = fmaf(v[j], __uint_as_float(x[j].x), acc.v[0]);
+            acc.v[1] = fmaf(v[j], __uint_as_float(x[j].y), acc.v[1]);
+            acc.v[2 % VEC] = fmaf(v[j], __uint_as_float(x[j].z), acc.v[2 % VEC]);
+            acc.v[3 % VEC] = fmaf(v[j], __uint_as_float(x[j].w), acc.v[3 % VEC]);
+          } else {  // 8 bf16 per 16 bytes: element 2k = low half of word k (bf16 -> fp32 is a 16-bit shift)
+            const unsigned w[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              acc.v[(2 * k) % VEC] = fmaf(v[j], __uint_as_float(w[k] << 16), acc.v[(2 * k) % VEC]);
+              acc.v[(2 * k + 1) % VEC] = fmaf(v[j], __uint_as_float(w[k] & 0xffff0000u), acc.v[(2 * k + 1) % VEC]);
+            }
+          }
         }
       }
     }
   }
   // combine the tasks of a split row in task order (deterministic)
-  part[threadIdx.x] = acc;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) part[j * 256 + threadIdx.x] = acc.v[j];
   __syncthreads();
   if (row < 0 || run_pos != 0) return;
   for (int t = 1; t < run_len; ++t) {
-    const float4 o = part[(g + t) * LANES + l];
-    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc.v[j] += part[j * 256 + (g + t) * LANES + l];
   }
 
   if (lb < P.n_partial_blocks) {  // segment of a giant row: park the raw partial row; spmm_fixup_kernel sums the segments in order
-    *reinterpret_cast<float4*>(P.partial + (size_t)lb * D + 4 * l) = acc;
+    store_f32<VEC>(P.partial + (size_t)lb * D + VEC * l, acc);
     return;
   }
-  spmm_finish<D>(P, row, l, acc);
+  spmm_finish<D, VEC>(P, row, l, acc);
 }
 
 // Rows longer than one workgroup's worth of tasks are cut into segments (one workgroup each, planned first in the task list).
-// This pass adds a row's segment partials in segment order (deterministic) and applies the epilogue.
+// This pass adds a row's segment partials and applies the epilogue: one WORKGROUP per giant row -- group g sums the segments
+// g, g + G, g + 2G, ... and the G partial rows are then added in group order through LDS (a fixed order: deterministic).
 template <int D>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) {
   constexpr int LANES = D / 4, G = 256 / LANES;
+  __shared__ float4 part[256];
   const dmm_spmm_problem& P = batch.p[blockIdx.y];
-  const int i = blockIdx.x * G + threadIdx.x / LANES, l = threadIdx.x % LANES;
-  if (i >= P.n_fix) return;
-  const int4 f = reinterpret_cast<const int4*>(P.fix)[i];  // {row, first_slot, n_slots, -}
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int sidx = 0; sidx < f.z; ++sidx) {
+  if ((int)blockIdx.x >= P.n_fix) return;
+  const int g = threadIdx.x / LANES, l = threadIdx.x % LANES;
+  const int4 f = reinterpret_cast<const int4*>(P.fix)[blockIdx.x];  // {row, first_slot, n_slots, -}
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sidx = g; sidx < f.z; sidx += G) {
     const float4 o = *reinterpret_cast<const float4*>(P.partial + (size_t)(f.y + sidx) * D + 4 * l);
-    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
   }
-  spmm_finish<D>(P, f.x, l, acc);
+  part[threadIdx.x] = a;
+  __syncthreads();
+  if (g != 0) return;
+  for (int t = 1; t < G; ++t) {
+    const float4 o = part[t * LANES + l];
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+  }
+  Acc<4> acc;
+  acc.v[0] = a.x; acc.v[1] = a.y; acc.v[2] = a.z; acc.v[3] = a.w;
+  spmm_finish<D, 4>(P, f.x, l, acc);
 }
 
-template <int D>
+template <int D, int VEC>
 static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL(spmm_kernel<D>, dim3(blocks), dim3(256), 0, s, b);
+  hipLaunchKernelGGL((spmm_kernel<D, VEC>), dim3(blocks), dim3(256), 0, s, b);
   int max_fix = 0;
   for (int i = 0; i < b.n; ++i) max_fix = max_fix > b.p[i].n_fix ? max_fix : b.p[i].n_fix;
-  if (max_fix > 0) hipLaunchKernelGGL(spmm_fixup_kernel<D>, dim3(cdiv(max_fix, 1024 / D), b.n), dim3(256), 0, s, b);
-  DMM_LAUNCH_CHECK("dmm_spmm_csr_f32");
+  if (max_fix > 0) hipLaunchKernelGGL(spmm_fixup_kernel<D>, dim3(max_fix, b.n), dim3(256), 0, s, b);
+  DMM_LAUNCH_CHECK("dmm_spmm_csr");
   return 0;
 }
 
@@ -214,10 +292,14 @@ extern "C" int dmm_spmm_tasks_per_block(int D) {
   if (D != 8 && D != 16 && D != 32 && D != 64 && D != 128 && D != 256) return -1;
   return 1024 / D;
 }
+extern "C" int dmm_spmm_tasks_per_block_bf16(int D) {
+  if (D != 16 && D != 32 && D != 64 && D != 128 && D != 256) return -1;
+  return 2048 / D;
+}
 
-static int spmm_fill_batch(const char* who, const dmm_spmm_problem* probs, int n_probs, int D, dmm::SpmmBatch& b, int& blocks) {
+static int spmm_fill_batch(const char* who, const dmm_spmm_problem* probs, int n_probs, int D, dmm::SpmmBatch& b, int& blocks, bool bf16 = false) {
   DMM_CHECK_ARG(probs && n_probs >= 1 && n_probs <= DMM_SPMM_MAX_BATCH, "%s: n_probs must be 1..%d", who, DMM_SPMM_MAX_BATCH);
-  const int G = dmm_spmm_tasks_per_block(D);
+  const int G = bf16 ? dmm_spmm_tasks_per_block_bf16(D) : dmm_spmm_tasks_per_block(D);
   DMM_CHECK_ARG(G > 0, "%s: D=%d unsupported (8,16,32,64,128,256)", who, D);
   memset(&b, 0, sizeof(b));
   b.n = n_probs;
@@ -232,10 +314,10 @@ static int spmm_fill_batch(const char* who, const dmm_spmm_problem* probs, int n
     DMM_CHECK_ARG(p.tasks && p.col && p.val && p.x_lo, "%s: problem %d has a null operand", who, i);
     DMM_CHECK_ARG(p.n_tasks > 0 && p.n_tasks % G == 0, "%s: problem %d: n_tasks=%d is not a multiple of %d", who, i, p.n_tasks, G);
     DMM_CHECK_ARG(p.n_head_tasks >= 0 && p.n_head_tasks <= p.n_tasks && p.n_head_tasks % G == 0, "%s: problem %d: bad n_head_tasks", who, i);
-    DMM_CHECK_ARG(p.y || p.y_pert, "%s: problem %d has no output", who, i);
+    DMM_CHECK_ARG(p.y || p.y_pert || p.y16 || p.y_pert16, "%s: problem %d has no output", who, i);
     DMM_CHECK_ARG(p.n_partial_blocks >= 0 && p.n_partial_blocks * G <= p.n_head_tasks && p.n_fix >= 0, "%s: problem %d: bad giant-row fields", who, i);
     DMM_CHECK_ARG(p.n_partial_blocks == 0 || (p.partial && p.fix && p.n_fix > 0), "%s: problem %d: giant rows need partial + fix buffers", who, i);
-    DMM_CHECK_ARG(!p.y_mean || (p.y_pert && p.m1 && p.m2), "%s: problem %d: y_mean needs y_pert, m1, m2", who, i);
+    DMM_CHECK_ARG(!p.y_mean || ((p.y_pert || p.y_pert16) && p.m1 && p.m2), "%s: problem %d: y_mean needs y_pert, m1, m2", who, i);
     DMM_CHECK_ARG(p.x_hi || p.split >= (1 << 30), "%s: problem %d: x_hi missing", who, i);
     DMM_CHECK_ARG(!p.raw || (p.raw_from >= 0 && p.raw_from <= p.n_rows && p.n_rows > 0), "%s: problem %d: raw rows need 0 <= raw_from <= n_rows", who, i);
     b.p[i] = p;
@@ -252,12 +334,29 @@ extern "C" int dmm_spmm_csr_f32(const dmm_spmm_problem* probs, int n_probs, int 
   if (int rc = spmm_fill_batch("dmm_spmm_csr_f32", probs, n_probs, D, b, blocks)) return rc;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 8: return dmm::launch<8>(b, blocks, s);
-    case 16: return dmm::launch<16>(b, blocks, s);
-    case 32: return dmm::launch<32>(b, blocks, s);
-    case 64: return dmm::launch<64>(b, blocks, s);
-    case 128: return dmm::launch<128>(b, blocks, s);
-    case 256: return dmm::launch<256>(b, blocks, s);
+    case 8: return dmm::launch<8, 4>(b, blocks, s);
+    case 16: return dmm::launch<16, 4>(b, blocks, s);
+    case 32: return dmm::launch<32, 4>(b, blocks, s);
+    case 64: return dmm::launch<64, 4>(b, blocks, s);
+    case 128: return dmm::launch<128, 4>(b, blocks, s);
+    case 256: return dmm::launch<256, 4>(b, blocks, s);
+  }
+  return DMM_ERR_INVALID_ARG;
+}
+
+// The same with the gathered operand X in bf16 ([rows, D] bf16, fp32 accumulation, fp32 epilogue operands and outputs; optional bf16
+// copies of the outputs feed the next layer's launch).  The task list is planned for dmm_spmm_tasks_per_block_bf16(D) = 2048 / D groups.
+extern "C" int dmm_spmm_csr_bf16(const dmm_spmm_problem* probs, int n_probs, int D, void* stream) {
+  dmm::SpmmBatch b;
+  int blocks = 0;
+  if (int rc = spmm_fill_batch("dmm_spmm_csr_bf16", probs, n_probs, D, b, blocks, true)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  switch (D) {
+    case 16: return dmm::launch<16, 8>(b, blocks, s);
+    case 32: return dmm::launch<32, 8>(b, blocks, s);
+    case 64: return dmm::launch<64, 8>(b, blocks, s);
+    case 128: return dmm::launch<128, 8>(b, blocks, s);
+    case 256: return dmm::launch<256, 8>(b, blocks, s);
   }
   return DMM_ERR_INVALID_ARG;
 }

@@ -191,6 +191,7 @@ class Adjacency:
     fix: Optional[torch.Tensor] = None  # int32 [n_giant, 4]: row, first_slot, n_slots, 0
     host: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
     uid: int = field(default_factory=lambda: next(_adjacency_uid))
+    vec: int = 4  # columns per lane the task list was planned for: 4 = fp32 operands (dmm_spmm_csr_f32), 8 = bf16 operands (dmm_spmm_csr_bf16)
 
     @property
     def n_tasks(self) -> int:
@@ -212,22 +213,27 @@ class Adjacency:
 
 
 def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
-                   keep_host: bool = False) -> Adjacency:
+                   keep_host: bool = False, vec: int = 4) -> Adjacency:
     rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)
-    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host)
+    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host, vec)
 
 
-def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = TASK_LEN, keep_host: bool = False) -> Adjacency:
-    plan = plan_tasks(rowptr, D, task_len, full=True)
+def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = TASK_LEN, keep_host: bool = False, vec: int = 4) -> Adjacency:
+    """vec = 8 plans the work list for bf16 operands: a lane owns 8 columns, so a workgroup holds 2048 / D task groups -- the plan of
+    width D / 2."""
+    if vec not in (4, 8):
+        raise ValueError("vec must be 4 (fp32 operands) or 8 (bf16 operands)")
+    Dp = D * 4 // vec
+    plan = plan_tasks(rowptr, Dp, task_len, full=True)
     tasks, head = plan.tasks, plan.head
-    check_plan(rowptr, tasks, D)
+    check_plan(rowptr, tasks, Dp)
     assert col.size == 0 or (col.min() >= 0 and col.max() < rowptr.shape[0] - 1), "column id out of range"
     dev = torch.device(device)
     return Adjacency(n=int(rowptr.shape[0] - 1), nnz=int(col.shape[0]), D=D,
                      rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
                      val=torch.from_numpy(val).to(dev), tasks=torch.from_numpy(tasks).to(dev), n_head_tasks=head,
                      n_partial_blocks=plan.n_partial_blocks, fix=torch.from_numpy(plan.fix).to(dev) if plan.n_partial_blocks else None,
-                     host=(rowptr, col, val) if keep_host else None)
+                     host=(rowptr, col, val) if keep_host else None, vec=vec)
 
 
 # ======================================================================================================

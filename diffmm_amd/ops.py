@@ -38,7 +38,8 @@ class SpmmOp:
                  alpha: float = 1.0, c1: Optional[Tensor] = None, beta: float = 0.0, c2: Optional[Tensor] = None, gamma: float = 0.0,
                  y_pert: Optional[Tensor] = None, noise: Optional[Tensor] = None, noise_degree: float = 0.0, seed: int = 0, offset: int = 0,
                  y_mean: Optional[Tensor] = None, m1: Optional[Tensor] = None, m2: Optional[Tensor] = None, partial: Optional[Tensor] = None,
-                 raw: Optional[Tensor] = None, raw_from: int = 0, rng_rows: Optional[tuple] = None):
+                 raw: Optional[Tensor] = None, raw_from: int = 0, rng_rows: Optional[tuple] = None, y16: Optional[Tensor] = None,
+                 y_pert16: Optional[Tensor] = None):
         """raw / raw_from: user-sharded launch -- rows >= raw_from park their raw partial sums in raw [n - raw_from, D] (all-reduce it over
         the replicas, then spmm_epilogue_rows finishes those rows).  rng_rows = (split, add_lo, add_hi): global row ids of the Philox draws."""
         D = adj.D
@@ -51,13 +52,19 @@ class SpmmOp:
             split = x_lo.shape[0] if split is None else split
             if x_lo.shape[0] != split or x_lo.shape[0] + x_hi.shape[0] != n or x_lo.shape[1] != D or x_hi.shape[1] != D:
                 raise ValueError("split SpMM operand: row counts must add up to the adjacency size")
-        for nm, t in (("x_lo", x_lo), ("x_hi", x_hi), ("y", y), ("c1", c1), ("c2", c2), ("y_pert", y_pert), ("noise", noise),
-                      ("y_mean", y_mean), ("m1", m1), ("m2", m2)):
+        xdt = torch.bfloat16 if adj.vec == 8 else torch.float32  # the adjacency's task list fixes the operand type
+        for nm, t in (("x_lo", x_lo), ("x_hi", x_hi)):
+            if t is not None and (t.dtype != xdt or not t.is_contiguous()):
+                raise ValueError(f"SpMM {nm}: this adjacency is planned for contiguous {xdt} operands, got {t.dtype}")
+        for nm, t in (("y", y), ("c1", c1), ("c2", c2), ("y_pert", y_pert), ("noise", noise), ("y_mean", y_mean), ("m1", m1), ("m2", m2)):
             if t is not None:
                 _f32c(t, nm)
-                if nm not in ("x_lo", "x_hi") and tuple(t.shape) != (n, D):
+                if tuple(t.shape) != (n, D):
                     raise ValueError(f"SpMM {nm} must be [{n}, {D}], got {tuple(t.shape)}")
-        self.keep = (adj, x_lo, x_hi, y, c1, c2, y_pert, noise, y_mean, m1, m2)
+        for nm, t in (("y16", y16), ("y_pert16", y_pert16)):
+            if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (n, D)):
+                raise ValueError(f"SpMM {nm} must be a contiguous bfloat16 [{n}, {D}] tensor")
+        self.keep = (adj, x_lo, x_hi, y, c1, c2, y_pert, noise, y_mean, m1, m2, y16, y_pert16)
         p = L.SpmmProblem()
         p.tasks, p.col, p.val = L.ptr(adj.tasks), L.ptr(adj.col), L.ptr(adj.val)
         p.x_lo, p.x_hi, p.split = L.ptr(x_lo), L.ptr(x_hi), split
@@ -65,6 +72,7 @@ class SpmmOp:
         p.alpha, p.beta, p.gamma = alpha, beta, gamma
         p.y_pert, p.noise, p.noise_degree, p.seed, p.offset = L.ptr(y_pert), L.ptr(noise), noise_degree, seed, offset
         p.y_mean, p.m1, p.m2 = L.ptr(y_mean), L.ptr(m1), L.ptr(m2)
+        p.y16, p.y_pert16 = L.ptr(y16), L.ptr(y_pert16)
         p.n_rows = adj.n
         p.n_partial_blocks, p.n_fix = adj.n_partial_blocks, (int(adj.fix.shape[0]) if adj.fix is not None else 0)
         p.fix = L.ptr(adj.fix) if adj.fix is not None else None
@@ -93,8 +101,10 @@ def spmm_batched(ops: Sequence[SpmmOp]):
             i = uses.get(id(o.adj), 0)
             uses[id(o.adj)] = i + 1
             o.p.partial = L.ptr(o.adj.partial_buffer(i))
+    if any(o.adj.vec != ops[0].adj.vec for o in ops):
+        raise ValueError("one launch takes fp32-operand or bf16-operand problems, not both")
     arr = (L.SpmmProblem * len(ops))(*[o.p for o in ops])
-    L.call("dmm_spmm_csr_f32", arr, len(ops), D, L.stream())
+    L.call("dmm_spmm_csr_bf16" if ops[0].adj.vec == 8 else "dmm_spmm_csr_f32", arr, len(ops), D, L.stream())
     return arr  # the launch's argument block (plans patch the Philox offsets in place)
 
 

@@ -78,10 +78,21 @@ typedef struct dmm_spmm_problem {
   /* In-kernel Philox draws are keyed by the row's GLOBAL id: row + (row < rng_row_split ? rng_row_add_lo : rng_row_add_hi), so a
    * replica draws what the unsharded launch draws for that row (all zero = local ids, the unsharded case). */
   int32_t rng_row_split, rng_row_add_lo, rng_row_add_hi;
+  /* optional bf16 copies of y / y_pert ([n_rows, D] bf16): the operand of the next layer's dmm_spmm_csr_bf16 launch, written by the
+   * producing launch instead of a separate cast pass */
+  void* y16;
+  void* y_pert16;
 } dmm_spmm_problem;
 
 int dmm_spmm_tasks_per_block(int D);
 int dmm_spmm_csr_f32(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
+/* bf16-storage variant (BASELINE.json configs 2-5, SURVEY 8d "bf16 storage / fp32 accumulate"): x_lo / x_hi point to bf16 rows
+ * ([rows, D] bf16, 16-byte aligned), the gather moves half the bytes and one wave carries twice the tasks; accumulation, epilogue
+ * operands (c1, c2, noise, m1, m2) and outputs stay fp32, y16 / y_pert16 add bf16 copies.  The task list must be planned for
+ * dmm_spmm_tasks_per_block_bf16(D) = 2048 / D groups per workgroup (diffmm_amd/graph.py: plan width D / 2).  Same fix-up pass,
+ * same determinism; the in-kernel Philox draws are the ones dmm_spmm_csr_f32 makes. */
+int dmm_spmm_tasks_per_block_bf16(int D);
+int dmm_spmm_csr_bf16(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
 /* epilogue of the rows >= raw_from from the (all-reduced) raw partial rows; problems with raw == NULL are skipped */
 int dmm_spmm_epilogue_rows(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
 

@@ -135,6 +135,60 @@ def test_spmm_giant_rows(dev, D):
     assert torch.equal(y, y3), "segmented rows stay bitwise reproducible"
 
 
+@pytest.mark.parametrize("name,D,hub", [("toy", 16, False), ("mid", 32, False), ("mid", 64, False), ("mid", 128, False), ("mid", 256, False), ("tiktok", 64, False),
+                                        ("tiktok", 64, True), ("tiktok", 256, True)])
+def test_spmm_bf16_operands(dev, name, D, hub):
+    """dmm_spmm_csr_bf16 (X in bf16, 8 columns per lane, fp32 accumulate / epilogue / outputs + bf16 copies).  Two bars:
+      * exactness of the kernel: against torch.sparse.mm on the bf16-ROUNDED operand (only the fp32 summation order differs), 1e-5;
+      * the storage tolerance of SURVEY 8c ("bf16 storage: 2e-2 rel. on embeddings"): against the fp32 operand, row by row within
+        2^-8 of sum_j |a_ij| |x_j| (every gathered element is off by at most half a bf16 ulp)."""
+    from diffmm_amd import ops, graph, synth
+    from oracle import diffmm_oracle as O
+    import torch.nn.functional as F
+    g = synth.named(name)
+    rows, cols = g.trn_rows, g.trn_cols
+    if hub:  # giant rows: an item every user has, a user with 3000 items -> multi-workgroup segments + fix-up pass
+        rows = np.concatenate([rows, np.arange(g.users), np.full(3000, 5)])
+        cols = np.concatenate([cols, np.zeros(g.users, dtype=np.int32), np.arange(3000)])
+    adj = graph.make_adjacency(rows, cols, g.users, g.items, D, dev, keep_host=True, vec=8)
+    assert adj.vec == 8 and (not hub or adj.n_partial_blocks >= 1)
+    A = O.csr_to_torch(*adj.host)
+    rng = np.random.default_rng(4)
+    n, U = adj.n, g.users
+    X = T(rng.standard_normal((n, D)).astype(np.float32)); C1 = T(rng.standard_normal((n, D)).astype(np.float32))
+    noise = T(rng.random((n, D)).astype(np.float32)); m1 = T(rng.standard_normal((n, D)).astype(np.float32)); m2 = T(rng.standard_normal((n, D)).astype(np.float32))
+    X16 = X.bfloat16()
+    ref = torch.sparse.mm(A, X16.float())
+    y, yp, ym = (torch.empty((n, D), device=dev) for _ in range(3))
+    y16, yp16 = (torch.empty((n, D), device=dev, dtype=torch.bfloat16) for _ in range(2))
+    ops.spmm_batched([ops.SpmmOp(adj, X16.to(dev), y=y, y16=y16)])
+    close(y, ref, rtol=2e-5, atol=2e-5, what="bf16 operand, plain")
+    assert torch.equal(y16, y.bfloat16()), "y16 is the bf16 rounding of y"
+    absA = torch.sparse_coo_tensor(A.indices(), A.values().abs(), A.shape).coalesce() if A.layout == torch.sparse_coo else None
+    full = torch.sparse.mm(A, X)
+    bound = torch.sparse.mm(absA if absA is not None else A.abs(), X.abs()) * 2.0 ** -8 + 1e-6
+    assert bool(((y.cpu() - full).abs() <= bound).all()), "outside the bf16 storage bound"
+    assert float((y.cpu() - full).abs().max()) <= 2e-2 * float(full.abs().max()), "SURVEY 8c: 2e-2 rel. on embeddings"
+    # epilogues + split operand + perturbation + mean + bf16 copy of the perturbed output
+    ops.spmm_batched([ops.SpmmOp(adj, X16[:U].contiguous().to(dev), x_hi=X16[U:].contiguous().to(dev), split=U, y=y, alpha=1.5, c1=C1.to(dev), beta=-0.5,
+                                 y_pert=yp, y_pert16=yp16, noise=noise.to(dev), noise_degree=1.5, y_mean=ym, m1=m1.to(dev), m2=m2.to(dev))])
+    r = 1.5 * ref - 0.5 * C1
+    rp = r + torch.sign(r) * F.normalize(noise) * 1.5
+    close(y, r, rtol=2e-5, atol=3e-5, what="epilogue"); close(yp, rp, rtol=2e-5, atol=3e-5, what="perturbed"); close(ym, (rp + m1 + m2) / 3, rtol=2e-5, atol=3e-5, what="mean")
+    assert torch.equal(yp16, yp.bfloat16())
+    # the in-kernel Philox draws are the fp32 kernel's (same element -> counter map): same perturbation direction for the same rows
+    adj32 = graph.make_adjacency(rows, cols, g.users, g.items, D, dev)
+    a32, b16 = torch.empty((n, D), device=dev), torch.empty((n, D), device=dev)
+    ops.spmm_batched([ops.SpmmOp(adj32, X16.float().to(dev), y_pert=a32, noise=None, noise_degree=0.7, seed=9, offset=77)])
+    ops.spmm_batched([ops.SpmmOp(adj, X16.to(dev), y_pert=b16, noise=None, noise_degree=0.7, seed=9, offset=77)])
+    close(b16, a32, rtol=2e-5, atol=3e-5, what="Philox perturbation, bf16 vs fp32 kernel")
+    again = torch.empty_like(b16)
+    ops.spmm_batched([ops.SpmmOp(adj, X16.to(dev), y_pert=again, noise=None, noise_degree=0.7, seed=9, offset=77)])
+    assert torch.equal(again, b16), "bitwise reproducible"
+    with pytest.raises(ValueError):
+        ops.SpmmOp(adj, X.to(dev), y=y)  # fp32 operand on a bf16-planned adjacency
+
+
 def test_spmm_is_deterministic_and_symmetric_backward(dev):
     from diffmm_amd import ops
     g, adj, A = _adj("tiktok", 64, dev)

@@ -1,37 +1,51 @@
 #!/usr/bin/env python3
-"""SpMM at shard scale: a synthetic graph of the TikTok degree law with 1M users (one GPU's share of the 10M-user configuration),
-operands far beyond L2 / Infinity Cache.  Reports time, algorithmic GB/s (nnz*8 + (N+1)*4 + 2*N*d*4 bytes) and the gather volume."""
-import argparse, os, sys, time
+"""SpMM at shard scale: a synthetic graph of the TikTok degree law with 1M users x 500k items (one GPU's share of the 10M-user
+configuration), operands far beyond L2 / Infinity Cache.  Per variant (fp32 operands: dmm_spmm_csr_f32; bf16 operands:
+dmm_spmm_csr_bf16): time per launch (HIP events over back-to-back launches on the launch stream), the compulsory-bytes rate
+(nnz*8 + (N+1)*4 + 2*N*d*s bytes, s = element size of the variant's X and Y) against the 8 TB/s roofline, and the gather
+volume nnz*d*s.  Prints one JSON line per variant (kept under profiles/)."""
+import argparse, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diffmm_amd import graph, ops, synth
+from diffmm_amd import graph, ops, synth, _lib as L
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--users", type=int, default=1_000_000); ap.add_argument("--items", type=int, default=500_000)
-ap.add_argument("--dims", default="64,256")
-a = ap.parse_args()
-t0 = time.time()
-g = synth.make_graph(a.users, a.items, feats=(), seed=1818, heavy_p=0.011, heavy=(300, 520))
-print(f"graph: U={g.users} I={g.items} E={g.nnz} ({time.time()-t0:.1f}s)", flush=True)
-dev = torch.device("cuda:0")
-for D in [int(x) for x in a.dims.split(",")]:
+
+def measure(g, D, dev, variant, reps=10):
+    vec = 8 if variant.startswith("bf16") else 4
+    adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev, vec=vec)
+    X = torch.randn(adj.n, D, device=dev)
+    Y = torch.empty_like(X)
+    if variant == "f32":
+        op, s_x, s_y = ops.SpmmOp(adj, X, y=Y), 4, 4
+    elif variant == "bf16_x":      # bf16 operand, fp32 output (what a layer followed by fp32 consumers writes)
+        op, s_x, s_y = ops.SpmmOp(adj, X.bfloat16(), y=Y), 2, 4
+    else:                           # bf16 operand, bf16 output only (an inner layer of a bf16-storage chain)
+        op, s_x, s_y = ops.SpmmOp(adj, X.bfloat16(), y16=torch.empty(adj.n, D, device=dev, dtype=torch.bfloat16)), 2, 2
+    with L.Recorder() as plan:
+        ops.spmm_batched([op])
+    L.replay(plan); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.replay(plan)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps * 1e-3
+    alg = adj.nnz * 8 + (adj.n + 1) * 4 + adj.n * D * (s_x + s_y)
+    return dict(variant=variant, users=g.users, items=g.items, nnz=adj.nnz, d=D, tasks=adj.n_tasks, giant_rows=0 if adj.fix is None else int(adj.fix.shape[0]),
+                us_per_launch=t * 1e6, algorithmic_bytes=alg, algorithmic_GBps=alg / t / 1e9, frac_of_8TBps=alg / t / 8e12,
+                gather_bytes=adj.nnz * D * s_x, gather_GBps=adj.nnz * D * s_x / t / 1e9)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=1_000_000); ap.add_argument("--items", type=int, default=500_000)
+    ap.add_argument("--dims", default="64"); ap.add_argument("--variants", default="f32,bf16_x,bf16_xy")
+    a = ap.parse_args()
     t0 = time.time()
-    adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev)
-    print(f"d={D}: nnz={adj.nnz} tasks={adj.n_tasks} partial_blocks={adj.n_partial_blocks} giant_rows={0 if adj.fix is None else adj.fix.shape[0]} "
-          f"(host build {time.time()-t0:.1f}s)", flush=True)
-    X = torch.randn(adj.n, D, device=dev); Y = torch.empty_like(X)
-    op = ops.SpmmOp(adj, X, y=Y)
-    for remap in ("0", "1"):
-        os.environ["DMM_SPMM_REMAP"] = remap
-        ops.spmm_batched([op]); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            ops.spmm_batched([op])
-        e1.record(); torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 10 * 1e-3
-        alg = adj.algorithmic_bytes(4)
-        print(f"   remap={remap}: {t*1e6:9.1f} us   algorithmic {alg/1e9:.2f} GB -> {alg/t/1e9:8.1f} GB/s ({alg/t/8e12:.3f} of 8 TB/s);  "
-              f"gather volume {adj.nnz*D*4/1e9:.2f} GB -> {adj.nnz*D*4/t/1e9:8.1f} GB/s", flush=True)
-    del adj, X, Y, op
-    torch.cuda.empty_cache()
+    g = synth.make_graph(a.users, a.items, feats=(), seed=1818, heavy_p=0.011, heavy=(300, 520))
+    print(f"graph: U={g.users} I={g.items} E={g.nnz} ({time.time()-t0:.1f}s)", flush=True)
+    dev = torch.device("cuda:0")
+    for D in [int(x) for x in a.dims.split(",")]:
+        for v in a.variants.split(","):
+            print(json.dumps(measure(g, D, dev, v)), flush=True)
+            torch.cuda.empty_cache()
