@@ -107,6 +107,7 @@ def roofline(coach, args):
             chain = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_chain_gemm.json")))
             l1, l2 = chain["gemm_bf16_nt_8ph_layer1"], chain["gemm_bf16_nt_8ph_layer2"]
             gemm["traffic"] = l1["traffic_bytes"]
+            gemm["traffic_source"] = spmm["traffic_source"] = "committed rocprofv3 --pmc passes of this workload (profiles/README.md); bench.py cannot run a PMC pass on itself"
             gemm["traffic_note"] = (f"layer 1: {l1['traffic_bytes'] / 1e6:.0f} MB fabric-side per launch vs {l1['algorithmic_bytes'] / 1e6:.0f} MB of operands + output "
                                     f"(L2 hit rate {l1['tcc_hit'] / (l1['tcc_hit'] + l1['tcc_miss']):.0%}); layer 2: {l2['traffic_bytes'] / 1e6:.0f} MB vs "
                                     f"{l2['algorithmic_bytes'] / 1e6:.0f} MB; profiles/r1_pmc_chain_gemm.json")
@@ -115,13 +116,59 @@ def roofline(coach, args):
     return gemm, spmm
 
 
+def roofline_spmm_shard(users: int = 1_000_000, items: int = 500_000, D: int = 64):
+    """The SpMM where it is HBM-bound: one GPU's share of the 10M-user configuration (1M users x 500k items, TikTok degree law;
+    X and Y are 384 MB each in fp32, far beyond L2 / Infinity Cache).  Live HIP-event timing of dmm_spmm_csr_f32 and dmm_spmm_csr_bf16
+    (tools/spmm_scale.py); the compulsory bytes of SURVEY 8(d) use each variant's own element sizes."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import spmm_scale
+    from diffmm_amd import synth
+    g = synth.make_graph(users, items, feats=(), seed=1818, heavy_p=0.011, heavy=(300, 520))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+    for v in ("f32", "bf16_xy"):
+        m = spmm_scale.measure(g, D, dev, v)
+        out[v] = {"bound": "hbm", "kernel": "spmm_kernel<64, 4> (fp32 X, Y)" if v == "f32" else "spmm_kernel<64, 8> (bf16 X, Y; fp32 accumulate)",
+                  "achieved": m["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": m["algorithmic_GBps"] / HBM_PEAK_GBS,
+                  "traffic": None, "avg_launch_us": m["us_per_launch"], "algorithmic_bytes": m["algorithmic_bytes"], "gather_GBps": m["gather_GBps"]}
+        torch.cuda.empty_cache()
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_spmm_shard.json")))
+        for v in out:
+            if v in pmc:
+                out[v]["traffic"] = pmc[v]["traffic_bytes"]
+                out[v]["traffic_source"] = "profiles/r2_pmc_spmm_shard.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/spmm_scale.py, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+    except Exception:
+        pass
+    out["workload"] = f"synthetic TikTok-degree-law graph, U={users} I={items} E={g.nnz}, d={D}"
+    return out
+
+
+def _pick_cpu_threads():
+    """torch-CPU oversubscribes on a many-core host: time a Denoise-layer-shaped GEMM + tanh at 8 .. 128 threads and keep the fastest."""
+    cand = [t for t in (8, 16, 32, 64, 128) if t <= (os.cpu_count() or 8)] or [torch.get_num_threads()]
+    x, w = torch.randn(2048, 6720), torch.randn(1024, 6720)
+    best, times = None, {}
+    for t in cand:
+        torch.set_num_threads(t)
+        torch.tanh(x @ w.t())
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.tanh(x @ w.t())
+        times[t] = (time.perf_counter() - t0) / 3
+        if best is None or times[t] < times[best]:
+            best = t
+    torch.set_num_threads(best)
+    return best, times
+
+
 def cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint):
     """The CPU oracle (a validated restatement of the reference's PyTorch-CPU path) timed on this box's host cores on a
     bounded sample of the same workload, extrapolated to one epoch."""
     from oracle import diffmm_oracle as O
     g = h.graph
     U, I, D, M, B, T = g.users, g.items, args.latdim, len(g.feats), args.batch, args.T
-    threads = torch.get_num_threads()
+    threads, sweep = _pick_cpu_threads()
     rng = np.random.default_rng(0)
     feats = [torch.from_numpy(f) for f in g.feats]
     model = {"u_embs": torch.nn.init.xavier_uniform_(torch.empty(U, D)), "i_embs": torch.nn.init.xavier_uniform_(torch.empty(I, D)),
@@ -141,25 +188,33 @@ def cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint):
     draws = O.Draws(seed=1)
     idx = rng.permutation(U)[:B]
     x0 = dense[torch.from_numpy(idx)]
+    budget_t0 = time.perf_counter()
     t0 = time.perf_counter(); O.diffusion_step(st, feats, x0, draws, sched, hp); t_diff = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        view = O.generate_view(st.dens[0], x0, sched, 0)
-        O.topk_edges(view[:256], idx[:256], np.bincount(g.trn_rows, minlength=U))
-    t_reb_unit = time.perf_counter() - t0
+    # rebuild units: T reverse steps over one user batch + the per-user top-k of that batch, one unit per modality while the budget lasts
+    units = []
+    deg = np.bincount(g.trn_rows, minlength=U)
+    for m in range(M):
+        if units and time.perf_counter() - budget_t0 > 22.0:
+            break
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            view = O.generate_view(st.dens[m], x0, sched, 0)
+            O.topk_edges(view, idx, deg)
+        units.append(time.perf_counter() - t0)
+    t_reb_unit = float(np.mean(units))
     e = rng.integers(0, g.nnz, size=B)
     u, p = torch.from_numpy(g.trn_rows[e].astype(np.int64)), torch.from_numpy(g.trn_cols[e].astype(np.int64))
     ng = torch.from_numpy(rng.integers(0, I, size=B))
     t0 = time.perf_counter()
-    for _ in range(2):
-        O.joint_step(st, feats, adj, [adj] * M, u, p, ng, draws, hp)
-    t_joint = (time.perf_counter() - t0) / 2
+    O.joint_step(st, feats, adj, [adj] * M, u, p, ng, draws, hp)
+    t_joint = time.perf_counter() - t0
     n_batches = -(-U // B)
     epoch = n_diff * t_diff + n_batches * M * t_reb_unit + n_joint * t_joint
     return {"value": iters_per_epoch / epoch, "unit": "iters/s", "cores": threads, "kind": "port",
-            "sample": f"1 diffusion iter ({t_diff:.2f}s) + 1 of {n_batches * M} rebuild units: T={T} reverse steps on one {B}-user batch, one modality "
-                      f"({t_reb_unit:.2f}s) + 2 joint iters ({t_joint:.2f}s each), extrapolated to an epoch of {epoch:.1f}s; torch {torch.__version__} CPU, "
-                      f"{threads} threads of {os.cpu_count()} cpus"}
+            "sample": f"1 diffusion iter ({t_diff:.2f}s) + {len(units)} of {n_batches * M} rebuild units (T={T} reverse steps on one {B}-user batch + its top-k, one "
+                      f"modality each: {', '.join(f'{x:.2f}s' for x in units)}) + 1 joint iter ({t_joint:.2f}s), extrapolated to an epoch of {epoch:.1f}s; "
+                      f"torch {torch.__version__} CPU at {threads} threads of {os.cpu_count()} cpus (fastest of "
+                      f"{', '.join(f'{k}: {v * 1e3:.0f} ms' for k, v in sweep.items())} on a 2048 x 6720 x 1024 GEMM + tanh)"}
 
 
 def main():
@@ -168,6 +223,8 @@ def main():
     ap.add_argument("--workload", default="tiktok"); ap.add_argument("--T", type=int, default=40); ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--latdim", type=int, default=64); ap.add_argument("--precision", type=int, default=1, choices=(1, 3))
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-shard-roofline", action="store_true", help="skip the 1M x 500k SpMM measurement (roofline_spmm_shard)")
+    ap.add_argument("--no-fp32-like", action="store_true", help="skip the extra precision-3 (bf16 hi/lo split, ~fp32) epochs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
@@ -228,6 +285,19 @@ def main():
     if not args.no_roofline:
         g, s = roofline(coach, args)
         out["roofline"], out["roofline_spmm"] = g, s
+        if world == 1 and not args.no_shard_roofline and args.workload == "tiktok":
+            out["roofline_spmm_shard"] = roofline_spmm_shard()
+    if world == 1 and args.precision == 1 and not args.no_fp32_like:  # the same epochs in split-bf16 (~fp32) arithmetic, next to the bf16 headline
+        coach.precision = 3
+        coach.model.precision = 3
+        coach.trainEpoch(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            coach.trainEpoch()
+        torch.cuda.synchronize()
+        out["config"]["fp32_like_iters_per_s"] = iters_per_epoch * 2 / (time.perf_counter() - t1)
+        coach.precision = 1
+        coach.model.precision = 1
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint)
     print(json.dumps(out))

@@ -152,9 +152,10 @@ __global__ __launch_bounds__(256) void spmm_epilogue_rows_kernel(const SpmmBatch
   }
 }
 
-// XT = float (VEC 4) or __bf16 (VEC 8)
-template <int D, int VEC>
-__global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
+// VEC 4 = fp32 operands, VEC 8 = bf16 operands; DEPTH = X-row gathers in flight per lane; MINW = waves per SIMD the register
+// allocation must leave room for (the kernel is bound by the number of tasks in flight: tools/spmm_scale.py)
+template <int D, int VEC, int DEPTH, int MINW>
+__global__ __launch_bounds__(256, MINW) void spmm_kernel(const SpmmBatch batch) {
   constexpr int LANES = D / VEC;    // lanes per task group
   constexpr int G = 256 / LANES;    // task groups per workgroup
   __shared__ float part[256 * VEC];
@@ -197,11 +198,11 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
         myc = col[base + l];
         myv = val[base + l];
       }
-      for (int j0 = 0; j0 < cnt; j0 += 8) {
-        uint4 x[8];
-        float v[8];
+      for (int j0 = 0; j0 < cnt; j0 += DEPTH) {
+        uint4 x[DEPTH];
+        float v[DEPTH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < DEPTH; ++j) {
           const int c = __shfl(myc, j0 + j, LANES);
           v[j] = __shfl(myv, j0 + j, LANES);
           x[j] = make_uint4(0u, 0u, 0u, 0u);
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmBatch batch) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < DEPTH; ++j) {
           if (VEC == 4) {
             acc.v[0] = fmaf(v[j], __uint_as_float(x[j].x), acc.v[0]);
             acc.v[1] = fmaf(v[j], __uint_as_float(x[j].y), acc.v[1]);
@@ -278,7 +279,13 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) 
 
 template <int D, int VEC>
 static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL((spmm_kernel<D, VEC>), dim3(blocks), dim3(256), 0, s, b);
+  // Measured at 1M users x 500k items, d = 64 (profiles/README.md): fp32 operands are bound by the bytes that miss L2 (450-465 us in
+  // every variant); bf16 operands are bound by the number of tasks in flight -- 4 gathers per lane in 58 VGPRs = 8 waves per SIMD x 8 tasks
+  // per wave: 258 us, against 315 us with 8 gathers in 82 VGPRs (5 waves) and 520 us when 8 gathers are forced into 64 VGPRs (spills).
+  static const int variant = [] { const char* e = getenv("DMM_SPMM_VARIANT"); return e ? atoi(e) : 0; }();  // tuning knob (read once)
+  const bool deep = variant == 0 ? VEC == 4 : variant == 2;
+  if (deep) hipLaunchKernelGGL((spmm_kernel<D, VEC, 8, 4>), dim3(blocks), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((spmm_kernel<D, VEC, 4, 8>), dim3(blocks), dim3(256), 0, s, b);
   int max_fix = 0;
   for (int i = 0; i < b.n; ++i) max_fix = max_fix > b.p[i].n_fix ? max_fix : b.p[i].n_fix;
   if (max_fix > 0) hipLaunchKernelGGL(spmm_fixup_kernel<D>, dim3(max_fix, b.n), dim3(256), 0, s, b);
