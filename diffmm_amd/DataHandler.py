@@ -143,8 +143,15 @@ class TestData:
 
 
 def dense_rows(ptr: torch.Tensor, col: torch.Tensor, users: torch.Tensor, items: int, ld: Optional[int] = None) -> torch.Tensor:
-    """0/1 rows of the interaction matrix for the given users, built on the device from its CSR."""
+    """0/1 rows of the interaction matrix for the given users, built from its CSR: dmm_csr_dense_rows on the GPU (int32 column ids);
+    index plumbing in torch for host tensors (CPU-side tests)."""
     users = users.long()
+    if ptr.is_cuda and col.dtype == torch.int32:
+        from . import ops
+        width = (items + 3) & ~3 if ld is None else ld
+        out = torch.empty((users.shape[0], width), dtype=torch.float32, device=ptr.device)
+        ops.csr_dense_rows(ptr, col, users.contiguous(), items, out)
+        return out if width == items else out[:, :items]
     start, cnt = ptr[users], ptr[users + 1] - ptr[users]
     total = int(cnt.sum())
     out = torch.zeros((users.shape[0], ld or items), dtype=torch.float32, device=ptr.device)
@@ -165,13 +172,19 @@ class DiffusionData:
         o = np.argsort(trn_rows, kind="stable")
         self.ptr = torch.from_numpy(np.searchsorted(np.asarray(trn_rows)[o], np.arange(users + 1)).astype(np.int64)).to(self.device)
         self.col = torch.from_numpy(np.asarray(trn_cols)[o].astype(np.int64)).to(self.device)
+        self.col32 = self.col.to(torch.int32)
         self.deg_ptr32 = self.ptr.to(torch.int32)
 
     def __len__(self) -> int:
         return self.users
 
     def rows(self, idx: torch.Tensor) -> torch.Tensor:
-        return dense_rows(self.ptr, self.col, idx, self.items)
+        return dense_rows(self.ptr, self.col32 if self.ptr.is_cuda else self.col, idx, self.items)
+
+    def csr_rows(self, idx: torch.Tensor):
+        """The same rows without densifying them: what the engines take as x_0 (engine.CsrRows)."""
+        from .engine import CsrRows
+        return CsrRows(self.ptr, self.col32, idx)
 
     def batch(self, idx: torch.Tensor):
         return self.rows(idx), idx

@@ -202,13 +202,13 @@ class Coach:
         diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
         for idx in diff_batches:
             own = idx if lay is None else idx[(idx >= lay.u0) & (idx < lay.u1)]
-            x0 = dd.rows(own)
+            x0 = dd.csr_rows(own)  # x_0 stays CSR: the engine densifies it straight into its operand buffer
             t = noise = None
             if draws is not None:
                 t, noise = [], []
                 for m in range(M):
                     t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
-                    noise.append(draws.randn(tuple(x0.shape)).to(dev))
+                    noise.append(draws.randn((x0.shape[0], int(cfg.data.item_num))).to(dev))
             means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]))
             tot = sum(means)
             for m in range(M):  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
@@ -221,7 +221,8 @@ class Coach:
         if modal_adj_override is None:
             sstep = int(cfg.hyper.sampling_step)
             if lay is None:
-                edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep)
+                edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep,
+                                         csr=(dd.ptr, dd.col32, 0))
                 if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
                     self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim))
             else:  # own users only (local ids index the local CSR; the data rows are looked up by global id)
@@ -230,7 +231,7 @@ class Coach:
                                                                    group=self.group)
                     self._own_local = torch.arange(lay.nu, device=dev)
                 edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [self._own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
-                                         sampling_step=sstep)
+                                         sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0))
             adjs = self.graph_builder.build_all(edges)
         else:
             adjs = list(modal_adj_override)

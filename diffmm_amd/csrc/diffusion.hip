@@ -69,6 +69,64 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// x_0 as CSR rows (the reference keeps a dense U x I matrix on the device, DataHandler.py:128 -- impossible at I = 1e6):
+//   csr_dense_rows      out[b, :ld] = 0/1 row of user rows[b]                              (DiffusionData.__getitem__, DataHandler.py:218-224)
+//   csr_gather_sum      h[b, :] = act(bias + sum_{j in items(rows[b])} Wt[j, :])            (Denoise layer 1 on x_t = x_0: a gather of W1^T
+//                       rows instead of a dense GEMM operand -- the first step of the reverse chain, Model.py:300-322 with sampling_step 0)
+//   csr_add_rows        y[b, j] += c for j in items(rows[b]); y16 = bf16(y) there           (that step's posterior-mean residual c2 * x_0)
+// One workgroup per row; ptr is the CSR of ALL users (int64), col int32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_dense_rows_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                             const long long* __restrict__ rows, float* __restrict__ out, long long ld, int I) {
+  const int b = blockIdx.x;
+  float* __restrict__ o = out + (long long)b * ld;
+  for (long long j = threadIdx.x * 4; j < ld; j += 1024) {
+    if (j + 4 <= ld) *reinterpret_cast<float4*>(o + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else for (long long q = j; q < ld; ++q) o[q] = 0.f;
+  }
+  __syncthreads();
+  const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int c = col[e];
+    if ((unsigned)c < (unsigned)I) o[c] = 1.0f;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void csr_gather_sum_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                             const long long* __restrict__ rows, const __bf16* __restrict__ Wt, long long ldw,
+                                                             const float* __restrict__ bias, __bf16* __restrict__ out16, long long ldo, int H) {
+  const int b = blockIdx.x;
+  const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
+  for (int h0 = threadIdx.x * 4; h0 < H; h0 += 1024) {  // 4 columns (8 bytes of bf16) per thread per pass
+    float a[4] = {bias[h0], bias[h0 + 1], bias[h0 + 2], bias[h0 + 3]};
+    for (long long e = beg; e < end; ++e) {
+      const uint2 w = *reinterpret_cast<const uint2*>(Wt + (long long)col[e] * ldw + h0);
+      a[0] += __uint_as_float(w.x << 16); a[1] += __uint_as_float(w.x & 0xffff0000u);
+      a[2] += __uint_as_float(w.y << 16); a[3] += __uint_as_float(w.y & 0xffff0000u);
+    }
+    __bf16 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (__bf16)(ACT == 1 ? tanhf(a[q]) : a[q]);
+    *reinterpret_cast<uint2*>(out16 + (long long)b * ldo + h0) = *reinterpret_cast<const uint2*>(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void csr_add_rows_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                           const long long* __restrict__ rows, float c, float* __restrict__ y, long long ldy,
+                                                           __bf16* __restrict__ y16, long long ldy16, int I) {
+  const int b = blockIdx.x;
+  const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int j = col[e];
+    if ((unsigned)j >= (unsigned)I) continue;
+    const float v = y[(long long)b * ldy + j] + c;  // a user's items are distinct: no two threads touch one element
+    y[(long long)b * ldy + j] = v;
+    if (y16) y16[(long long)b * ldy16 + j] = (__bf16)v;
+  }
+}
+
 // out[b, :] = a[t_b] * x[b, :] + c[t_b] * y[b, :] with per-row timesteps: GaussianDiffusion.forward_cal_xt with explicit noise
 // (Model.py:339-341: x = x_0, y = noise, tables sqrt(alpha_bar), sqrt(1 - alpha_bar)) and the posterior mean of p_mean_variance
 // (Model.py:375: x = Denoise output, y = x_t, tables posterior_mean_coef1 / coef2) for callers of the reference-named API.
@@ -595,6 +653,35 @@ extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* nois
   hipLaunchKernelGGL(qsample_temb_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)ldx0, noise, t, sqrt_ac, sqrt_1mac, w_emb,
                      b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out);
   DMM_LAUNCH_CHECK("dmm_qsample_temb");
+  return 0;
+}
+
+extern "C" int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && out && B > 0 && I > 0 && ldo >= I && ldo % 4 == 0, "dmm_csr_dense_rows: bad arguments (ldo must be a multiple of 4 >= I)");
+  hipLaunchKernelGGL(csr_dense_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, out, (long long)ldo, I);
+  DMM_LAUNCH_CHECK("dmm_csr_dense_rows");
+  return 0;
+}
+extern "C" int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias,
+                                       int H, int act, void* out16, int64_t ldo, void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && Wt && bias && out16 && B > 0 && H > 0 && H % 4 == 0 && ldw >= H && ldw % 4 == 0 && ldo >= H && ldo % 4 == 0,
+                "dmm_csr_gather_sum_bf16: bad arguments (H, ldw, ldo multiples of 4)");
+  DMM_CHECK_ARG(act == DMM_ACT_NONE || act == DMM_ACT_TANH, "dmm_csr_gather_sum_bf16: act must be NONE or TANH");
+  if (act == DMM_ACT_TANH)
+    hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows,
+                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H);
+  else
+    hipLaunchKernelGGL(csr_gather_sum_kernel<0>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows,
+                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H);
+  DMM_LAUNCH_CHECK("dmm_csr_gather_sum_bf16");
+  return 0;
+}
+extern "C" int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float c, float* y, int64_t ldy, void* y16,
+                                int64_t ldy16, void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && y && B > 0 && I > 0 && ldy >= I && (!y16 || ldy16 >= I), "dmm_csr_add_rows: bad arguments");
+  hipLaunchKernelGGL(csr_add_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, c, y,
+                     (long long)ldy, (__bf16*)y16, (long long)ldy16, I);
+  DMM_LAUNCH_CHECK("dmm_csr_add_rows");
   return 0;
 }
 

@@ -30,6 +30,18 @@ def _align4(n: int) -> int:
     return (n + 3) & ~3
 
 
+class CsrRows:
+    """Rows of the 0/1 interaction matrix named by user id, kept as CSR (ptr int64 over ALL users, col int32): what the engines take
+    instead of a dense [B, I] x_0 (the reference's dense U x I matrix, DataHandler.py:128, cannot exist at I = 1e6)."""
+
+    def __init__(self, ptr: Tensor, col: Tensor, users: Tensor):
+        self.ptr, self.col, self.users = ptr, col, users.to(torch.int64).contiguous()
+
+    @property
+    def shape(self):
+        return (int(self.users.shape[0]),)
+
+
 class FlatParams:
     """Named fp32 tensors carved out of one flat buffer (+ same-layout grad / Adam m / Adam v buffers)."""
 
@@ -383,6 +395,7 @@ class DiffusionEngine:
         self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
         self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
+        self._w1T_chain = None  # bf16 W1^T per modality, allocated by the first CSR chain start
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
@@ -407,10 +420,14 @@ class DiffusionEngine:
         sd["in_layers.0.weight"] = sd["in_layers.0.weight"][:, : self.I + self.te].contiguous()
         return sd
 
-    def _set_x0(self, x0: Tensor) -> Tensor:
+    def _set_x0(self, x0) -> Tensor:
+        """x_0 into the padded operand buffer: a dense [B, I] tensor is copied, CSR rows are densified straight into it (dmm_csr_dense_rows)."""
         B = x0.shape[0]
         x0p = self.x0p[:B]
-        x0p[:, : self.I].copy_(x0)
+        if isinstance(x0, CsrRows):
+            ops.csr_dense_rows(x0.ptr, x0.col, x0.users, self.I, x0p)
+        else:
+            x0p[:, : self.I].copy_(x0)
         return x0p
 
     # -- Denoise.forward on an operand buffer that already holds [x_t | temb | 0] ---------------------
@@ -672,6 +689,10 @@ class DiffusionEngine:
             ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
             ops.temb_bias_table(P.view("emb_layer.weight"), P.view("emb_layer.bias"), P.view("in_layers.0.weight"), self.I, P.view("in_layers.0.bias"),
                                 self.bias_t[m])
+            if self._w1T_chain is not None:  # CSR chain start: layer 1 of the first step gathers rows of W1^T; its layer 2 has no residual
+                ops.transpose_cast_bf16(P.view("in_layers.0.weight"), self._w1T_chain[m], rows=self.H, cols=self.Kp)
+                ops.zero_(self._b2_first[m])  # operand, so the posterior-mean scale c1 goes into alpha and into this pre-scaled bias
+                ops.add_inplace(self._b2_first[m], P.view("out_layers.0.bias"), float(self.c1[self.T - 1]))
             self.w16_step[m] = P.step
 
     def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
@@ -772,6 +793,66 @@ class DiffusionEngine:
         fin = self.cxa if self.T % 2 == 0 else self.cxb
         return [fin[m][:B, :I] for m in range(M)]
 
+    def generate_views_bf16_csr(self, rows: CsrRows) -> List[Tensor]:
+        """All modalities' reverse chains (sampling_step 0: x_T = x_0) started from CSR rows: no dense x_0 exists.  Step T-1 runs layer 1 as a
+        gather of W1^T rows (dmm_csr_gather_sum_bf16: x_0 is 0/1 with ~6 non-zeros per row), layer 2 as the usual GEMM with the epilogue
+        c1 * pred, and adds the residual c2 * x_0 at the row's non-zeros (dmm_csr_add_rows); steps T-2 .. 0 are the dense chain.  One HIP
+        stream per modality, launches recorded once per batch size (the user ids live in a static buffer)."""
+        B, I, M, T = rows.shape[0], self.I, self.M, self.T
+        if self._w1T_chain is None:
+            self._w1T_chain = [torch.zeros(self.Kp, self.H, dtype=torch.bfloat16, device=self.dev) for _ in range(M)]
+            self._b2_first = [torch.zeros(I, dtype=torch.float32, device=self.dev) for _ in range(M)]
+            self.w16_step = [-1] * M
+            self._csr_users = torch.zeros(self.chain_rows, dtype=torch.int64, device=self.dev)
+        for m in range(M):
+            self._refresh_bf16_weights(m)
+        self._csr_users[:B].copy_(rows.users)
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
+            self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
+        key = ("csr", B, rows.ptr.data_ptr(), rows.col.data_ptr())
+        plan = self._chain_plans.get(key)
+        if plan is None:
+            users = self._csr_users[:B]
+            with L.Recorder() as head:
+                for m in range(M):  # temb / pad columns of the ping-pong operands stay zero (temb enters through the bias table)
+                    ops.zero_(self.cxb16[m][:B])
+                    ops.zero_(self.cxa16[m][:B])
+            per = []
+            for m in range(M):
+                with torch.cuda.stream(self._side_streams[m]), L.Recorder() as pm:
+                    b2 = self.P[m].view("out_layers.0.bias")
+                    cur, nxt, cur16, nxt16, h16 = None, self.cxb[m][:B], None, self.cxb16[m][:B], self.ch16[m][:B]
+                    own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
+                    for i in range(T - 1, -1, -1):
+                        if i == T - 1:
+                            ops.csr_gather_sum_bf16(rows.ptr, rows.col, users, self._w1T_chain[m], self.bias_t[m][i], h16, act=L.ACT_TANH)
+                            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
+                            ops.csr_add_rows(rows.ptr, rows.col, users, I, float(self.c2[i]), nxt, nxt16)
+                            cur, nxt, cur16, nxt16 = nxt, own, nxt16, own16
+                            continue
+                        ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
+                        ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
+                        cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
+                per.append(pm)
+            # chains have equal length up to the two extra launches of the first step: interleave launch by launch
+            n = max(len(p_) for p_ in per)
+            plan = dict(head=head, chains=[p_[j] for j in range(n) for p_ in per if j < len(p_)])
+            if len(self._chain_plans) > 16:
+                self._chain_plans.clear()
+            self._chain_plans[key] = plan
+        L.replay(plan["head"])
+        self._side_events[M].record(main)
+        for m in range(M):
+            self._side_streams[m].wait_event(self._side_events[M])
+        L.replay(plan["chains"])
+        for m in range(M):
+            self._side_events[m].record(self._side_streams[m])
+            main.wait_event(self._side_events[m])
+        fin = self.cxb if T % 2 == 1 else self.cxa
+        return [fin[m][:B, :I] for m in range(M)]
+
     def generate_view(self, m: int, x0: Tensor, precision: int = 1) -> Tensor:
         """sampling_step == 0 path: x_T = x0, then T deterministic posterior-mean steps.  Returns a [B, I] view (ld = Kp)."""
         if precision == 1:
@@ -802,10 +883,11 @@ class DiffusionEngine:
         return self._xT[:B, :I]
 
     def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1,
-                      sampling_step: int = 0) -> List[Tensor]:
+                      sampling_step: int = 0, csr: Optional[tuple] = None) -> List[Tensor]:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
         int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]]).  The ids in `user_batches`
         index deg_ptr and are what `dense_rows` receives (a user-sharded replica passes LOCAL ids and maps them itself).
+        csr = (ptr int64 over all users, col int32, id offset): with it (bf16 chain, sampling_step 0) x_0 is never densified.
         sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
         if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow
@@ -816,6 +898,11 @@ class DiffusionEngine:
             user_batches = [all_users[s:s + per] for s in range(0, n, per)]
         for ub in user_batches:
             if ub.numel() == 0:
+                continue
+            if csr is not None and precision == 1 and sampling_step == 0:  # x_0 stays CSR: no dense [rows, I] operand is built
+                views = self.generate_views_bf16_csr(CsrRows(csr[0], csr[1], ub + int(csr[2])))
+                for m in range(self.M):
+                    ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
                 continue
             x0 = dense_rows(ub)
             if precision == 1 and sampling_step == 0:

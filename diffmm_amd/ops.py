@@ -383,6 +383,39 @@ def qsample_temb(x0: Optional[Tensor], noise: Optional[Tensor], t: Tensor, sqrt_
                                      offset, L.ptr(eps_out), L.stream())
 
 
+def _csr_args(ptr: Tensor, col: Tensor, rows: Tensor):
+    if ptr.dtype != torch.int64 or col.dtype != torch.int32 or rows.dtype != torch.int64 or not (ptr.is_contiguous() and col.is_contiguous() and rows.is_contiguous()):
+        raise ValueError("CSR rows: ptr int64, col int32, rows int64, all contiguous")
+    return L.ptr(ptr), L.ptr(col), L.ptr(rows), int(rows.shape[0])
+
+
+def csr_dense_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, out: Tensor) -> Tensor:
+    """out[b, :] = 0/1 interaction row of user rows[b] (whole leading dimension written: columns >= I are zero)."""
+    p, c, r, B = _csr_args(ptr, col, rows)
+    if out.dtype != torch.float32 or out.stride(1) != 1 or out.shape[0] < B or out.shape[1] < I or out.stride(0) % 4 or out.shape[1] != out.stride(0):
+        raise ValueError("csr_dense_rows: out must be fp32 [>= B, ld] with ld % 4 == 0, written over its whole width")
+    if B:
+        L.call("dmm_csr_dense_rows", p, c, r, B, I, L.ptr(out), out.stride(0), L.stream())
+    return out
+
+
+def csr_gather_sum_bf16(ptr: Tensor, col: Tensor, rows: Tensor, Wt: Tensor, bias: Tensor, out16: Tensor, act: int = L.ACT_NONE) -> None:
+    """out16[b] = act(bias + sum of the rows Wt[j] over user rows[b]'s items); Wt bf16 [>= I, H]."""
+    p, c, r, B = _csr_args(ptr, col, rows)
+    H = bias.numel()
+    if Wt.dtype != torch.bfloat16 or out16.dtype != torch.bfloat16 or Wt.stride(1) != 1 or out16.stride(1) != 1 or Wt.shape[1] < H or out16.shape[1] < H or out16.shape[0] < B:
+        raise ValueError("csr_gather_sum_bf16: bad operands")
+    L.call("dmm_csr_gather_sum_bf16", p, c, r, B, L.ptr(Wt), Wt.stride(0), L.ptr(_f32c(bias, "bias")), H, act, L.ptr(out16), out16.stride(0), L.stream())
+
+
+def csr_add_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, c_: float, y: Tensor, y16: Optional[Tensor] = None) -> None:
+    """y[b, j] += c_ for j in user rows[b]'s items (y16, optional, receives the bf16 of the new values)."""
+    p, c, r, B = _csr_args(ptr, col, rows)
+    if y.dtype != torch.float32 or y.stride(1) != 1 or y.shape[0] < B or y.shape[1] < I or (y16 is not None and (y16.dtype != torch.bfloat16 or y16.stride(1) != 1 or y16.shape[1] < I)):
+        raise ValueError("csr_add_rows: bad operands")
+    L.call("dmm_csr_add_rows", p, c, r, B, I, c_, L.ptr(y), y.stride(0), L.ptr(y16), y16.stride(0) if y16 is not None else 0, L.stream())
+
+
 def rows_axpby(x: Tensor, y: Tensor, t: Tensor, a_table: Tensor, c_table: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """out[b] = a_table[t_b] * x[b] + c_table[t_b] * y[b]  (fp32 tables on the device; x, y, out row-strided [B, I] views)."""
     B, I = x.shape

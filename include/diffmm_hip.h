@@ -244,6 +244,18 @@ int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const in
                      const float* sqrt_1mac, const float* w_emb /*[te,te]*/, const float* b_emb /*[te]*/, int te,
                      float* xcat, int64_t ldx, int B, int I, int draw_noise, uint64_t seed, uint64_t offset,
                      float* eps_out, void* stream);
+/* x_0 as CSR rows.  The reference keeps the dense U x I interaction matrix on the device (DataHandler.py:128) and indexes rows out of it
+ * (DataHandler.py:218-224); here the interactions stay CSR (ptr int64 [U+1] over ALL users, col int32) and `rows` (int64 [B]) names the users:
+ *   dmm_csr_dense_rows       out[b, :ldo] = the 0/1 row of user rows[b] (columns >= I zero) -- the dense operand where one is needed;
+ *   dmm_csr_gather_sum_bf16  out16[b, :H] = act(bias + sum_{j in items(rows[b])} Wt[j, :H]), Wt = W^T in bf16 [>= I, ldw]: a Linear layer applied
+ *                            to a 0/1 row is a gather of W^T rows (Denoise layer 1 of the first reverse-chain step, x_T = x_0: Model.py:300-322, :211);
+ *   dmm_csr_add_rows         y[b, j] += c (and y16[b, j] = bf16 of it) for j in items(rows[b]): the posterior-mean residual c2 * x_0 of that step
+ *                            (Model.py:375) without a dense x_0. */
+int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream);
+int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias, int H,
+                            int act, void* out16, int64_t ldo, void* stream);
+int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float c, float* y, int64_t ldy, void* y16, int64_t ldy16,
+                     void* stream);
 /* out[b, :I] = a_table[t_b] * x[b, :I] + c_table[t_b] * y[b, :I] (per-row timesteps): forward_cal_xt with explicit noise (Model.py:339-341)
  * and the posterior mean c1[t] * Denoise(x_t, t) + c2[t] * x_t of p_mean_variance (Model.py:375), for the reference-named Python API
  * (the training / rebuild engines fuse both into their GEMM operands and epilogues). */

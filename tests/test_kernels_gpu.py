@@ -747,6 +747,59 @@ def test_reverse_chains_on_streams_match_single_chain(dev):
         assert float((first[m] - batched[m]).abs().max()) < 2e-3 * float(batched[m].abs().max()), f"modality {m}: streams vs batched launches"
 
 
+def test_csr_rows_equal_the_dense_path(dev):
+    """x_0 as CSR rows (the I = 1e6 configuration cannot hold dense user rows): dmm_csr_dense_rows against the index
+    arithmetic it replaces; a training step fed CSR rows against the same step fed the dense rows (bit-identical: the same operand buffer);
+    the reverse chain started from CSR rows (layer 1 of the first step = a gather of W1^T rows, its residual a sparse add) against the
+    chain started from the dense x_0 -- the same bf16 products and fp32 sums in another order."""
+    from diffmm_amd import ops, synth
+    from diffmm_amd.DataHandler import DiffusionData
+    from diffmm_amd.engine import CsrRows, DiffusionEngine
+    torch.manual_seed(7)
+    g = synth.named("mid")
+    U, I, D, H, M, T_, B = g.users, g.items, 64, 256, 3, 6, 128
+    dd = DiffusionData(g.trn_rows, g.trn_cols, U, I, dev)
+    users = torch.randperm(U, device=dev)[:B]
+    want = torch.zeros(B, I, device=dev)
+    r = torch.from_numpy(g.trn_rows.astype(np.int64)).to(dev); c = torch.from_numpy(g.trn_cols.astype(np.int64)).to(dev)
+    full = torch.zeros(U, I, device=dev); full[r, c] = 1.0
+    want = full[users]
+    assert torch.equal(dd.rows(users), want), "dmm_csr_dense_rows"
+    padded = torch.full((B, 264), 9.0, device=dev)
+    ops.csr_dense_rows(dd.ptr, dd.col32, users, I, padded)
+    assert torch.equal(padded[:, :I], want) and float(padded[:, I:].abs().max()) == 0.0, "whole leading dimension written"
+    hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3, seed=11)
+    E = DiffusionEngine(I, D, H, 10, M, T_, hp, dev, B)
+    for m in range(M):
+        E.P[m].data.normal_(0, 0.05)
+        E.P[m].view("in_layers.0.weight")[:, I + 10:].zero_()
+    feats = [torch.nn.functional.normalize(torch.randn(I, D, device=dev)) for _ in range(M)]
+    ie = torch.randn(I, D, device=dev) * 0.1
+    t = [torch.randint(0, T_, (B,), device=dev, dtype=torch.int32) for _ in range(M)]
+    noise = [torch.randn(B, I, device=dev) for _ in range(M)]
+    rows = dd.csr_rows(users)
+    assert isinstance(rows, CsrRows) and rows.shape == (B,)
+    md = E.train_step(want, feats, ie, t=t, noise=noise, precision=1, update=False)
+    gd = [E.P[m].grad.clone() for m in range(M)]
+    mc = E.train_step(rows, feats, ie, t=t, noise=noise, precision=1, update=False)
+    assert md == mc and all(torch.equal(gd[m], E.P[m].grad) for m in range(M)), "CSR-fed training step == dense-fed training step"
+    dense = [v.clone() for v in E.generate_views_bf16(want)]
+    sparse = E.generate_views_bf16_csr(rows)
+    for m in range(M):
+        scale = float(dense[m].abs().max())
+        assert float((sparse[m] - dense[m]).abs().max()) < 2e-3 * scale, f"modality {m}: CSR chain start vs dense chain"
+    again = [v.clone() for v in sparse]
+    sparse2 = E.generate_views_bf16_csr(rows)
+    assert all(torch.equal(again[m], sparse2[m]) for m in range(M)), "reproducible (recorded plan, static user buffer)"
+    # the rebuild's edges: per-user top-k of both chains agree except at near-ties
+    ptr32 = dd.deg_ptr32
+    e_d = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1)
+    e_s = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1, csr=(dd.ptr, dd.col32, 0))
+    for m in range(M):
+        same = float((e_d[m] == e_s[m]).float().mean())
+        assert same > 0.995, f"modality {m}: {same:.4f} of the rebuilt edges agree"
+
+
 def test_transpose_cast(dev):
     from diffmm_amd import ops
     x = torch.randn(1116, 6710, device=dev)

@@ -15,7 +15,8 @@ def per_kernel(path, counter):
 
 
 def variant(name):
-    return "bf16_xy" if "ELi8E" in name.replace(" ", "") or ", 8," in name else "f32"
+    vec = name.split("<", 1)[1].split(",")[1].strip()  # spmm_kernel<D, VEC, DEPTH, MINW>
+    return "bf16_xy" if vec == "8" else "f32"
 
 
 fetch = per_kernel(os.path.join(src, "fetch", "f_counter_collection.csv"), "FETCH_SIZE")
