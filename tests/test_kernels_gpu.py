@@ -749,7 +749,7 @@ def test_reverse_chains_on_streams_match_single_chain(dev):
 
 def test_csr_rows_equal_the_dense_path(dev):
     """x_0 as CSR rows (the I = 1e6 configuration cannot hold dense user rows): dmm_csr_dense_rows against the index
-    arithmetic it replaces; a training step fed CSR rows against the same step fed the dense rows (bit-identical: the same operand buffer);
+    arithmetic it replaces; a training step fed CSR rows against the same step fed the dense rows (the same operand buffer);
     the reverse chain started from CSR rows (layer 1 of the first step = a gather of W1^T rows, its residual a sparse add) against the
     chain started from the dense x_0 -- the same bf16 products and fp32 sums in another order."""
     from diffmm_amd import ops, synth
@@ -782,7 +782,10 @@ def test_csr_rows_equal_the_dense_path(dev):
     md = E.train_step(want, feats, ie, t=t, noise=noise, precision=1, update=False)
     gd = [E.P[m].grad.clone() for m in range(M)]
     mc = E.train_step(rows, feats, ie, t=t, noise=noise, precision=1, update=False)
-    assert md == mc and all(torch.equal(gd[m], E.P[m].grad) for m in range(M)), "CSR-fed training step == dense-fed training step"
+    # the same operand buffer either way; the step itself accumulates a few products with fp32 atomics, so runs agree to round-off only
+    for m in range(M):
+        assert abs(md[m] - mc[m]) <= 1e-9 * abs(md[m]), "CSR-fed training step == dense-fed training step (loss)"
+        assert float((gd[m] - E.P[m].grad).abs().max()) <= 1e-5 * float(gd[m].abs().max()), "CSR-fed training step == dense-fed training step (gradients)"
     dense = [v.clone() for v in E.generate_views_bf16(want)]
     sparse = E.generate_views_bf16_csr(rows)
     for m in range(M):
