@@ -227,9 +227,8 @@ class DataHandler:
     # -- loading ---------------------------------------------------------------------------------------
     def _read(self) -> synth.SynthGraph:
         if os.path.exists(self.bundle):
-            z = np.load(self.bundle, allow_pickle=False)
-            feats = [z[k].astype(np.float32) for k in sorted(f for f in z.files if f.startswith("feat"))]
-            return synth.SynthGraph(int(z["users"]), int(z["items"]), z["trn_rows"], z["trn_cols"], z["tst_rows"], z["tst_cols"], feats)
+            from .bundle import read_bundle
+            return read_bundle(self.bundle)
         if self.config.data.name in synth.SHAPES:
             return synth.named(self.config.data.name, seed=int(self.config.base.seed))
         raise ValueError(f"Unknown dataset: {self.config.data.name} (no {self.bundle} and no synthetic shape of that name)")

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void csr_add_rows_kernel(const long long* __re
   for (long long e = beg + threadIdx.x; e < end; e += 256) {
     const int j = col[e];
     if ((unsigned)j >= (unsigned)I) continue;
-    const float v = y[(long long)b * ldy + j] + c;  // a user's items are distinct: no two threads touch one element
-    y[(long long)b * ldy + j] = v;
+    // a user's items are distinct: no two threads touch one element.  y == NULL: the row lives in bf16 only (y16 is read and written)
+    const float v = (y ? y[(long long)b * ldy + j] : (float)y16[(long long)b * ldy16 + j]) + c;
+    if (y) y[(long long)b * ldy + j] = v;
     if (y16) y16[(long long)b * ldy16 + j] = (__bf16)v;
   }
 }
@@ -678,7 +679,7 @@ extern "C" int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, c
 }
 extern "C" int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float c, float* y, int64_t ldy, void* y16,
                                 int64_t ldy16, void* stream) {
-  DMM_CHECK_ARG(ptr && col && rows && y && B > 0 && I > 0 && ldy >= I && (!y16 || ldy16 >= I), "dmm_csr_add_rows: bad arguments");
+  DMM_CHECK_ARG(ptr && col && rows && (y || y16) && B > 0 && I > 0 && (!y || ldy >= I) && (!y16 || ldy16 >= I), "dmm_csr_add_rows: bad arguments");
   hipLaunchKernelGGL(csr_add_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, c, y,
                      (long long)ldy, (__bf16*)y16, (long long)ldy16, I);
   DMM_LAUNCH_CHECK("dmm_csr_add_rows");

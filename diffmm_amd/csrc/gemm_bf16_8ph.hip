@@ -133,15 +133,35 @@ __device__ __forceinline__ void p8_st_edge(T* p, const float (&v)[4], int nv) {
   if (nv > 2) p[2] = (T)v[2];
 }
 
-template <int PASS, bool HAS_R, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
-__device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float*& pR,
+// Residual kinds: RK = 0 none, 1 fp32 rows (R), 2 bf16 rows (Rb: the reverse chain with its running x_t kept in bf16 only).  pR is a byte
+// pointer to the lane's four columns of the pass's first row, rs the row stride in bytes.
+template <int RK>
+__device__ __forceinline__ float4 p8_ld_res(const char* p) {
+  if (RK == 1) return p8_ld_stream(reinterpret_cast<const float*>(p));
+  const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+  return make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u));
+}
+template <int RK>
+__device__ __forceinline__ float4 p8_ld_res_edge(const char* p, int nv) {
+  if (RK == 1) return p8_ld_edge(reinterpret_cast<const float*>(p), nv);
+  const __bf16* b = reinterpret_cast<const __bf16*>(p);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nv > 0) r.x = (float)b[0];
+  if (nv > 1) r.y = (float)b[1];
+  if (nv > 2) r.z = (float)b[2];
+  return r;
+}
+
+template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
+__device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const char*& pR, long long rs,
                                              float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8], int mrow, int nv) {
+  constexpr bool HAS_R = RK != 0;
   if (HAS_R && PASS < 2) {  // two passes ahead: 16 KiB of residual rows in flight per wave while a pass is being stored
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const float* p = pR + (long long)(64 + it * 4) * E.ldr;
-      if (!EDGE) rnext[it] = p8_ld_stream(p);
-      else if (mrow + PASS * 32 + 64 + it * 4 < E.M) rnext[it] = nv == 4 ? p8_ld_stream(p) : p8_ld_edge(p, nv);
+      const char* p = pR + (long long)(64 + it * 4) * rs;
+      if (!EDGE) rnext[it] = p8_ld_res<RK>(p);
+      else if (mrow + PASS * 32 + 64 + it * 4 < E.M) rnext[it] = nv == 4 ? p8_ld_res<RK>(p) : p8_ld_res_edge<RK>(p, nv);
       else rnext[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
@@ -174,13 +194,14 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
   __builtin_amdgcn_wave_barrier();
-  if (HAS_R) pR += 32 * E.ldr;
+  if (HAS_R) pR += 32 * rs;
   if (HAS_C) pC += 32 * E.ldc;
   if (HAS_CB) pCb += 32 * E.ldcb;
 }
 
-template <bool HAS_R, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
+template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
 __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
+  constexpr bool HAS_R = RK != 0;
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
   float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
   const int n = n0 + wc * 64 + fr * 4;
@@ -189,28 +210,29 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
   const int nv = EDGE ? max(0, min(4, E.N - n)) : 4;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (E.bias) b4 = nv == 4 ? *reinterpret_cast<const float4*>(E.bias + n) : p8_ld_edge(E.bias + n, nv);
-  const float* pR = HAS_R ? E.R + m * E.ldr + n : nullptr;
+  const long long rs = RK == 1 ? E.ldr * 4 : E.ldrb * 2;
+  const char* pR = RK == 1 ? reinterpret_cast<const char*>(E.R + m * E.ldr + n) : RK == 2 ? reinterpret_cast<const char*>(E.Rb + m * E.ldrb + n) : nullptr;
   float* pC = HAS_C ? E.C + m * E.ldc + n : nullptr;
   __bf16* pCb = HAS_CB ? E.Cb + m * E.ldcb + n : nullptr;
   float4 ra[8], rb[8], rc[8];
   if (HAS_R) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const float* p0 = pR + (long long)(it * 4) * E.ldr;
-      const float* p1 = pR + (long long)(32 + it * 4) * E.ldr;
+      const char* p0 = pR + (long long)(it * 4) * rs;
+      const char* p1 = pR + (long long)(32 + it * 4) * rs;
       if (!EDGE) {
-        ra[it] = p8_ld_stream(p0);
-        rb[it] = p8_ld_stream(p1);
+        ra[it] = p8_ld_res<RK>(p0);
+        rb[it] = p8_ld_res<RK>(p1);
       } else {
-        ra[it] = mrow + it * 4 < E.M ? (nv == 4 ? p8_ld_stream(p0) : p8_ld_edge(p0, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rb[it] = mrow + 32 + it * 4 < E.M ? (nv == 4 ? p8_ld_stream(p1) : p8_ld_edge(p1, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[it] = mrow + it * 4 < E.M ? (nv == 4 ? p8_ld_res<RK>(p0) : p8_ld_res_edge<RK>(p0, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[it] = mrow + 32 + it * 4 < E.M ? (nv == 4 ? p8_ld_res<RK>(p1) : p8_ld_res_edge<RK>(p1, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   }
-  p8_fast_pass<0, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
-  p8_fast_pass<1, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
-  p8_fast_pass<2, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, rc, rb, mrow, nv);
-  p8_fast_pass<3, HAS_R, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, pC, pCb, ra, rb, mrow, nv);
+  p8_fast_pass<0, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
+  p8_fast_pass<1, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
+  p8_fast_pass<2, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, rc, rb, mrow, nv);
+  p8_fast_pass<3, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, ra, rb, mrow, nv);
 }
 
 // Edge tiles, unaligned operands and the rarely used operand combinations: bounds-checked, element-wise where needed.
@@ -254,23 +276,29 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
   E.ldc = P.ldc; E.ldcb = P.ldcb; E.ldr = P.ldr; E.ldrb = P.ldrb;
   E.M = P.M; E.N = P.N; E.act = P.act; E.alpha = P.alpha; E.e1 = P.e1; E.e2 = P.e2;
   const bool vec_ok = (!E.C || (E.ldc % 4 == 0 && ((uintptr_t)E.C & 15) == 0)) && (!E.Cb || (E.ldcb % 4 == 0 && ((uintptr_t)E.Cb & 7) == 0));
-  const bool fast = vec_ok && !E.Rb && (!E.bias || ((uintptr_t)E.bias & 15) == 0) && (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0));
+  const bool fast = vec_ok && (!E.bias || ((uintptr_t)E.bias & 15) == 0) && (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0)) &&
+                    (!E.Rb || (!E.R && E.ldrb % 4 == 0 && ((uintptr_t)E.Rb & 7) == 0));
   const bool interior = m0 + 256 <= E.M && n0 + 256 <= E.N;
 #define P8_FAST(R_, C_, CB_, ACT_)                                                                   \
   do {                                                                                               \
     if (interior) p8_epilogue_fast<R_, C_, CB_, ACT_, false>(E, acc, smem, m0, n0, wave, lane);      \
     else p8_epilogue_fast<R_, C_, CB_, ACT_, true>(E, acc, smem, m0, n0, wave, lane);                \
   } while (0)
-  if (fast && !E.R && !E.C && E.Cb && E.act == DMM_ACT_TANH) {
-    P8_FAST(false, false, true, DMM_ACT_TANH);
-  } else if (fast && !E.R && !E.C && E.Cb && E.act == DMM_ACT_NONE) {
-    P8_FAST(false, false, true, DMM_ACT_NONE);
+  const bool noR = !E.R && !E.Rb;
+  if (fast && noR && !E.C && E.Cb && E.act == DMM_ACT_TANH) {
+    P8_FAST(0, false, true, DMM_ACT_TANH);
+  } else if (fast && noR && !E.C && E.Cb && E.act == DMM_ACT_NONE) {
+    P8_FAST(0, false, true, DMM_ACT_NONE);
   } else if (fast && E.R && E.C && E.Cb && E.act == DMM_ACT_NONE) {
-    P8_FAST(true, true, true, DMM_ACT_NONE);
-  } else if (fast && !E.R && E.C && !E.Cb && E.act == DMM_ACT_NONE) {
-    P8_FAST(false, true, false, DMM_ACT_NONE);
-  } else if (fast && !E.R && E.C && E.Cb && E.act == DMM_ACT_TANH) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
-    P8_FAST(false, true, true, DMM_ACT_TANH);
+    P8_FAST(1, true, true, DMM_ACT_NONE);
+  } else if (fast && E.Rb && !E.C && E.Cb && E.act == DMM_ACT_NONE) {  // reverse chain, bf16 running state: x_t in, x_{t-1} out, both bf16
+    P8_FAST(2, false, true, DMM_ACT_NONE);
+  } else if (fast && E.Rb && E.C && !E.Cb && E.act == DMM_ACT_NONE) {  // its last step: the fp32 view the top-k reads
+    P8_FAST(2, true, false, DMM_ACT_NONE);
+  } else if (fast && noR && E.C && !E.Cb && E.act == DMM_ACT_NONE) {
+    P8_FAST(0, true, false, DMM_ACT_NONE);
+  } else if (fast && noR && E.C && E.Cb && E.act == DMM_ACT_TANH) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
+    P8_FAST(0, true, true, DMM_ACT_TANH);
 #undef P8_FAST
   } else {
     float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;

@@ -751,6 +751,23 @@ class DiffusionEngine:
         fin = self.cxa if self.T % 2 == 0 else self.cxb
         return [fin[m][:B, :I] for m in range(M)]
 
+    def _bf16_state(self) -> bool:
+        """Precision of the reverse chain's running x_t between steps.  "bf16" (default): only the bf16 copy the next layer-1 GEMM reads
+        anyway is carried -- layer 2's epilogue moves 4 instead of 10 bytes per element (it is HBM-bound: DESIGN 4.2); the last step writes
+        the fp32 view the top-k ranks.  What the state's low bits can still influence is damped by the posterior coefficients: the last
+        step has c2 = 0, c1 = 1 (x_0' = Denoise(x_1) exactly), the steps before it c2 = 0.28, 0.45, ...  "fp32" keeps round 1's fp32 state."""
+        return self.hp.get("chain_state", os.environ.get("DMM_CHAIN_STATE", "bf16")) == "bf16"
+
+    def _chain_layer2(self, m: int, i: int, h16: Tensor, cur: Tensor, cur16: Tensor, nxt: Tensor, nxt16: Tensor):
+        """Layer 2 of chain step i with the posterior mean c1[i] * pred + c2[i] * x_t as its epilogue (Model.py:375)."""
+        b2, e1, e2, I = self.P[m].view("out_layers.0.bias"), float(self.c1[i]), float(self.c2[i]), self.I
+        if not self._bf16_state():
+            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=e1, e2=e2, N=I)
+        elif i > 0:
+            ops.gemm_bf16_nt(h16, self.w2_16[m], out_bf16=nxt16, bias=b2, residual_bf16=cur16, e1=e1, e2=e2, N=I)
+        else:
+            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, bias=b2, residual_bf16=cur16, e1=e1, e2=e2, N=I)
+
     def _generate_views_streams(self, B: int) -> List[Tensor]:
         """The modalities' chains are independent: each runs on its own HIP stream.  A layer-2 launch ends every workgroup in an
         HBM-bound epilogue (fp32 state read + write, bf16 copy) and a layer-1 launch leaves CUs idle in its last round; with three
@@ -761,7 +778,7 @@ class DiffusionEngine:
         if not hasattr(self, "_side_streams"):
             self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
             self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
-        plan = self._chain_plans.get(("streams", B))
+        plan = self._chain_plans.get(("streams", B, self._bf16_state()))
         if plan is None:
             with L.Recorder() as head:  # on the caller's stream, before the chains fork: the shared bf16 copy of x_0
                 ops.cast_bf16(self.cx0[:B], self.cx016[:B], cols=I, cols_pad=self.Kp)
@@ -775,13 +792,12 @@ class DiffusionEngine:
                     own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
                     for i in range(self.T - 1, -1, -1):
                         ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
-                        ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self.P[m].view("out_layers.0.bias"), residual=cur,
-                                         e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
+                        self._chain_layer2(m, i, h16, cur, cur16, nxt, nxt16)
                         # the first step read the shared x_0 buffers; from then on the chain ping-pongs between its own pair
                         cur, nxt, cur16, nxt16 = nxt, (own if i == self.T - 1 else cur), nxt16, (own16 if i == self.T - 1 else cur16)
                 per.append(pm)
             plan = dict(head=head, chains=[c for group in zip(*per) for c in group])  # same length per chain: interleave launch by launch
-            self._chain_plans[("streams", B)] = plan
+            self._chain_plans[("streams", B, self._bf16_state())] = plan
         L.replay(plan["head"])
         self._side_events[M].record(main)
         for m in range(M):
@@ -811,7 +827,7 @@ class DiffusionEngine:
         if not hasattr(self, "_side_streams"):
             self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
             self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
-        key = ("csr", B, rows.ptr.data_ptr(), rows.col.data_ptr())
+        key = ("csr", B, rows.ptr.data_ptr(), rows.col.data_ptr(), self._bf16_state())
         plan = self._chain_plans.get(key)
         if plan is None:
             users = self._csr_users[:B]
@@ -827,13 +843,14 @@ class DiffusionEngine:
                     own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
                     for i in range(T - 1, -1, -1):
                         if i == T - 1:
+                            keep32 = not self._bf16_state() or i == 0  # the fp32 row is only needed by the residual of an fp32-state chain / the top-k
                             ops.csr_gather_sum_bf16(rows.ptr, rows.col, users, self._w1T_chain[m], self.bias_t[m][i], h16, act=L.ACT_TANH)
-                            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
-                            ops.csr_add_rows(rows.ptr, rows.col, users, I, float(self.c2[i]), nxt, nxt16)
+                            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt if keep32 else None, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
+                            ops.csr_add_rows(rows.ptr, rows.col, users, I, float(self.c2[i]), nxt if keep32 else None, nxt16)
                             cur, nxt, cur16, nxt16 = nxt, own, nxt16, own16
                             continue
                         ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
-                        ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
+                        self._chain_layer2(m, i, h16, cur, cur16, nxt, nxt16)
                         cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
                 per.append(pm)
             # chains have equal length up to the two extra launches of the first step: interleave launch by launch

@@ -408,12 +408,13 @@ def csr_gather_sum_bf16(ptr: Tensor, col: Tensor, rows: Tensor, Wt: Tensor, bias
     L.call("dmm_csr_gather_sum_bf16", p, c, r, B, L.ptr(Wt), Wt.stride(0), L.ptr(_f32c(bias, "bias")), H, act, L.ptr(out16), out16.stride(0), L.stream())
 
 
-def csr_add_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, c_: float, y: Tensor, y16: Optional[Tensor] = None) -> None:
-    """y[b, j] += c_ for j in user rows[b]'s items (y16, optional, receives the bf16 of the new values)."""
+def csr_add_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, c_: float, y: Optional[Tensor], y16: Optional[Tensor] = None) -> None:
+    """y[b, j] += c_ for j in user rows[b]'s items (y16, optional, receives the bf16 of the new values; y None: y16 alone holds the row)."""
     p, c, r, B = _csr_args(ptr, col, rows)
-    if y.dtype != torch.float32 or y.stride(1) != 1 or y.shape[0] < B or y.shape[1] < I or (y16 is not None and (y16.dtype != torch.bfloat16 or y16.stride(1) != 1 or y16.shape[1] < I)):
+    if (y is None and y16 is None) or (y is not None and (y.dtype != torch.float32 or y.stride(1) != 1 or y.shape[0] < B or y.shape[1] < I)) or \
+            (y16 is not None and (y16.dtype != torch.bfloat16 or y16.stride(1) != 1 or y16.shape[1] < I or y16.shape[0] < B)):
         raise ValueError("csr_add_rows: bad operands")
-    L.call("dmm_csr_add_rows", p, c, r, B, I, c_, L.ptr(y), y.stride(0), L.ptr(y16), y16.stride(0) if y16 is not None else 0, L.stream())
+    L.call("dmm_csr_add_rows", p, c, r, B, I, c_, L.ptr(y), y.stride(0) if y is not None else 0, L.ptr(y16), y16.stride(0) if y16 is not None else 0, L.stream())
 
 
 def rows_axpby(x: Tensor, y: Tensor, t: Tensor, a_table: Tensor, c_table: Tensor, out: Optional[Tensor] = None) -> Tensor:

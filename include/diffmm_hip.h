@@ -250,7 +250,7 @@ int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const in
  *   dmm_csr_gather_sum_bf16  out16[b, :H] = act(bias + sum_{j in items(rows[b])} Wt[j, :H]), Wt = W^T in bf16 [>= I, ldw]: a Linear layer applied
  *                            to a 0/1 row is a gather of W^T rows (Denoise layer 1 of the first reverse-chain step, x_T = x_0: Model.py:300-322, :211);
  *   dmm_csr_add_rows         y[b, j] += c (and y16[b, j] = bf16 of it) for j in items(rows[b]): the posterior-mean residual c2 * x_0 of that step
- *                            (Model.py:375) without a dense x_0. */
+ *                            (Model.py:375) without a dense x_0; y == NULL: the row is kept in bf16 only (y16 read and written). */
 int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream);
 int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias, int H,
                             int act, void* out16, int64_t ldo, void* stream);

@@ -130,27 +130,32 @@ def test_epoch_with_noised_chain_start(precision):
             assert len(items) == deg[u] and len(set(items.tolist())) == deg[u] and (items >= U).all()
 
 
-def test_checkpoint_resume_continues_the_run(tmp_path):
+@pytest.mark.parametrize("sampling_step", [0, 1])
+def test_checkpoint_resume_continues_the_run(tmp_path, sampling_step):
     """Coach.save_checkpoint / load_checkpoint: a fresh Coach that loads the checkpoint written after epoch 1 produces the same epoch 2
-    as the uninterrupted run (up to the summation order of the fp32 atomics in the training kernels)."""
+    as the uninterrupted run (up to the summation order of the fp32 atomics in the training kernels).  sampling_step = 1 also exercises
+    the Philox position of the noised chain starts (restored on a freshly built engine) and the best-metric bookkeeping."""
     need_gpu()
     z = load("epoch_mid.npz")
 
     def fresh():
         coach, h, M = _coach(z)
         coach.precision = 1
+        coach.config.hyper.sampling_step = sampling_step
         h.trainLoader.fixed_perm = h.diffusionLoader.fixed_perm = None  # real shuffling: the loader generators are part of the state
         return coach
 
     a = fresh()
     torch.manual_seed(11); torch.cuda.manual_seed_all(11)
     a.trainEpoch()
+    a.best, a.his_max = dict(Recall=0.25, NDCG=0.125, Precision=0.0625, epoch=0), [0.25, 0.125, 0.0625]
     ck = os.path.join(tmp_path, "ck.pt")
     a.save_checkpoint(ck)
     res_a = a.trainEpoch()
     b = fresh()
     b.load_checkpoint(ck)
-    assert b.epoch_idx == 1
+    assert b.epoch_idx == 1 and b.best == a.best and b.his_max == a.his_max
+    assert b.diff_engine._xT_calls == (a.M if sampling_step else 0), "Philox position of the noised chain starts"
     res_b = b.trainEpoch()
     for k in res_a:
         assert abs(res_a[k] - res_b[k]) <= 1e-4 * abs(res_a[k]) + 1e-7, (k, res_a[k], res_b[k])

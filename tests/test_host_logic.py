@@ -150,3 +150,43 @@ def test_shipped_configs_load():
     with pytest.raises(TypeError):
         load_config(fh.name)
     os.unlink(fh.name)
+
+
+def test_bundle_round_trip_and_reference_feature_files(tmp_path):
+    """the .npz bundle writer / reader (what DataHandler.LoadData picks up) round-trips a data set exactly (fp32 features) or to
+    fp16 (the reference's on-disk precision); the reference's own .npy feature files load with allow_pickle=False.  (Its interaction
+    matrices are pickles and are never opened.)"""
+    import os
+    from diffmm_amd import bundle, synth
+    from diffmm_amd.Conf import load_config
+    from diffmm_amd.DataHandler import DataHandler
+    g = synth.named("mid")
+    p = bundle.write_bundle(str(tmp_path / "Datasets" / "mid" / "mid.npz"), g.users, g.items, g.trn_rows, g.trn_cols, g.tst_rows, g.tst_cols, g.feats,
+                            feat_dtype=np.float32)
+    r = bundle.read_bundle(p)
+    assert (r.users, r.items) == (g.users, g.items)
+    for a, b in ((r.trn_rows, g.trn_rows), (r.trn_cols, g.trn_cols), (r.tst_rows, g.tst_rows), (r.tst_cols, g.tst_cols)):
+        assert a.dtype == np.int32 and np.array_equal(a, b)
+    assert len(r.feats) == len(g.feats) and all(np.array_equal(a, b) for a, b in zip(r.feats, g.feats))
+    p16 = bundle.write_bundle(str(tmp_path / "h.npz"), g.users, g.items, g.trn_rows, g.trn_cols, g.tst_rows, g.tst_cols, g.feats)
+    r16 = bundle.read_bundle(p16)
+    assert all(np.array_equal(a, b.astype(np.float16).astype(np.float32)) for a, b in zip(r16.feats, g.feats))
+    with pytest.raises(ValueError):
+        bundle.write_bundle(str(tmp_path / "bad.npz"), g.users, g.items, g.trn_rows + g.users, g.trn_cols, g.tst_rows, g.tst_cols, g.feats)
+    # the CLI writes the same file; DataHandler reads it from ./Datasets/<name>/<name>.npz
+    bundle.main(["--synth", "toy", "--out", str(tmp_path / "Datasets" / "toy" / "toy.npz")])
+    cfg = load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf", "tiktok.toml"))
+    cfg.data.name, cfg.train.batch = "toy", 8
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        h = DataHandler(cfg)
+        t = synth.named("toy")
+        got = h._read()
+        assert np.array_equal(got.trn_rows, t.trn_rows) and np.array_equal(got.tst_cols, t.tst_cols) and got.feats[0].shape == t.feats[0].shape
+    finally:
+        os.chdir(cwd)
+    ref = "/root/reference/Datasets/tiktok/image_feat.npy"  # present in the build container only
+    if os.path.exists(ref):
+        f = bundle.load_feature_npy(ref)
+        assert f.dtype == np.float32 and f.shape == (6710, 128) and np.isfinite(f).all()
