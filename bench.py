@@ -79,9 +79,9 @@ def roofline(coach, args):
             ops.cast_bf16(DE.cxa[m][:rows], DE.cxa16[m][:rows])
         t1 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.cxa16[m][:rows], B=DE.w1_16[m], out_bf16=DE.ch16[m][:rows], bias=DE.bias_t[m][0],
                                                                    act=L.ACT_TANH) for m in range(M)]), 10)
-        t2 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.ch16[m][:rows], B=DE.w2_16[m], out=DE.cxb[m][:rows], out_bf16=DE.cxb16[m][:rows],
-                                                                   bias=DE.P[m].view("out_layers.0.bias"), residual=DE.cxa[m][:rows], e1=0.5, e2=0.5, N=I)
-                                                              for m in range(M)]), 10)
+        # layer 2 exactly as the chain issues it (an inner step: i = 1 -- the running x_t in bf16 by default, DiffusionEngine._bf16_state)
+        t2 = timed_launches(lambda: ops.gemm_bf16_nt_batched([DE._chain_layer2_args(m, 1, DE.ch16[m][:rows], DE.cxa[m][:rows], DE.cxa16[m][:rows],
+                                                                                    DE.cxb[m][:rows], DE.cxb16[m][:rows]) for m in range(M)]), 10)
     else:
         t1 = timed_launches(lambda: ops.gemm(x, P.view("in_layers.0.weight"), out=h, trans_b=True, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH,
                                              precision=args.precision), 20)
@@ -97,7 +97,7 @@ def roofline(coach, args):
     sb = A.algorithmic_bytes(4)
     gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_8ph_kernel (256x256 LDS-DMA tile): Denoise layer 1 of the reverse chain, {nb} modalities x ({rows} x {Kp}) x ({H} x {Kp})^T per launch", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
             "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6,
-            "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6}
+            "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6, "layer2_state": "bf16" if DE._bf16_state() else "fp32"}
     spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sb / ts / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": ts * 1e6, "algorithmic_bytes": sb}
     try:  # fabric-side traffic per launch from the committed PMC passes (profiles/README.md); bench.py itself cannot run rocprofv3

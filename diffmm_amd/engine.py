@@ -701,7 +701,7 @@ class DiffusionEngine:
         B, I, P, Kp = x0.shape[0], self.I, self.P[m], self.Kp
         self._refresh_bf16_weights(m)
         self.xa[:B, :I].copy_(x0)
-        plan = self._chain_plans.get((m, B))
+        plan = self._chain_plans.get((m, B, self._bf16_state()))
         if plan is None:  # 2 T + 2 launches on static buffers: record once, replay for every user batch and epoch
             with L.Recorder() as plan:
                 cur, nxt, cur16, nxt16, h16 = self.xa[:B], self.xb[:B], self.xa16[:B], self.xb16[:B], self.h16[:B]
@@ -710,9 +710,9 @@ class DiffusionEngine:
                 b2 = P.view("out_layers.0.bias")
                 for i in range(self.T - 1, -1, -1):
                     ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
-                    ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=float(self.c1[i]), e2=float(self.c2[i]), N=I)
+                    self._chain_layer2(m, i, h16, cur, cur16, nxt, nxt16)
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
-            self._chain_plans[(m, B)] = plan
+            self._chain_plans[(m, B, self._bf16_state())] = plan
         L.replay(plan)
         return (self.xa if self.T % 2 == 0 else self.xb)[:B, :I]
 
@@ -732,7 +732,7 @@ class DiffusionEngine:
             return self._generate_views_streams(B)
         for m in range(M):
             self.cxa[m][:B, :I].copy_(x0)
-        plan = self._chain_plans.get(("all", B))
+        plan = self._chain_plans.get(("all", B, self._bf16_state()))
         if plan is None:
             with L.Recorder() as plan:
                 cur, nxt = [t[:B] for t in self.cxa], [t[:B] for t in self.cxb]
@@ -743,10 +743,9 @@ class DiffusionEngine:
                 for i in range(self.T - 1, -1, -1):
                     ops.gemm_bf16_nt_batched([dict(A=cur16[m], B=self.w1_16[m], out_bf16=h16[m], bias=self.bias_t[m][i], act=L.ACT_TANH)
                                               for m in range(M)])
-                    ops.gemm_bf16_nt_batched([dict(A=h16[m], B=self.w2_16[m], out=nxt[m], out_bf16=nxt16[m], bias=self.P[m].view("out_layers.0.bias"),
-                                                   residual=cur[m], e1=float(self.c1[i]), e2=float(self.c2[i]), N=I) for m in range(M)])
+                    ops.gemm_bf16_nt_batched([self._chain_layer2_args(m, i, h16[m], cur[m], cur16[m], nxt[m], nxt16[m]) for m in range(M)])
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
-            self._chain_plans[("all", B)] = plan
+            self._chain_plans[("all", B, self._bf16_state())] = plan
         L.replay(plan)
         fin = self.cxa if self.T % 2 == 0 else self.cxb
         return [fin[m][:B, :I] for m in range(M)]
@@ -758,15 +757,19 @@ class DiffusionEngine:
         step has c2 = 0, c1 = 1 (x_0' = Denoise(x_1) exactly), the steps before it c2 = 0.28, 0.45, ...  "fp32" keeps round 1's fp32 state."""
         return self.hp.get("chain_state", os.environ.get("DMM_CHAIN_STATE", "bf16")) == "bf16"
 
-    def _chain_layer2(self, m: int, i: int, h16: Tensor, cur: Tensor, cur16: Tensor, nxt: Tensor, nxt16: Tensor):
+    def _chain_layer2_args(self, m: int, i: int, h16: Tensor, cur: Tensor, cur16: Tensor, nxt: Tensor, nxt16: Tensor) -> dict:
         """Layer 2 of chain step i with the posterior mean c1[i] * pred + c2[i] * x_t as its epilogue (Model.py:375)."""
-        b2, e1, e2, I = self.P[m].view("out_layers.0.bias"), float(self.c1[i]), float(self.c2[i]), self.I
+        a = dict(A=h16, B=self.w2_16[m], bias=self.P[m].view("out_layers.0.bias"), e1=float(self.c1[i]), e2=float(self.c2[i]), N=self.I)
         if not self._bf16_state():
-            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=b2, residual=cur, e1=e1, e2=e2, N=I)
+            a.update(out=nxt, out_bf16=nxt16, residual=cur)
         elif i > 0:
-            ops.gemm_bf16_nt(h16, self.w2_16[m], out_bf16=nxt16, bias=b2, residual_bf16=cur16, e1=e1, e2=e2, N=I)
+            a.update(out_bf16=nxt16, residual_bf16=cur16)
         else:
-            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, bias=b2, residual_bf16=cur16, e1=e1, e2=e2, N=I)
+            a.update(out=nxt, residual_bf16=cur16)
+        return a
+
+    def _chain_layer2(self, m: int, i: int, h16: Tensor, cur: Tensor, cur16: Tensor, nxt: Tensor, nxt16: Tensor):
+        ops.gemm_bf16_nt(**self._chain_layer2_args(m, i, h16, cur, cur16, nxt, nxt16))
 
     def _generate_views_streams(self, B: int) -> List[Tensor]:
         """The modalities' chains are independent: each runs on its own HIP stream.  A layer-2 launch ends every workgroup in an

@@ -745,6 +745,12 @@ def test_reverse_chains_on_streams_match_single_chain(dev):
     batched = E.generate_views_bf16(x0)
     for m in range(M):
         assert float((first[m] - batched[m]).abs().max()) < 2e-3 * float(batched[m].abs().max()), f"modality {m}: streams vs batched launches"
+    # the running x_t carried in bf16 (default) against the fp32 state of round 1: what the state's low bits can move is bounded by the
+    # bf16 rounding of a value the next layer reads in bf16 anyway (and the last step has c2 = 0: its output is Denoise(x_1) exactly)
+    E.hp["chain_streams"], E.hp["chain_state"] = True, "fp32"
+    wide = E.generate_views_bf16(x0)
+    for m in range(M):
+        assert float((first[m] - wide[m]).abs().max()) < 1e-2 * float(wide[m].abs().max()), f"modality {m}: bf16 state vs fp32 state"
 
 
 def test_csr_rows_equal_the_dense_path(dev):
