@@ -846,10 +846,11 @@ class DiffusionEngine:
                     own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
                     for i in range(T - 1, -1, -1):
                         if i == T - 1:
-                            keep32 = not self._bf16_state() or i == 0  # the fp32 row is only needed by the residual of an fp32-state chain / the top-k
+                            # (this one step also writes the fp32 row: the sparse residual is added to it and rounded to bf16 once, like the
+                            # dense chain's fused epilogue)
                             ops.csr_gather_sum_bf16(rows.ptr, rows.col, users, self._w1T_chain[m], self.bias_t[m][i], h16, act=L.ACT_TANH)
-                            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt if keep32 else None, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
-                            ops.csr_add_rows(rows.ptr, rows.col, users, I, float(self.c2[i]), nxt if keep32 else None, nxt16)
+                            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
+                            ops.csr_add_rows(rows.ptr, rows.col, users, I, float(self.c2[i]), nxt, nxt16)
                             cur, nxt, cur16, nxt16 = nxt, own, nxt16, own16
                             continue
                         ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
