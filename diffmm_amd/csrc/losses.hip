@@ -467,6 +467,137 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
     }
 }
 
+template <int PER>
+__device__ __forceinline__ void inb_gload(uint4 (&stage)[PER], const __bf16* const (&src)[PER], size_t off) {
+#pragma unroll
+  for (int i = 0; i < PER; ++i) stage[i] = *reinterpret_cast<const uint4*>(src[i] + off);
+}
+template <int PER>
+__device__ __forceinline__ void inb_sstore(const uint4 (&stage)[PER], __bf16* dst) {
+#pragma unroll
+  for (int i = 0; i < PER; ++i) *reinterpret_cast<uint4*>(dst + (size_t)i * 256 * 8) = stage[i];
+}
+
+// The same backward with the walk over the other view SHARED by the four waves of a workgroup: every 32-row tile of the other view
+// (its row-fragment block for the logits and its k-packed transposed block for the output product: 2 x 32 x D bf16, contiguous in the
+// pack) is copied once into LDS (double-buffered, one barrier per tile; the next tile's global loads are in flight under the math)
+// and read by all four waves -- a quarter of the L2 traffic of the per-wave walk above, which was latency-bound on exactly those loads
+// (MFMA pipe 12 % busy).  Each wave now owns its 32 rows over the WHOLE walk, so the K split and its 4x atomics are gone: one
+// atomicAdd per output element and (term, pass) -- a slot still takes part in several terms.
+template <int D, int PREC>
+__global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
+                                                               float* __restrict__ dzhat) {
+  constexpr int NB = PREC == 3 ? 4 : 2;   // blocks per tile: hi, hiT (+ lo, loT)
+  constexpr int BLK = 32 * D;             // bf16 elements per block
+  constexpr int TILE = NB * BLK;
+  constexpr int PER = TILE / 8 / 256;     // 16-byte chunks per thread and tile
+  static_assert(TILE % (8 * 256) == 0, "tile must split into whole 16-byte chunks per thread");
+  extern __shared__ __attribute__((aligned(16))) __bf16 sm_oth[];  // [2][TILE]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const int t = blockIdx.y, pass = blockIdx.z;
+  const int o0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = o0 < B;
+  const dmm_infonce_term term = T.t[t];
+  const int own_slot = pass == 0 ? term.a : term.b, oth_slot = pass == 0 ? term.b : term.a;
+  const int tiles = pk.Bp >> 5;
+  const size_t oth_base = (size_t)oth_slot * tiles * BLK;
+
+  // per-thread source pointers of its PER chunks (tile 0); a tile step advances every block by BLK elements
+  const __bf16* src[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = i * 256 + tid, blk = c / (BLK / 8), w = c % (BLK / 8);
+    src[i] = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)w * 8;
+  }
+  uint4 stage[PER];
+#define INB_GLOAD(kt_) inb_gload<PER>(stage, src, (size_t)(kt_) * BLK)
+#define INB_SSTORE(buf_) inb_sstore<PER>(stage, sm_oth + (size_t)(buf_) * TILE + (size_t)tid * 8)
+
+  bf16x8 own_h[D / 16], own_l[D / 16];
+  const int otile = active ? (o0 >> 5) : 0;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const size_t o = frag_off<D>(own_slot, tiles, otile, ks, fh, fr);
+    own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+    if (PREC == 3) own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
+  }
+  f32x16 out[D / 32];
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[cb][r] = 0.f;
+  const float inv_t = 1.0f / term.temp;
+  const float* __restrict__ ls = lse + (size_t)t * B;
+  const int oidx = o0 + fr;
+  const float lse_own = ls[oidx < B ? oidx : B - 1];
+
+  INB_GLOAD(0);
+  INB_SSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < tiles; ++kt) {
+    const __bf16* S = sm_oth + (size_t)(kt & 1) * TILE;
+    if (kt + 1 < tiles) { INB_GLOAD(kt + 1); }  // in flight under this tile's math
+    if (active) {
+      const int k0 = kt * 32;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
+        const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(S + fo);
+        if (PREC == 3) {
+          const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(S + 2 * BLK + fo);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, own_h[ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_l[ks], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_h[ks], acc, 0, 0, 0);
+      }
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kidx = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const float l = pass == 0 ? lse_own : ls[kidx < B ? kidx : B - 1];
+        p[r] = kidx < B ? __expf(acc[r] * inv_t - l) - (kidx == oidx ? 1.f : 0.f) : 0.f;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {  // k-step s2 of the output MFMA covers tile rows 16 s2 .. 16 s2 + 15 in accumulator order
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ph[j] = (__bf16)p[8 * s2 + j];
+          if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < D / 32; ++cb) {
+          const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
+          const bf16x8 t_h = *reinterpret_cast<const bf16x8*>(S + BLK + to);
+          if (PREC == 3) {
+            const bf16x8 t_l = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
+            out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, t_h, out[cb], 0, 0, 0);
+            out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_l, out[cb], 0, 0, 0);
+          }
+          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_h, out[cb], 0, 0, 0);
+        }
+      }
+    }
+    // the other buffer was last read in iteration kt - 1, which every wave left through the barrier below
+    if (kt + 1 < tiles) { INB_SSTORE((kt + 1) & 1); }
+    __syncthreads();
+  }
+#undef INB_GLOAD
+#undef INB_SSTORE
+  if (!active) return;
+  const float coef = term.weight * inv_t / (float)B;
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = o0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (row < B) atomicAdd(dzhat + ((size_t)own_slot * B + row) * D + cb * 32 + fr, out[cb][r] * coef);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BPR forward + backward
 // ---------------------------------------------------------------------------------------------
@@ -632,8 +763,21 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
   if (bf16_pack && precision != 0 && mfma_ok(D)) {
     DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_bwd: precision must be 0 (fp32 VALU), 1 or 3");
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
-    static const int ks_env = [] { const char* e = getenv("DMM_INFONCE_KSPLIT"); return e ? atoi(e) : 0; }();  // tuning knob
-    const int ksplit = ks_env > 0 ? ks_env : INFONCE_KSPLIT;
+    static const int ks_env = [] { const char* e = getenv("DMM_INFONCE_KSPLIT"); return e ? atoi(e) : 0; }();  // tuning knob: > 0 = the per-wave walk
+    if (ks_env <= 0) {  // default: the LDS-shared walk
+      const size_t lds = (size_t)2 * (precision == 3 ? 4 : 2) * 32 * D * 2;
+      static const bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 128 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 256 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<256, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 256 * 2);
+        return true;
+      }();
+      (void)once;
+      DISPATCH_MFMA(D, precision, infonce_bwd_lds_kernel, dim3(cdiv(B, 128), n_terms, 2), dim3(256), lds, (hipStream_t)stream, pk, lse, T, B, dzhat);
+      DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma, lds)");
+      return 0;
+    }
+    const int ksplit = ks_env;
     DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2 * ksplit), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
     DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma)");
     return 0;
