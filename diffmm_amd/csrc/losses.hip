@@ -467,32 +467,108 @@ __global__ __launch_bounds__(256) void infonce_bwd_mfma_kernel(Bf16Pack pk, cons
     }
 }
 
-template <int PER>
-__device__ __forceinline__ void inb_gload(uint4 (&stage)[PER], const __bf16* const (&src)[PER], size_t off) {
-#pragma unroll
-  for (int i = 0; i < PER; ++i) stage[i] = *reinterpret_cast<const uint4*>(src[i] + off);
-}
-template <int PER>
-__device__ __forceinline__ void inb_sstore(const uint4 (&stage)[PER], __bf16* dst) {
-#pragma unroll
-  for (int i = 0; i < PER; ++i) *reinterpret_cast<uint4*>(dst + (size_t)i * 256 * 8) = stage[i];
-}
-
 // The same backward with the walk over the other view SHARED by the four waves of a workgroup: every 32-row tile of the other view
 // (its row-fragment block for the logits and its k-packed transposed block for the output product: 2 x 32 x D bf16, contiguous in the
-// pack) is copied once into LDS (double-buffered, one barrier per tile; the next tile's global loads are in flight under the math)
-// and read by all four waves -- a quarter of the L2 traffic of the per-wave walk above, which was latency-bound on exactly those loads
-// (MFMA pipe 12 % busy).  Each wave now owns its 32 rows over the WHOLE walk, so the K split and its 4x atomics are gone: one
-// atomicAdd per output element and (term, pass) -- a slot still takes part in several terms.
+// pack) is brought into an LDS ring by LDS-DMA (global_load_lds, no staging registers), NS - 1 tiles ahead of the math, and read by
+// all four waves -- a quarter of the L2 traffic of the per-wave walk above, which was latency-bound on exactly those loads (MFMA pipe
+// 12 % busy).  Completion is counted (s_waitcnt vmcnt((NS - 2) * PER): the younger tiles stay in flight across the raw s_barrier).
+// Each wave owns its 32 rows over the WHOLE walk, so the K split and its 4x atomics are gone: one atomicAdd per output element and
+// (term, pass) -- a slot still takes part in several terms.
+template <int D, int PREC>
+struct InbShape {
+  static constexpr int NB = PREC == 3 ? 4 : 2;   // blocks per tile: hi, hiT (+ lo, loT)
+  static constexpr int BLK = 32 * D;             // bf16 elements per block
+  static constexpr int TILE = NB * BLK;
+  static constexpr int PER = TILE / 8 / 256;     // 16-byte LDS-DMA pieces per lane and tile
+  static constexpr int NS = TILE * 2 * 4 <= 131072 ? 4 : (TILE * 2 * 3 <= 131072 ? 3 : 2);  // ring stages
+  static constexpr int LDS_BYTES = NS * TILE * 2;
+};
+template <int N>
+__device__ __forceinline__ void inb_wait_vmcnt() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // conservative for shapes without a dedicated immediate
+}
+
+// One 32-row tile of the other view (LDS image S) against the wave's 32 own rows: logits (transposed: other index in the accumulator
+// registers, own index on the lane), probabilities minus the identity, and their product with the other rows added into `out`.
+// CHECK = false drops the per-element bounds and diagonal tests (two compares and two selects per element of a VALU-bound loop).
+template <int D, int PREC, bool CHECK>
+__device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16], f32x16 (&out)[D / 32], int k0,
+                                         int oidx, int B, float c1, bool own_lse, float l2_own, const float* ls_lds, int fr, int fh) {
+  constexpr int BLK = 32 * D;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
+    const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(S + fo);
+    if (PREC == 3) {
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(S + 2 * BLK + fo);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, own_h[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_l[ks], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_h[ks], acc, 0, 0, 0);
+  }
+  float p[16], l2[16];
+  if (own_lse) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) l2[r] = l2_own;
+  } else if (!CHECK) {  // accumulator registers 4g .. 4g+3 hold four consecutive other rows: one 16-byte LDS read each
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(ls_lds + k0 + 8 * g + 4 * fh);
+      l2[4 * g] = v.x; l2[4 * g + 1] = v.y; l2[4 * g + 2] = v.z; l2[4 * g + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kidx = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      l2[r] = ls_lds[kidx < B ? kidx : B - 1];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kidx = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    p[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c1, -l2[r]));
+    if (CHECK) p[r] = kidx < B ? p[r] - (kidx == oidx ? 1.f : 0.f) : 0.f;
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {  // k-step s2 of the output MFMA covers tile rows 16 s2 .. 16 s2 + 15 in accumulator order
+    bf16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ph[j] = (__bf16)p[8 * s2 + j];
+      if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb) {
+      const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
+      const bf16x8 t_h = *reinterpret_cast<const bf16x8*>(S + BLK + to);
+      if (PREC == 3) {
+        const bf16x8 t_l = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, t_h, out[cb], 0, 0, 0);
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_l, out[cb], 0, 0, 0);
+      }
+      out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_h, out[cb], 0, 0, 0);
+    }
+  }
+}
+
 template <int D, int PREC>
 __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
                                                                float* __restrict__ dzhat) {
-  constexpr int NB = PREC == 3 ? 4 : 2;   // blocks per tile: hi, hiT (+ lo, loT)
-  constexpr int BLK = 32 * D;             // bf16 elements per block
-  constexpr int TILE = NB * BLK;
-  constexpr int PER = TILE / 8 / 256;     // 16-byte chunks per thread and tile
-  static_assert(TILE % (8 * 256) == 0, "tile must split into whole 16-byte chunks per thread");
-  extern __shared__ __attribute__((aligned(16))) __bf16 sm_oth[];  // [2][TILE]
+  using Sh = InbShape<D, PREC>;
+  constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS;
+  static_assert(TILE % (8 * 256) == 0, "tile must split into whole 16-byte pieces per lane");
+  extern __shared__ __attribute__((aligned(16))) __bf16 sm_oth[];  // [NS][TILE]
+  typedef __attribute__((address_space(3))) void* lds_p;
+  typedef const __attribute__((address_space(1))) void* gbl_p;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
   const int t = blockIdx.y, pass = blockIdx.z;
   const int o0 = (blockIdx.x * 4 + wave) * 32;
@@ -502,16 +578,17 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
   const int tiles = pk.Bp >> 5;
   const size_t oth_base = (size_t)oth_slot * tiles * BLK;
 
-  // per-thread source pointers of its PER chunks (tile 0); a tile step advances every block by BLK elements
-  const __bf16* src[PER];
+  // piece i of a tile: 16 bytes per lane, pieces of one wave-instruction contiguous (what LDS-DMA writes: base + 16 * lane)
+  auto issue = [&](int kt, int stage) {
+    const int k = kt < tiles ? kt : tiles - 1;  // past the end: a redundant copy of the last tile (keeps the DMA count per iteration fixed)
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = i * 256 + tid, blk = c / (BLK / 8), w = c % (BLK / 8);
-    src[i] = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)w * 8;
-  }
-  uint4 stage[PER];
-#define INB_GLOAD(kt_) inb_gload<PER>(stage, src, (size_t)(kt_) * BLK)
-#define INB_SSTORE(buf_) inb_sstore<PER>(stage, sm_oth + (size_t)(buf_) * TILE + (size_t)tid * 8)
+    for (int i = 0; i < PER; ++i) {
+      const int c0 = i * 256 + wave * 64;        // first chunk of this wave-instruction
+      const int c = c0 + lane, blk = c / (BLK / 8), w = c % (BLK / 8);
+      const __bf16* src = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)k * BLK + (size_t)w * 8;
+      __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(sm_oth + (size_t)stage * TILE + (size_t)c0 * 8), 16, 0, 0);
+    }
+  };
 
   bf16x8 own_h[D / 16], own_l[D / 16];
   const int otile = active ? (o0 >> 5) : 0;
@@ -530,63 +607,30 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
   const float* __restrict__ ls = lse + (size_t)t * B;
   const int oidx = o0 + fr;
   const float lse_own = ls[oidx < B ? oidx : B - 1];
+  // pass 1 indexes the log-sum-exp by the OTHER row: the term's whole lse vector goes to LDS once, so that the walk issues no
+  // register loads (a waited register load would drain the LDS-DMA queue: vector-memory operations retire in order)
+  float* const ls_lds = reinterpret_cast<float*>(sm_oth + (size_t)NS * TILE);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c1 = inv_t * LOG2E, l2_own = lse_own * LOG2E;  // p = exp(s / temp - lse) = exp2(s * c1 - lse * log2 e): one fma + one v_exp
+  if (pass == 1)
+    for (int i = tid; i < B; i += 256) ls_lds[i] = ls[i] * LOG2E;
+  // the register loads above are out of the counted window, and the LDS stores have landed before the first (raw) barrier
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-  INB_GLOAD(0);
-  INB_SSTORE(0);
-  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j) issue(j, j);
   for (int kt = 0; kt < tiles; ++kt) {
-    const __bf16* S = sm_oth + (size_t)(kt & 1) * TILE;
-    if (kt + 1 < tiles) { INB_GLOAD(kt + 1); }  // in flight under this tile's math
+    inb_wait_vmcnt<(NS - 2) * PER>();  // this wave's pieces of tile kt have landed (the NS - 2 younger tiles stay in flight)
+    asm volatile("s_barrier" ::: "memory");  // ... every wave's pieces; and every wave is done reading tile kt - 1
+    issue(kt + NS - 1, (kt + NS - 1) % NS);  // into the stage tile kt - 1 occupied
+    const __bf16* S = sm_oth + (size_t)(kt % NS) * TILE;
     if (active) {
-      const int k0 = kt * 32;
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
-        const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
-        const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(S + fo);
-        if (PREC == 3) {
-          const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(S + 2 * BLK + fo);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, own_h[ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_l[ks], acc, 0, 0, 0);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_h[ks], acc, 0, 0, 0);
-      }
-      float p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kidx = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const float l = pass == 0 ? lse_own : ls[kidx < B ? kidx : B - 1];
-        p[r] = kidx < B ? __expf(acc[r] * inv_t - l) - (kidx == oidx ? 1.f : 0.f) : 0.f;
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {  // k-step s2 of the output MFMA covers tile rows 16 s2 .. 16 s2 + 15 in accumulator order
-        bf16x8 ph, pl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          ph[j] = (__bf16)p[8 * s2 + j];
-          if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
-        }
-#pragma unroll
-        for (int cb = 0; cb < D / 32; ++cb) {
-          const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
-          const bf16x8 t_h = *reinterpret_cast<const bf16x8*>(S + BLK + to);
-          if (PREC == 3) {
-            const bf16x8 t_l = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
-            out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, t_h, out[cb], 0, 0, 0);
-            out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_l, out[cb], 0, 0, 0);
-          }
-          out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_h, out[cb], 0, 0, 0);
-        }
-      }
+      // bounds / diagonal handling only where it can matter: the tile that holds the wave's own rows and the (padded) last tile
+      if (kt == otile || kt == tiles - 1) inb_tile<D, PREC, true>(S, own_h, own_l, out, kt * 32, oidx, B, c1, pass == 0, l2_own, ls_lds, fr, fh);
+      else inb_tile<D, PREC, false>(S, own_h, own_l, out, kt * 32, oidx, B, c1, pass == 0, l2_own, ls_lds, fr, fh);
     }
-    // the other buffer was last read in iteration kt - 1, which every wave left through the barrier below
-    if (kt + 1 < tiles) { INB_SSTORE((kt + 1) & 1); }
-    __syncthreads();
   }
-#undef INB_GLOAD
-#undef INB_SSTORE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing redundant copies have landed before the workgroup's LDS goes away
   if (!active) return;
   const float coef = term.weight * inv_t / (float)B;
 #pragma unroll
@@ -596,6 +640,19 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
       const int row = o0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
       if (row < B) atomicAdd(dzhat + ((size_t)own_slot * B + row) * D + cb * 32 + fr, out[cb][r] * coef);
     }
+}
+
+constexpr int INB_MAX_B = 8192;  // the term's lse vector (4 B per batch row) sits in LDS behind the ring: 32 KiB at most
+template <int D, int PREC>
+static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat) {
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              InbShape<D, PREC>::LDS_BYTES + INB_MAX_B * 4);
+    return true;
+  }();
+  (void)once;
+  const size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES + (size_t)((B + 3) & ~3) * 4;
+  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, lse, T, B, dzhat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -764,20 +821,19 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
     DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_bwd: precision must be 0 (fp32 VALU), 1 or 3");
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
     static const int ks_env = [] { const char* e = getenv("DMM_INFONCE_KSPLIT"); return e ? atoi(e) : 0; }();  // tuning knob: > 0 = the per-wave walk
-    if (ks_env <= 0) {  // default: the LDS-shared walk
-      const size_t lds = (size_t)2 * (precision == 3 ? 4 : 2) * 32 * D * 2;
-      static const bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 128 * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 256 * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<256, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 256 * 2);
-        return true;
-      }();
-      (void)once;
-      DISPATCH_MFMA(D, precision, infonce_bwd_lds_kernel, dim3(cdiv(B, 128), n_terms, 2), dim3(256), lds, (hipStream_t)stream, pk, lse, T, B, dzhat);
+    if (ks_env <= 0 && B <= INB_MAX_B) {  // default: the LDS-shared walk
+      const dim3 grid(cdiv(B, 128), n_terms, 2);
+      hipStream_t st = (hipStream_t)stream;
+      switch (D) {
+        case 32: if (precision == 3) inb_launch<32, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<32, 1>(grid, st, pk, lse, T, B, dzhat); break;
+        case 64: if (precision == 3) inb_launch<64, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<64, 1>(grid, st, pk, lse, T, B, dzhat); break;
+        case 128: if (precision == 3) inb_launch<128, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<128, 1>(grid, st, pk, lse, T, B, dzhat); break;
+        case 256: if (precision == 3) inb_launch<256, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<256, 1>(grid, st, pk, lse, T, B, dzhat); break;
+      }
       DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma, lds)");
       return 0;
     }
-    const int ksplit = ks_env;
+    const int ksplit = ks_env > 0 ? ks_env : INFONCE_KSPLIT;
     DISPATCH_MFMA(D, precision, infonce_bwd_mfma_kernel, dim3(cdiv(B, 128), n_terms, 2 * ksplit), dim3(256), 0, (hipStream_t)stream, pk, lse, T, B, dzhat);
     DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma)");
     return 0;
