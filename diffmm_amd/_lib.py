@@ -61,6 +61,7 @@ _SIGS = {
     "dmm_spmm_csr_bf16": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
     "dmm_spmm_epilogue_rows": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
     "dmm_gemm": (C.c_int, [C.POINTER(GemmArgs), _P]),
+    "dmm_gemm_batched": (C.c_int, [C.POINTER(GemmArgs), _I, _P]),
     "dmm_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmBf16Args), _P]),
     "dmm_gemm_bf16_nt_batched": (C.c_int, [C.POINTER(GemmBf16Args), _I, _P]),
     "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),

@@ -14,6 +14,8 @@
 //     16 distinct 16-byte slots (5 is coprime to 16) -> conflict-free fragment reads;
 //   * the next K tile's global loads are issued before the MFMAs of the current one (register prefetch), so HBM/L2
 //     latency hides under the matrix work; 4 workgroups per CU (<= 128 VGPRs, 20-40 KiB LDS) hide the barriers.
+#include <algorithm>
+
 #include "common.h"
 
 namespace dmm {
@@ -121,8 +123,18 @@ __device__ __forceinline__ void store_tile(const Stage& st, char* hi, char* lo) 
   }
 }
 
+// Up to GEMM_MAX_BATCH problems of one operand layout in one launch (the modalities' small projections: each alone fills a fifth
+// of the chip).  blockIdx.y runs over the problems' row tiles back to back; grid.x / grid.z are the largest column-tile / K-slice
+// counts, workgroups beyond a problem's own counts leave at once.
+constexpr int GEMM_MAX_BATCH = 4;
+struct GemmBatchP {
+  GemmP p[GEMM_MAX_BATCH];
+  int ybegin[GEMM_MAX_BATCH + 1];
+  int n;
+};
+
 template <bool AKC, bool BKC, int PREC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP P) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatchP Bt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = BM * PITCH;  // 10240 bytes
   char* a_hi = smem;
@@ -130,10 +142,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP P) {
   char* a_lo = smem + 2 * TILE;
   char* b_lo = smem + 3 * TILE;
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_BATCH; ++i)
+    if (i < Bt.n && (int)blockIdx.y >= Bt.ybegin[i]) pi = i;
+  const GemmP& P = Bt.p[pi];
+  const int m0 = ((int)blockIdx.y - Bt.ybegin[pi]) * BM, n0 = blockIdx.x * BN;
   const int total_tiles = (P.K + BK - 1) / BK;
   const int kt_begin = blockIdx.z * P.k_tiles_per_slice;
   const int kt_end = min(total_tiles, kt_begin + P.k_tiles_per_slice);
+  if (n0 >= P.N || (blockIdx.z > 0 && kt_begin >= kt_end)) return;  // (uniform per workgroup: before any barrier)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP P) {
 }
 
 template <bool AKC, bool BKC>
-static void launch_prec(const GemmP& P, dim3 grid, hipStream_t s, int prec) {
+static void launch_prec(const GemmBatchP& P, dim3 grid, hipStream_t s, int prec) {
   if (prec == 3)
     hipLaunchKernelGGL((gemm_kernel<AKC, BKC, 3>), grid, dim3(256), 4 * BM * PITCH, s, P);
   else
@@ -225,7 +243,7 @@ static void launch_prec(const GemmP& P, dim3 grid, hipStream_t s, int prec) {
 }  // namespace dmm
 using namespace dmm;
 
-extern "C" int dmm_gemm(const dmm_gemm_args* a, void* stream) {
+static int gemm_fill(const dmm_gemm_args* a, GemmP& P, bool& akc, bool& bkc, int& split) {
   DMM_CHECK_ARG(a && a->A && a->B && a->C, "dmm_gemm: null operand");
   DMM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "dmm_gemm: bad shape %d x %d x %d", a->M, a->N, a->K);
   DMM_CHECK_ARG(a->precision == 1 || a->precision == 3, "dmm_gemm: precision must be 1 or 3");
@@ -233,29 +251,52 @@ extern "C" int dmm_gemm(const dmm_gemm_args* a, void* stream) {
   DMM_CHECK_ARG(a->sbk == 1 || a->sbn == 1, "dmm_gemm: B must be contiguous along k or n");
   DMM_CHECK_ARG(a->split_k >= 1, "dmm_gemm: split_k >= 1");
   DMM_CHECK_ARG(a->split_k == 1 || (a->act == DMM_ACT_NONE && !a->R && !a->accumulate), "dmm_gemm: split_k > 1 needs act=NONE, R=NULL, accumulate=0");
-  GemmP P;
   P.A = a->A; P.sam = a->sam; P.sak = a->sak;
   P.B = a->B; P.sbk = a->sbk; P.sbn = a->sbn;
   P.C = a->C; P.ldc = a->ldc; P.bias = a->bias; P.R = a->R; P.ldr = a->ldr;
   P.M = a->M; P.N = a->N; P.K = a->K;
   P.alpha = a->alpha; P.e1 = a->e1; P.e2 = a->e2;
   P.act = a->act; P.split_k = a->split_k; P.accumulate = a->accumulate;
-  const bool akc = a->sak == 1 && !(a->sam == 1 && a->M > 1 && a->K == 1);
-  const bool bkc = a->sbk == 1 && !(a->sbn == 1 && a->N > 1 && a->K == 1);
+  akc = a->sak == 1 && !(a->sam == 1 && a->M > 1 && a->K == 1);
+  bkc = a->sbk == 1 && !(a->sbn == 1 && a->N > 1 && a->K == 1);
   const long long lda = akc ? a->sam : a->sak, ldb = bkc ? a->sbn : a->sbk;
   P.vecA = (((uintptr_t)a->A & 15) == 0) && (lda % 4 == 0);
   P.vecB = (((uintptr_t)a->B & 15) == 0) && (ldb % 4 == 0);
   const int tiles = (a->K + BK - 1) / BK;
-  int split = a->split_k > tiles ? tiles : a->split_k;
+  split = a->split_k > tiles ? tiles : a->split_k;
   P.k_tiles_per_slice = (tiles + split - 1) / split;
   split = (tiles + P.k_tiles_per_slice - 1) / P.k_tiles_per_slice;
   P.split_k = a->split_k > 1 ? (split > 1 ? split : 2) : 1;  // keep the atomic epilogue whenever the caller pre-zeroed C
-  dim3 grid(cdiv(a->N, BN), cdiv(a->M, BM), split);
+  return 0;
+}
+
+extern "C" int dmm_gemm_batched(const dmm_gemm_args* a, int n, void* stream) {
+  DMM_CHECK_ARG(a && n >= 1 && n <= GEMM_MAX_BATCH, "dmm_gemm_batched: 1..%d problems", GEMM_MAX_BATCH);
+  GemmBatchP Bt;
+  memset(&Bt, 0, sizeof(Bt));
+  Bt.n = n;
+  bool akc0 = false, bkc0 = false;
+  int y = 0, gx = 0, gz = 1;
+  for (int i = 0; i < n; ++i) {
+    bool akc, bkc;
+    int split;
+    if (int rc = gemm_fill(a + i, Bt.p[i], akc, bkc, split)) return rc;
+    if (i == 0) { akc0 = akc; bkc0 = bkc; }
+    DMM_CHECK_ARG(akc == akc0 && bkc == bkc0 && a[i].precision == a[0].precision, "dmm_gemm_batched: problem %d differs in operand layout or precision", i);
+    Bt.ybegin[i] = y;
+    y += (int)cdiv(a[i].M, BM);
+    gx = std::max(gx, (int)cdiv(a[i].N, BN));
+    gz = std::max(gz, split);
+  }
+  for (int i = n; i <= GEMM_MAX_BATCH; ++i) Bt.ybegin[i] = y;
+  dim3 grid(gx, y, gz);
   hipStream_t s = (hipStream_t)stream;
-  if (akc && bkc) launch_prec<true, true>(P, grid, s, a->precision);
-  else if (akc && !bkc) launch_prec<true, false>(P, grid, s, a->precision);
-  else if (!akc && bkc) launch_prec<false, true>(P, grid, s, a->precision);
-  else launch_prec<false, false>(P, grid, s, a->precision);
+  if (akc0 && bkc0) launch_prec<true, true>(Bt, grid, s, a[0].precision);
+  else if (akc0 && !bkc0) launch_prec<true, false>(Bt, grid, s, a[0].precision);
+  else if (!akc0 && bkc0) launch_prec<false, true>(Bt, grid, s, a[0].precision);
+  else launch_prec<false, false>(Bt, grid, s, a[0].precision);
   DMM_LAUNCH_CHECK("dmm_gemm");
   return 0;
 }
+
+extern "C" int dmm_gemm(const dmm_gemm_args* a, void* stream) { return dmm_gemm_batched(a, 1, stream); }

@@ -124,12 +124,25 @@ def spmm(adj: Adjacency, x: Tensor, y: Optional[Tensor] = None, **kw) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
-def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None,
-         act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
-         precision: int = 1, split_k: int = 1, accumulate: bool = False, M: Optional[int] = None, N: Optional[int] = None,
-         K: Optional[int] = None) -> Tensor:
+def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, **kw) -> Tensor:
     """out[M,N] = post(act(alpha * op(A) op(B) + bias)); op(A) = A^T if trans_a (A stored [K, M]); op(B) = B^T if trans_b
     (B stored [N, K], the nn.Linear weight layout).  A, B, out, residual may be row-strided views (last dim contiguous)."""
+    g, out = _gemm_args(A, B, out, **kw)
+    L.call("dmm_gemm", C.byref(g), L.stream())
+    return out
+
+
+def gemm_batched(problems: Sequence[dict]) -> None:
+    """Up to 4 problems (dicts of gemm() arguments incl. A, B, out) of one operand layout and precision in ONE launch."""
+    args = [_gemm_args(**p)[0] for p in problems]
+    arr = (L.GemmArgs * len(args))(*args)
+    L.call("dmm_gemm_batched", arr, len(args), L.stream())
+
+
+def _gemm_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None,
+               act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
+               precision: int = 1, split_k: int = 1, accumulate: bool = False, M: Optional[int] = None, N: Optional[int] = None,
+               K: Optional[int] = None):
     for nm, t in (("A", A), ("B", B)):
         if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
             raise ValueError(f"gemm {nm}: need a 2-D float32 tensor with unit inner stride")
@@ -160,8 +173,8 @@ def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: bool = 
     g.M, g.N, g.K = m, n, k
     g.alpha, g.e1, g.e2, g.act = alpha, e1, e2, act
     g.split_k, g.precision, g.accumulate = split_k, precision, int(accumulate)
-    L.call("dmm_gemm", C.byref(g), L.stream())
-    return out
+    g._keep = (A, B, out, bias, residual)
+    return g, out
 
 
 def _bf16_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, *, bias: Optional[Tensor] = None,

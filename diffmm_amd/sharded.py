@@ -214,9 +214,10 @@ class ShardedJointEngine:
 
     # -- forward of gcn_MM (+ the 3 perturbed CL layers) ---------------------------------------------------
     def _project(self, precision: int):
-        for m, nm in enumerate(modality_names(self.M)):  # replicated: every replica needs all normalised item features as SpMM operand
-            ops.gemm(self.feats[m], self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
-                     precision=precision)
+        # replicated: every replica needs all normalised item features as SpMM operand; one launch for the modalities' projections
+        ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
+                               precision=precision) for m, nm in enumerate(modality_names(self.M))])
+        for m in range(self.M):
             ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
 
     def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3):
@@ -342,16 +343,17 @@ class ShardedJointEngine:
         ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
                         dw=self.P.g("modal_weight"), partials=self.mix_partials, count=(nu * D, (nu + i0) * D, (nu + i1) * D))
         self._spmm([dict(adj=A, x_lo=self.dBx, y=self.P.g("emb"))] + [dict(adj=self.modal_adj[m], x_lo=self.dZ[m], y=self.T[m]) for m in range(M)])
-        for m, nm in enumerate(modality_names(M)):  # projection backward: this replica's slice of the items
-            gw, gb = self.P.g(f"{nm}_layer.weight"), self.P.g(f"{nm}_layer.bias")
-            ops.zero_(gw)
-            if i1 > i0:
-                ops.rownorm_bwd(self.T[m][nu + i0:nu + i1], self.nf[m][i0:i1], self.fnorm[m][i0:i1], self.dfeat[m][i0:i1])
-                ops.gemm(self.dfeat[m][i0:i1], self.feats[m][i0:i1], out=gw, trans_a=True, precision=precision, split_k=128)
-                ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, gb)
-            else:
-                ops.zero_(gb)
         ne = self.n * D
+        names = modality_names(M)
+        mw = self.P.offsets["modal_weight"]
+        ops.zero_(self.P.grad[ne:mw])  # projection weights (accumulated by K slices) and biases; d(modal_weight) behind them was just written
+        if i1 > i0:  # projection backward: this replica's slice of the items, the modalities' weight gradients in one launch
+            for m in range(M):
+                ops.rownorm_bwd(self.T[m][nu + i0:nu + i1], self.nf[m][i0:i1], self.fnorm[m][i0:i1], self.dfeat[m][i0:i1])
+            ops.gemm_batched([dict(A=self.dfeat[m][i0:i1], B=self.feats[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), trans_a=True, precision=precision,
+                                   split_k=128) for m, nm in enumerate(names)])
+            for m, nm in enumerate(names):
+                ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, self.P.g(f"{nm}_layer.bias"))
         self._ar(self.P.grad[ne:])  # projections + modal_weight: partial sums over disjoint node sets
         if update:
             self.apply_adam()

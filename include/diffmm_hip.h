@@ -121,6 +121,9 @@ typedef struct dmm_gemm_args {
   int32_t accumulate; /* 1: C += result (plain read-modify-write, split_k == 1) */
 } dmm_gemm_args;
 int dmm_gemm(const dmm_gemm_args* a /*host*/, void* stream);
+/* up to 4 problems of one operand layout (NN / NT / TN) and precision in one launch; M, N, K, split_k and the epilogues are per problem
+ * (the modalities' projections Linear_m(E_m) and their weight gradients: Model.py:84-85,103) */
+int dmm_gemm_batched(const dmm_gemm_args* a /*host array*/, int n, void* stream);
 
 /* bf16 NT GEMM of the reverse diffusion chain (GaussianDiffusion.generate_view, Model.py:300-322: T x Denoise.forward +
  * posterior mean): A [M,K] and B [N,K] are bf16 row-major with K % 8 == 0; outputs fp32 (C) and/or bf16 (Cb); same epilogue
