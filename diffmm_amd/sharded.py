@@ -199,11 +199,40 @@ class ShardedJointEngine:
     def _spmm(self, batch: List[dict]):
         """batch: SpmmOp keyword dicts (with adj, x_lo).  Local launch -> all-reduce of the raw item partials -> item-row epilogue."""
         k = len(batch)
-        opl = [ops.SpmmOp(raw=self.xraw[i], raw_from=self.nu, **b) for i, b in enumerate(batch)]
-        arr = ops.spmm_batched(opl)
+        arr = self._spmm_local(batch, 0)
         self._ar(self.xraw[:k])
         ops.spmm_epilogue_rows(arr, k, self.D)
         return arr
+
+    def _spmm_local(self, batch: List[dict], slot0: int):
+        """The local launch alone: own user rows finished, raw item partials parked in xraw[slot0 : slot0 + len(batch)]."""
+        return ops.spmm_batched([ops.SpmmOp(raw=self.xraw[slot0 + i], raw_from=self.nu, **b) for i, b in enumerate(batch)])
+
+    # The exchange of one launch's partials can run on a side stream UNDER the next launch (RCCL uses its own stream anyway; the side
+    # stream only orders it behind the producing launch without blocking the main stream): the gradient all-reduces of the backward --
+    # the item rows of the modal SpMMs that feed the projection gradients, then the item rows of the base SpMM = d(i_embs) -- overlap
+    # with the remaining backward SpMM and with the projection backward.
+    def _exchange_begin(self, slot0: int, k: int):
+        if self.world > 1:
+            L.call_py(self._exchange_begin_now, slot0, k)
+
+    def _exchange_end(self):
+        if self.world > 1:
+            L.call_py(self._exchange_end_now)
+
+    def _exchange_begin_now(self, slot0: int, k: int):
+        import torch.distributed as dist
+        if not hasattr(self, "_comm_stream"):
+            self._comm_stream, self._comm_event = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
+        self._comm_event.record(torch.cuda.current_stream())
+        self._comm_stream.wait_event(self._comm_event)
+        with torch.cuda.stream(self._comm_stream):
+            self._work = dist.all_reduce(self.xraw[slot0:slot0 + k], group=self.group, async_op=True)
+
+    def _exchange_end_now(self):
+        self._work.wait()
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._work = None
 
     def _rng(self, k: int, noise) -> dict:
         lanes = self.D // 4
@@ -226,14 +255,19 @@ class ShardedJointEngine:
         nd = hp["noise_degree"]
         self._project(precision)
         refs = self._philox_refs
-        batch = [dict(adj=self.modal_adj[m], x_lo=self.u_embs, y=self.Z[m], x_hi=self.nf[m], split=self.nu) for m in range(self.M)]
-        if with_cl:
-            batch.append(dict(adj=A, x_lo=emb, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **self._rng(0, noise)))
-        else:
-            batch.append(dict(adj=A, x_lo=emb, y=self.Bx))
-        arr = self._spmm(batch)
+        M = self.M
+        modal = [dict(adj=self.modal_adj[m], x_lo=self.u_embs, y=self.Z[m], x_hi=self.nf[m], split=self.nu) for m in range(M)]
+        base = dict(adj=A, x_lo=emb, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **self._rng(0, noise)) if with_cl else dict(adj=A, x_lo=emb, y=self.Bx)
+        # the modal graphs' partials are exchanged under the base graph's launch
+        arr_m = self._spmm_local(modal, 0)
+        self._exchange_begin(0, M)
+        arr = self._spmm_local([base], M)
+        self._exchange_end()
+        ops.spmm_epilogue_rows(arr_m, M, self.D)
+        self._ar(self.xraw[M:M + 1])
+        ops.spmm_epilogue_rows(arr, 1, self.D)
         if refs is not None and with_cl:
-            refs.append((arr, len(batch) - 1, 0))
+            refs.append((arr, 0, 0))
         ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx)
         s = 1.0 + hp["residual_weight"]
         batch = [dict(adj=A, x_lo=self.Mx, y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
@@ -342,7 +376,15 @@ class ShardedJointEngine:
         i0, i1 = self.layout.item_slice()
         ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
                         dw=self.P.g("modal_weight"), partials=self.mix_partials, count=(nu * D, (nu + i0) * D, (nu + i1) * D))
-        self._spmm([dict(adj=A, x_lo=self.dBx, y=self.P.g("emb"))] + [dict(adj=self.modal_adj[m], x_lo=self.dZ[m], y=self.T[m]) for m in range(M)])
+        # last backward SpMMs.  Gradient exchange overlapped with the remaining backward work: the modal graphs' item partials (they feed
+        # the projection gradients) travel under the base graph's SpMM; the base graph's item partials (= d i_embs) travel under the
+        # projection backward.
+        arr_m = self._spmm_local([dict(adj=self.modal_adj[m], x_lo=self.dZ[m], y=self.T[m]) for m in range(M)], 0)
+        self._exchange_begin(0, M)
+        arr_b = self._spmm_local([dict(adj=A, x_lo=self.dBx, y=self.P.g("emb"))], M)
+        self._exchange_end()
+        ops.spmm_epilogue_rows(arr_m, M, D)
+        self._exchange_begin(M, 1)
         ne = self.n * D
         names = modality_names(M)
         mw = self.P.offsets["modal_weight"]
@@ -354,6 +396,8 @@ class ShardedJointEngine:
                                    split_k=128) for m, nm in enumerate(names)])
             for m, nm in enumerate(names):
                 ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, self.P.g(f"{nm}_layer.bias"))
+        self._exchange_end()
+        ops.spmm_epilogue_rows(arr_b, 1, D)
         self._ar(self.P.grad[ne:])  # projections + modal_weight: partial sums over disjoint node sets
         if update:
             self.apply_adam()
