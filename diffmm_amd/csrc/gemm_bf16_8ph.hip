@@ -135,34 +135,40 @@ __device__ __forceinline__ void p8_st_edge(T* p, const float (&v)[4], int nv) {
 
 // Residual kinds: RK = 0 none, 1 fp32 rows (R), 2 bf16 rows (Rb: the reverse chain with its running x_t kept in bf16 only).  pR is a byte
 // pointer to the lane's four columns of the pass's first row, rs the row stride in bytes.
-template <int RK>
-__device__ __forceinline__ float4 p8_ld_res(const char* p) {
-  if (RK == 1) return p8_ld_stream(reinterpret_cast<const float*>(p));
-  const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+// A residual piece (the lane's four columns of one row) as it waits in registers: fp32 rows as a float4, bf16 rows as the raw 8 bytes
+// (two passes of 8 pieces each are in flight per wave: 48 instead of 96 registers next to the 128 accumulators).
+template <int RK> struct P8Res { typedef float4 type; };
+template <> struct P8Res<2> { typedef u32x2 type; };
+__device__ __forceinline__ float4 p8_res_f4(const float4& r) { return r; }
+__device__ __forceinline__ float4 p8_res_f4(const u32x2& w) {
   return make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u));
 }
-template <int RK>
-__device__ __forceinline__ float4 p8_ld_res_edge(const char* p, int nv) {
-  if (RK == 1) return p8_ld_edge(reinterpret_cast<const float*>(p), nv);
-  const __bf16* b = reinterpret_cast<const __bf16*>(p);
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nv > 0) r.x = (float)b[0];
-  if (nv > 1) r.y = (float)b[1];
-  if (nv > 2) r.z = (float)b[2];
-  return r;
+__device__ __forceinline__ void p8_res_zero(float4& r) { r = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void p8_res_zero(u32x2& r) { r = u32x2{0u, 0u}; }
+__device__ __forceinline__ void p8_ld_res(const char* p, float4& r) { r = p8_ld_stream(reinterpret_cast<const float*>(p)); }
+__device__ __forceinline__ void p8_ld_res(const char* p, u32x2& r) { r = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)); }
+__device__ __forceinline__ void p8_ld_res_edge(const char* p, int nv, float4& r) { r = p8_ld_edge(reinterpret_cast<const float*>(p), nv); }
+__device__ __forceinline__ void p8_ld_res_edge(const char* p, int nv, u32x2& r) {
+  const unsigned short* b = reinterpret_cast<const unsigned short*>(p);
+  unsigned w0 = 0u, w1 = 0u;
+  if (nv > 0) w0 = b[0];
+  if (nv > 1) w0 |= (unsigned)b[1] << 16;
+  if (nv > 2) w1 = b[2];
+  r = u32x2{w0, w1};
 }
 
 template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
 __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const char*& pR, long long rs,
-                                             float*& pC, __bf16*& pCb, const float4 (&rcur)[8], float4 (&rnext)[8], int mrow, int nv) {
+                                             float*& pC, __bf16*& pCb, const typename P8Res<RK>::type (&rcur)[8], typename P8Res<RK>::type (&rnext)[8],
+                                             int mrow, int nv) {
   constexpr bool HAS_R = RK != 0;
   if (HAS_R && PASS < 2) {  // two passes ahead: 16 KiB of residual rows in flight per wave while a pass is being stored
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const char* p = pR + (long long)(64 + it * 4) * rs;
-      if (!EDGE) rnext[it] = p8_ld_res<RK>(p);
-      else if (mrow + PASS * 32 + 64 + it * 4 < E.M) rnext[it] = nv == 4 ? p8_ld_res<RK>(p) : p8_ld_res_edge<RK>(p, nv);
-      else rnext[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!EDGE) p8_ld_res(p, rnext[it]);
+      else if (mrow + PASS * 32 + 64 + it * 4 < E.M) { if (nv == 4) p8_ld_res(p, rnext[it]); else p8_ld_res_edge(p, nv, rnext[it]); }
+      else p8_res_zero(rnext[it]);
     }
   }
   p8_acc_to_lds<(PASS >> 1), (PASS & 1)>(acc, tile, q, fr);
@@ -176,7 +182,7 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
       else if (ACT == DMM_ACT_SIGMOID) v[u] = 1.0f / (1.0f + expf(-v[u]));
     }
     if (HAS_R) {
-      const float4 r4 = rcur[it];
+      const float4 r4 = p8_res_f4(rcur[it]);
       v[0] = E.e1 * v[0] + E.e2 * r4.x; v[1] = E.e1 * v[1] + E.e2 * r4.y; v[2] = E.e1 * v[2] + E.e2 * r4.z; v[3] = E.e1 * v[3] + E.e2 * r4.w;
     }
     if (!EDGE) {
@@ -214,18 +220,18 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
   const char* pR = RK == 1 ? reinterpret_cast<const char*>(E.R + m * E.ldr + n) : RK == 2 ? reinterpret_cast<const char*>(E.Rb + m * E.ldrb + n) : nullptr;
   float* pC = HAS_C ? E.C + m * E.ldc + n : nullptr;
   __bf16* pCb = HAS_CB ? E.Cb + m * E.ldcb + n : nullptr;
-  float4 ra[8], rb[8], rc[8];
+  typename P8Res<RK>::type ra[8], rb[8], rc[8];
   if (HAS_R) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const char* p0 = pR + (long long)(it * 4) * rs;
       const char* p1 = pR + (long long)(32 + it * 4) * rs;
       if (!EDGE) {
-        ra[it] = p8_ld_res<RK>(p0);
-        rb[it] = p8_ld_res<RK>(p1);
+        p8_ld_res(p0, ra[it]);
+        p8_ld_res(p1, rb[it]);
       } else {
-        ra[it] = mrow + it * 4 < E.M ? (nv == 4 ? p8_ld_res<RK>(p0) : p8_ld_res_edge<RK>(p0, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rb[it] = mrow + 32 + it * 4 < E.M ? (nv == 4 ? p8_ld_res<RK>(p1) : p8_ld_res_edge<RK>(p1, nv)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mrow + it * 4 < E.M) { if (nv == 4) p8_ld_res(p0, ra[it]); else p8_ld_res_edge(p0, nv, ra[it]); } else p8_res_zero(ra[it]);
+        if (mrow + 32 + it * 4 < E.M) { if (nv == 4) p8_ld_res(p1, rb[it]); else p8_ld_res_edge(p1, nv, rb[it]); } else p8_res_zero(rb[it]);
       }
     }
   }
@@ -270,6 +276,24 @@ __device__ __forceinline__ void p8_generic_pass(const P8Epi& E, const P8Acc& acc
   __builtin_amdgcn_wave_barrier();
 }
 
+// Epilogue kinds.  Each gets its own kernel instantiation -- its own symbol in a rocprof trace (the chain's layer 1 and layer 2 no longer
+// share one row of the kernel stats) and only its own epilogue code and registers.  EPI_GENERIC dispatches at run time.
+enum { EPI_GENERIC = 0, EPI_TANH_CB = 1 /* chain layer 1 */, EPI_R32_C_CB = 2 /* chain layer 2, fp32 state */, EPI_R16_CB = 3 /* chain layer 2, bf16 state */,
+       EPI_R16_C = 4 /* last chain step */, EPI_TANH_C_CB = 5 /* training: h in fp32 and bf16 */, EPI_C = 6, EPI_CB = 7, EPI_COUNT = 8 };
+
+static int p8_pick_epi(const GemmBf16P& P) {
+  const bool noR = !P.R && !P.Rb;
+  if (noR && !P.C && P.Cb && P.act == DMM_ACT_TANH) return EPI_TANH_CB;
+  if (P.R && !P.Rb && P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_R32_C_CB;
+  if (P.Rb && !P.R && !P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_R16_CB;
+  if (P.Rb && !P.R && P.C && !P.Cb && P.act == DMM_ACT_NONE) return EPI_R16_C;
+  if (noR && P.C && P.Cb && P.act == DMM_ACT_TANH) return EPI_TANH_C_CB;
+  if (noR && P.C && !P.Cb && P.act == DMM_ACT_NONE) return EPI_C;
+  if (noR && !P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_CB;
+  return EPI_GENERIC;
+}
+
+template <int EPI>
 __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
   P8Epi E;
   E.C = P.C; E.Cb = P.Cb; E.R = P.R; E.Rb = P.Rb; E.bias = P.bias;
@@ -284,23 +308,22 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
     if (interior) p8_epilogue_fast<R_, C_, CB_, ACT_, false>(E, acc, smem, m0, n0, wave, lane);      \
     else p8_epilogue_fast<R_, C_, CB_, ACT_, true>(E, acc, smem, m0, n0, wave, lane);                \
   } while (0)
-  const bool noR = !E.R && !E.Rb;
-  if (fast && noR && !E.C && E.Cb && E.act == DMM_ACT_TANH) {
+  if (fast && EPI == EPI_TANH_CB) {
     P8_FAST(0, false, true, DMM_ACT_TANH);
-  } else if (fast && noR && !E.C && E.Cb && E.act == DMM_ACT_NONE) {
+  } else if (fast && EPI == EPI_CB) {
     P8_FAST(0, false, true, DMM_ACT_NONE);
-  } else if (fast && E.R && E.C && E.Cb && E.act == DMM_ACT_NONE) {
+  } else if (fast && EPI == EPI_R32_C_CB) {
     P8_FAST(1, true, true, DMM_ACT_NONE);
-  } else if (fast && E.Rb && !E.C && E.Cb && E.act == DMM_ACT_NONE) {  // reverse chain, bf16 running state: x_t in, x_{t-1} out, both bf16
+  } else if (fast && EPI == EPI_R16_CB) {  // reverse chain, bf16 running state: x_t in, x_{t-1} out, both bf16
     P8_FAST(2, false, true, DMM_ACT_NONE);
-  } else if (fast && E.Rb && E.C && !E.Cb && E.act == DMM_ACT_NONE) {  // its last step: the fp32 view the top-k reads
+  } else if (fast && EPI == EPI_R16_C) {  // its last step: the fp32 view the top-k reads
     P8_FAST(2, true, false, DMM_ACT_NONE);
-  } else if (fast && noR && E.C && !E.Cb && E.act == DMM_ACT_NONE) {
+  } else if (fast && EPI == EPI_C) {
     P8_FAST(0, true, false, DMM_ACT_NONE);
-  } else if (fast && noR && E.C && E.Cb && E.act == DMM_ACT_TANH) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
+  } else if (fast && EPI == EPI_TANH_C_CB) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
     P8_FAST(0, true, true, DMM_ACT_TANH);
 #undef P8_FAST
-  } else {
+  } else {  // unaligned operands and the rarely used operand combinations
     float* tile = reinterpret_cast<float*>(smem) + wave * 32 * P8_LDT;
     p8_generic_pass<0, 0>(E, acc, tile, m0, n0, wave, lane, vec_ok);
     p8_generic_pass<0, 1>(E, acc, tile, m0, n0, wave, lane, vec_ok);
@@ -316,6 +339,7 @@ __device__ unsigned long long p8_stamps[8 * 8192];
 #define P8_STAMP(i)
 #endif
 
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Batch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GemmBf16P& P = batch.p[blockIdx.y];
@@ -438,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
   if (wr == 0) P8_BARRIER();  // row 0 waits for row 1's last phase
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every LDS-DMA landed, every read done: LDS is free
   if (threadIdx.x < 64) { P8_STAMP(2); }
-  p8_epilogue(P, acc, smem, m0, n0, wave, lane);
+  p8_epilogue<EPI>(P, acc, smem, m0, n0, wave, lane);
   if (threadIdx.x < 64) { P8_STAMP(3); }
 #ifdef P8_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,13 +470,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
 #endif
 }
 
-void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
+template <int EPI>
+static void p8_launch(const GemmBf16Batch& b, hipStream_t s) {
   static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_8ph_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(gemm_bf16_nt_8ph_kernel, dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(512), P8_LDS, s, b);
+  hipLaunchKernelGGL(gemm_bf16_nt_8ph_kernel<EPI>, dim3(b.p[0].mt * b.p[0].nt, b.n), dim3(512), P8_LDS, s, b);
+}
+
+void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
+  int epi = p8_pick_epi(b.p[0]);
+  for (int i = 1; i < b.n; ++i)
+    if (p8_pick_epi(b.p[i]) != epi) epi = EPI_GENERIC;  // mixed batches take the run-time dispatch
+  switch (epi) {
+    case EPI_TANH_CB: p8_launch<EPI_TANH_CB>(b, s); break;
+    case EPI_R32_C_CB: p8_launch<EPI_R32_C_CB>(b, s); break;
+    case EPI_R16_CB: p8_launch<EPI_R16_CB>(b, s); break;
+    case EPI_R16_C: p8_launch<EPI_R16_C>(b, s); break;
+    case EPI_TANH_C_CB: p8_launch<EPI_TANH_C_CB>(b, s); break;
+    case EPI_C: p8_launch<EPI_C>(b, s); break;
+    case EPI_CB: p8_launch<EPI_CB>(b, s); break;
+    default: p8_launch<EPI_GENERIC>(b, s); break;
+  }
 }
 
 }  // namespace dmm
