@@ -101,7 +101,18 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const long long* __
   const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
   for (int h0 = threadIdx.x * 4; h0 < H; h0 += 1024) {  // 4 columns (8 bytes of bf16) per thread per pass
     float a[4] = {bias[h0], bias[h0 + 1], bias[h0 + 2], bias[h0 + 3]};
-    for (long long e = beg; e < end; ++e) {
+    long long e = beg;
+    for (; e + 8 <= end; e += 8) {  // 8 independent row gathers in flight (a heavy user has hundreds of items: the loop is latency-bound)
+      uint2 w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const uint2*>(Wt + (long long)col[e + j] * ldw + h0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[0] += __uint_as_float(w[j].x << 16); a[1] += __uint_as_float(w[j].x & 0xffff0000u);
+        a[2] += __uint_as_float(w[j].y << 16); a[3] += __uint_as_float(w[j].y & 0xffff0000u);
+      }
+    }
+    for (; e < end; ++e) {
       const uint2 w = *reinterpret_cast<const uint2*>(Wt + (long long)col[e] * ldw + h0);
       a[0] += __uint_as_float(w.x << 16); a[1] += __uint_as_float(w.x & 0xffff0000u);
       a[2] += __uint_as_float(w.y << 16); a[3] += __uint_as_float(w.y & 0xffff0000u);

@@ -279,7 +279,7 @@ __device__ __forceinline__ void p8_generic_pass(const P8Epi& E, const P8Acc& acc
 // Epilogue kinds.  Each gets its own kernel instantiation -- its own symbol in a rocprof trace (the chain's layer 1 and layer 2 no longer
 // share one row of the kernel stats) and only its own epilogue code and registers.  EPI_GENERIC dispatches at run time.
 enum { EPI_GENERIC = 0, EPI_TANH_CB = 1 /* chain layer 1 */, EPI_R32_C_CB = 2 /* chain layer 2, fp32 state */, EPI_R16_CB = 3 /* chain layer 2, bf16 state */,
-       EPI_R16_C = 4 /* last chain step */, EPI_TANH_C_CB = 5 /* training: h in fp32 and bf16 */, EPI_C = 6, EPI_CB = 7, EPI_COUNT = 8 };
+       EPI_R16_C = 4 /* last chain step */, EPI_TANH_C_CB = 5 /* training: h in fp32 and bf16 */, EPI_C = 6, EPI_CB = 7, EPI_C_CB = 8 /* first step of a CSR-started chain */, EPI_COUNT = 9 };
 
 static int p8_pick_epi(const GemmBf16P& P) {
   const bool noR = !P.R && !P.Rb;
@@ -290,6 +290,7 @@ static int p8_pick_epi(const GemmBf16P& P) {
   if (noR && P.C && P.Cb && P.act == DMM_ACT_TANH) return EPI_TANH_C_CB;
   if (noR && P.C && !P.Cb && P.act == DMM_ACT_NONE) return EPI_C;
   if (noR && !P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_CB;
+  if (noR && P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_C_CB;
   return EPI_GENERIC;
 }
 
@@ -320,6 +321,8 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
     P8_FAST(2, true, false, DMM_ACT_NONE);
   } else if (fast && EPI == EPI_C) {
     P8_FAST(0, true, false, DMM_ACT_NONE);
+  } else if (fast && EPI == EPI_C_CB) {
+    P8_FAST(0, true, true, DMM_ACT_NONE);
   } else if (fast && EPI == EPI_TANH_C_CB) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
     P8_FAST(0, true, true, DMM_ACT_TANH);
 #undef P8_FAST
@@ -492,6 +495,7 @@ void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
     case EPI_TANH_C_CB: p8_launch<EPI_TANH_C_CB>(b, s); break;
     case EPI_C: p8_launch<EPI_C>(b, s); break;
     case EPI_CB: p8_launch<EPI_CB>(b, s); break;
+    case EPI_C_CB: p8_launch<EPI_C_CB>(b, s); break;
     default: p8_launch<EPI_GENERIC>(b, s); break;
   }
 }

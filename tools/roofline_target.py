@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""The two launches bench.py's `roofline` times, alone: 20 x the reverse chain's batched layer-1 GEMM, then 20 x layer 2 (bench shapes:
-3 modalities x 9308 users, I = 6710, Kp = 6720, H = 1024).  Profile with
-    rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/roofline_target.py
-the first 20 dispatches of gemm_bf16_nt_8ph_kernel are layer 1 (the `roofline.achieved` kernel), the last 20 layer 2."""
+"""The launches bench.py's `roofline` times, alone and as the reverse chain issues them (bench shapes: 3 modalities x 9308 users,
+I = 6710, Kp = 6720, H = 1024): N x the batched layer-1 GEMM (tanh -> bf16), N x layer 2 with the running x_t in bf16 (the default
+chain state), N x layer 2 with the fp32 state of round 1.  Each epilogue kind is its own kernel instantiation, so a profile separates them:
+    rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/roofline_target.py [N]
+    gemm_bf16_nt_8ph_kernel<1> = layer 1, <3> = layer 2 (bf16 state), <2> = layer 2 (fp32 state)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffmm_amd import ops, _lib as L
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda:0")
 Mc, I, Kp, H = 9308, 6710, 6720, 1024
 torch.manual_seed(0)
@@ -17,9 +19,10 @@ x32 = [torch.randn(Mc, Kp, device=dev) for _ in range(3)]
 y32 = [torch.zeros(Mc, Kp, device=dev) for _ in range(3)]
 y16 = [torch.zeros(Mc, Kp, dtype=torch.bfloat16, device=dev) for _ in range(3)]
 l1 = lambda: ops.gemm_bf16_nt_batched([dict(A=x16[m], B=w1[m], out_bf16=h16[m], bias=b1, act=L.ACT_TANH) for m in range(3)])
-l2 = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=w2[m], out=y32[m], out_bf16=y16[m], bias=b2, residual=x32[m], e1=0.9, e2=0.1, N=I) for m in range(3)])
-for fn in (l1, l2):
+l2 = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=w2[m], out_bf16=y16[m], bias=b2, residual_bf16=x16[m], e1=0.9, e2=0.1, N=I) for m in range(3)])
+l2_fp32 = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=w2[m], out=y32[m], out_bf16=y16[m], bias=b2, residual=x32[m], e1=0.9, e2=0.1, N=I) for m in range(3)])
+for fn in (l1, l2, l2_fp32):
     fn(); torch.cuda.synchronize()
-    for _ in range(20):
+    for _ in range(N):
         fn()
     torch.cuda.synchronize()
