@@ -104,13 +104,14 @@ def roofline(coach, args):
         if args.precision == 1 and args.batch == 4096 and args.workload == "tiktok" and nb == 3:
             pmc = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")))
             spmm["traffic"] = pmc["spmm_kernel_64"]["traffic_bytes"]
-            chain = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_chain_gemm.json")))
-            l1, l2 = chain["gemm_bf16_nt_8ph_layer1"], chain["gemm_bf16_nt_8ph_layer2"]
+            chain = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_chain_gemm.json")))
+            l1, l2 = chain["layer1_tanh_bf16"], chain["layer2_bf16_state" if DE._bf16_state() else "layer2_fp32_state"]
             gemm["traffic"] = l1["traffic_bytes"]
-            gemm["traffic_source"] = spmm["traffic_source"] = "committed rocprofv3 --pmc passes of this workload (profiles/README.md); bench.py cannot run a PMC pass on itself"
+            gemm["traffic_source"] = "profiles/r2_pmc_chain_gemm.json (committed rocprofv3 --pmc passes of tools/roofline_target.py; bench.py cannot run a PMC pass on itself)"
+            spmm["traffic_source"] = "profiles/r1_pmc_traffic.json (committed rocprofv3 --pmc passes of this launch)"
             gemm["traffic_note"] = (f"layer 1: {l1['traffic_bytes'] / 1e6:.0f} MB fabric-side per launch vs {l1['algorithmic_bytes'] / 1e6:.0f} MB of operands + output "
-                                    f"(L2 hit rate {l1['tcc_hit'] / (l1['tcc_hit'] + l1['tcc_miss']):.0%}); layer 2: {l2['traffic_bytes'] / 1e6:.0f} MB vs "
-                                    f"{l2['algorithmic_bytes'] / 1e6:.0f} MB; profiles/r1_pmc_chain_gemm.json")
+                                    f"(L2 hit rate {l1['l2_hit_rate']:.0%}, MFMA pipe busy {l1['mfma_busy']:.0%}); layer 2 ({gemm['layer2_state']} state): "
+                                    f"{l2['traffic_bytes'] / 1e6:.0f} MB vs {l2['algorithmic_bytes'] / 1e6:.0f} MB (L2 hit rate {l2['l2_hit_rate']:.0%}, MFMA pipe busy {l2['mfma_busy']:.0%})")
     except Exception:
         pass
     return gemm, spmm

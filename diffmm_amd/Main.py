@@ -71,7 +71,7 @@ class Coach:
         own_users = lay.nu if lay is not None else int(cfg.data.user_num)
         self.diff_engine = DiffusionEngine(int(cfg.data.item_num), int(cfg.base.latdim), int(in_dims[1]), int(cfg.base.d_emb_size), M,
                                            int(cfg.hyper.steps), hyper_dict(cfg), self.device, int(cfg.train.batch),
-                                           chain_rows=min(max(own_users, 1), 16384))
+                                           chain_rows=min(max(own_users, 1), 16384), hidden=[int(x) for x in out_dims[:-1]])
         dens = [Denoise(in_dims, out_dims, cfg, _engine=self.diff_engine, _slot=m, precision=self.precision) for m in range(M)]
         self.image_denoise_model, self.text_denoise_model = dens[0], dens[1]
         if M == 3:

@@ -126,18 +126,25 @@ class Denoise:
         self.in_dims, self.out_dims = in_dims, out_dims
         self.time_emb_dim = int(config.base.d_emb_size)
         self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
-        if len(in_dims) != 2 or len(out_dims) != 2:
-            raise ValueError("the HIP Denoise supports the reference's shipped shape: one hidden layer (denoise_dim = '[H]')")
+        if len(in_dims) < 2 or list(in_dims) != list(out_dims)[::-1]:
+            raise ValueError("Denoise: in_dims must be out_dims reversed, [items, H_k, ..., H_1] (Main.py:96-98)")
         I, H, D = int(in_dims[0]), int(in_dims[1]), int(config.base.latdim)
+        hidden = [int(x) for x in out_dims[:-1]]  # base.denoise_dim: [H_1, ..., H_k], H = H_k
         self.precision = precision
         if _engine is None:
-            _engine = DiffusionEngine(I, D, H, self.time_emb_dim, 1, int(config.hyper.steps), hyper_dict(config), self.device, int(config.train.batch))
+            _engine = DiffusionEngine(I, D, H, self.time_emb_dim, 1, int(config.hyper.steps), hyper_dict(config), self.device, int(config.train.batch),
+                                      hidden=hidden)
         self.engine, self.slot = _engine, _slot
         te = self.time_emb_dim
         xn = torch.nn.init.xavier_normal_
-        sd = {"emb_layer.weight": xn(torch.empty(te, te)), "emb_layer.bias": torch.empty(te).normal_(0.0, 0.001),
-              "in_layers.0.weight": xn(torch.empty(H, I + te)), "in_layers.0.bias": torch.empty(H).normal_(0.0, 0.001),
-              "out_layers.0.weight": xn(torch.empty(I, H)), "out_layers.0.bias": torch.empty(I).normal_(0.0, 0.001)}
+        lin = lambda o, i: (xn(torch.empty(o, i)), torch.empty(o).normal_(0.0, 0.001))  # init_weights(): xavier_normal / N(0, 1e-3)
+        sd = {}
+        in_t = [I + te] + [int(x) for x in in_dims[1:]]
+        for j, (di, do) in enumerate(zip(in_t[:-1], in_t[1:])):     # Model.py:156-158
+            sd[f"in_layers.{j}.weight"], sd[f"in_layers.{j}.bias"] = lin(do, di)
+        for j, (di, do) in enumerate(zip(out_dims[:-1], out_dims[1:])):  # Model.py:159-160
+            sd[f"out_layers.{j}.weight"], sd[f"out_layers.{j}.bias"] = lin(int(do), int(di))
+        sd["emb_layer.weight"], sd["emb_layer.bias"] = lin(te, te)
         sd["gate_layer.weight"], sd["gate_layer.bias"] = _linear_default_init(D, D)  # created after init_weights(): default init
         self.engine.load_reference_state(self.slot, sd)
 

@@ -359,9 +359,21 @@ def schedule_tables(T: int, noise_scale: float, noise_min: float, noise_max: flo
 class DiffusionEngine:
     """Denoise MLPs of all modalities + GaussianDiffusion arithmetic."""
 
-    def __init__(self, items: int, D: int, H: int, te: int, M: int, T: int, hp: dict, device, B_max: int, chain_rows: Optional[int] = None):
+    def __init__(self, items: int, D: int, H: int, te: int, M: int, T: int, hp: dict, device, B_max: int, chain_rows: Optional[int] = None,
+                 hidden: Optional[Sequence[int]] = None):
         """chain_rows: rows the reverse chain processes per launch sequence (>= B_max).  The chain's rows are independent, so the
-        rebuild is free to use far larger GEMMs than the training batch: more 128x128 tiles per launch, no ragged tail batch."""
+        rebuild is free to use far larger GEMMs than the training batch: more 128x128 tiles per launch, no ragged tail batch.
+        hidden: the reference's `base.denoise_dim` list [H_1, ..., H_k] (Model.py:156-160): in_layers (I+te -> H_k), (H_k -> H_k-1), ...,
+        (H_2 -> H_1), out_layers (H_1 -> H_2), ..., (H_k -> I); H = H_k is the width next to the item dimension.  The 2 (k - 1) layers
+        between the two item-sized ones ("mids", all tanh) are small dense GEMMs; k = 1 (every shipped config) has none."""
+        hidden = [int(H)] if hidden is None else [int(x) for x in hidden]
+        if hidden[-1] != H:
+            raise ValueError("DiffusionEngine: H must be the last entry of `hidden`")
+        k = len(hidden)
+        self.hidden = hidden
+        self.L2 = f"out_layers.{k - 1}"  # the layer that maps H -> I
+        w_in = hidden[::-1]  # output widths of in_layers.0 .. k-1
+        self.mids = [(f"in_layers.{j}", w_in[j - 1], w_in[j]) for j in range(1, k)] + [(f"out_layers.{j}", hidden[j], hidden[j + 1]) for j in range(k - 1)]
         self.I, self.D, self.H, self.te, self.M, self.T = items, D, H, te, M, T
         self.chain_rows = max(int(chain_rows or B_max), B_max)
         self.hp = dict(hp)
@@ -369,7 +381,9 @@ class DiffusionEngine:
         self.Kp = (items + te + 63) & ~63  # leading dimension of [x_t | temb | 0-pad]; also of out / dout.  Whole 64-wide K tiles: the
         # 256 x 256 LDS-DMA GEMM tile (csrc/gemm_bf16_8ph.hip) takes no K remainder
         shapes = [("emb_layer.weight", (te, te)), ("emb_layer.bias", (te,)), ("in_layers.0.weight", (H, self.Kp)), ("in_layers.0.bias", (H,)),
-                  ("out_layers.0.weight", (items, H)), ("out_layers.0.bias", (items,)), ("gate_layer.weight", (D, D)), ("gate_layer.bias", (D,))]
+                  (self.L2 + ".weight", (items, H)), (self.L2 + ".bias", (items,)), ("gate_layer.weight", (D, D)), ("gate_layer.bias", (D,))]
+        for nm, din, dout in self.mids:
+            shapes += [(nm + ".weight", (dout, din)), (nm + ".bias", (dout,))]
         self.P = [FlatParams(shapes, self.dev) for _ in range(M)]
         self.sched = schedule_tables(T, hp["noise_scale"], hp["noise_min"], hp["noise_max"])
         f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(self.dev)
@@ -386,6 +400,11 @@ class DiffusionEngine:
         self.act = [dict(xcat=z(B_max, Kp), proj=z(B_max, D), gate=z(B_max, D), pg=z(B_max, D), h=z(B_max, H), out=z(B_max, Kp), um=z(B_max, D),
                          t=torch.zeros(B_max, dtype=torch.int32, device=self.dev), loss=torch.zeros(B_max, dtype=torch.float64, device=self.dev))
                     for _ in range(M)]
+        R_mid = max(B_max, self.chain_rows)
+        for a_ in self.act:  # activations of the mid layers (fp32, kept for the backward) and their gradients
+            a_["mid"] = [z(R_mid, dout) for _, _, dout in self.mids]
+        self.dmid_pre = [z(B_max, dout) for _, _, dout in self.mids]
+        self.dmid_in = [z(B_max, din) for _, din, _ in self.mids]
         self.x0p = z(B_max, Kp)  # x0 with the padded leading dimension
         self.ui = z(B_max, D)
         self.dout, self.dxcat = z(B_max, Kp), z(B_max, Kp)
@@ -398,6 +417,10 @@ class DiffusionEngine:
         self.cxa16, self.cxb16, self.ch16 = [zb(R, Kp) for _ in range(M)], [zb(R, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
         self.xa, self.xb, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxb[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
         self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
+        if any(w % 8 for w in hidden):
+            raise ValueError("DiffusionEngine: hidden widths must be multiples of 8 (bf16 operand rows are 16-byte pieces)")
+        self.wmid16 = [[zb(dout, din) for _, din, dout in self.mids] for _ in range(M)]
+        self.cmid16 = [[zb(R, dout) for _, _, dout in self.mids] for _ in range(M)]  # the chain's mid activations
         self.w16_step = [-1] * M  # Adam step the bf16 weight copies were taken at
         self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
         self.I8 = (items + 7) & ~7
@@ -437,26 +460,64 @@ class DiffusionEngine:
             x0p[:, : self.I].copy_(x0)
         return x0p
 
+    # -- the 2 (k - 1) small tanh layers between the item-sized ones (none for the shipped single-hidden-layer shape) -----------------
+    def _mids_fwd(self, m: int, h: Tensor, precision: int) -> Tensor:
+        """h [B, H] (fp32, layer 1's tanh output) through in_layers.1.. and out_layers..k-2; returns the input of the last layer."""
+        P, a, B = self.P[m], self.act[m], h.shape[0]
+        for j, (nm, din, dout) in enumerate(self.mids):
+            o = a["mid"][j][:B]
+            ops.gemm(h, P.view(nm + ".weight"), out=o, trans_b=True, bias=P.view(nm + ".bias"), act=L.ACT_TANH, precision=precision)
+            h = o
+        return h
+
+    def _mids_bwd(self, m: int, h: Tensor, d_last: Tensor, precision: int) -> Tensor:
+        """Backward of _mids_fwd: d_last = d loss / d (its return value); fills the mid layers' gradients, returns d loss / d h."""
+        P, a, B = self.P[m], self.act[m], h.shape[0]
+        d = d_last
+        for j in range(len(self.mids) - 1, -1, -1):
+            nm, din, dout = self.mids[j]
+            inp = a["mid"][j - 1][:B] if j > 0 else h
+            dpre, dn = self.dmid_pre[j][:B], self.dmid_in[j][:B]
+            ops.tanh_bwd(d, a["mid"][j][:B], dpre)
+            ops.gemm(dpre, inp, out=P.g(nm + ".weight"), trans_a=True, precision=precision)  # dW = dpre^T input
+            ops.colsum(dpre, B, dout, P.g(nm + ".bias"))
+            ops.gemm(dpre, P.view(nm + ".weight"), out=dn, precision=precision)                # d input = dpre W
+            d = dn
+        return d
+
+    def _mids_chain(self, m: int, h16: Tensor) -> Tensor:
+        """The same layers on the reverse chain's bf16 activations (bf16 copies of the weights, taken by _refresh_bf16_weights)."""
+        B = h16.shape[0]
+        for j, (nm, din, dout) in enumerate(self.mids):
+            o = self.cmid16[m][j][:B]
+            ops.gemm_bf16_nt(h16, self.wmid16[m][j], out_bf16=o, bias=self.P[m].view(nm + ".bias"), act=L.ACT_TANH)
+            h16 = o
+        return h16
+
     # -- Denoise.forward on an operand buffer that already holds [x_t | temb | 0] ---------------------
     def _mlp_train_bf16(self, m: int, xcat: Tensor, h: Tensor, out: Tensor):
         """Training-time Denoise MLP on the bf16 NT kernel: operands are cast once, h is also kept in bf16 for the backward."""
         P, B = self.P[m], xcat.shape[0]
         ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
-        ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+        ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
         self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
         ops.cast_bf16(xcat, self.xa16[:B])
         ops.gemm_bf16_nt(self.xa16[:B], self.w1_16[m], out=h, out_bf16=self.h16[:B], bias=P.view("in_layers.0.bias"), act=L.ACT_TANH)
-        ops.gemm_bf16_nt(self.h16[:B], self.w2_16[m], out=out, bias=P.view("out_layers.0.bias"), N=self.I)
+        if self.mids:
+            ops.cast_bf16(self._mids_fwd(m, h, 1), self.h16[:B])
+        ops.gemm_bf16_nt(self.h16[:B], self.w2_16[m], out=out, bias=P.view(self.L2 + ".bias"), N=self.I)
 
     def _mlp(self, m: int, xcat: Tensor, h: Tensor, out: Tensor, precision: int, post: Optional[Tuple[float, float, Tensor]] = None):
         P = self.P[m]
         B = xcat.shape[0]
         ops.gemm(xcat, P.view("in_layers.0.weight"), out=h, trans_b=True, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH, precision=precision)
+        if self.mids:
+            h = self._mids_fwd(m, h, precision)
         if post is None:
-            ops.gemm(h, P.view("out_layers.0.weight"), out=out, trans_b=True, bias=P.view("out_layers.0.bias"), precision=precision, N=self.I)
+            ops.gemm(h, P.view(self.L2 + ".weight"), out=out, trans_b=True, bias=P.view(self.L2 + ".bias"), precision=precision, N=self.I)
         else:  # posterior mean as epilogue: c1 * pred + c2 * x_t  (Model.py:375)
             e1, e2, R = post
-            ops.gemm(h, P.view("out_layers.0.weight"), out=out, trans_b=True, bias=P.view("out_layers.0.bias"), precision=precision, N=self.I,
+            ops.gemm(h, P.view(self.L2 + ".weight"), out=out, trans_b=True, bias=P.view(self.L2 + ".bias"), precision=precision, N=self.I,
                      residual=R, e1=e1, e2=e2)
 
     def denoise_forward(self, m: int, x_t: Tensor, t: Tensor, feat: Optional[Tensor], precision: int = 3) -> Tensor:
@@ -527,10 +588,12 @@ class DiffusionEngine:
         ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], dout, dum)
         ops.gemm(dum, feat, out=dout, trans_b=True, precision=precision, N=I, accumulate=True)  # d(out F) -> dout += dum F^T
         # (the precision == 1 training step runs staged over the modalities on the bf16 NT kernels: _backward_batched)
-        ops.gemm(dout, a["h"][:B], out=P.g("out_layers.0.weight"), trans_a=True, precision=precision, M=I)  # dW2 = dout^T h
-        ops.colsum(dout, B, I, P.g("out_layers.0.bias"))
-        ops.gemm(dout, P.view("out_layers.0.weight"), out=self.dh[:B], precision=precision, K=I)  # dh = dout W2
-        ops.tanh_bwd(self.dh[:B], a["h"][:B], self.dpre[:B])
+        a_last = a["mid"][-1][:B] if self.mids else a["h"][:B]  # input of the last layer
+        ops.gemm(dout, a_last, out=P.g(self.L2 + ".weight"), trans_a=True, precision=precision, M=I)  # dW2 = dout^T h
+        ops.colsum(dout, B, I, P.g(self.L2 + ".bias"))
+        ops.gemm(dout, P.view(self.L2 + ".weight"), out=self.dh[:B], precision=precision, K=I)  # dh = dout W2
+        dh = self._mids_bwd(m, a["h"][:B], self.dh[:B], precision) if self.mids else self.dh[:B]
+        ops.tanh_bwd(dh, a["h"][:B], self.dpre[:B])
         ops.gemm(self.dpre[:B], a["xcat"][:B], out=P.g("in_layers.0.weight"), trans_a=True, precision=precision)  # dW1 = dpre^T [x|temb]
         ops.colsum(self.dpre[:B], B, H, P.g("in_layers.0.bias"))
         ops.gemm(self.dpre[:B], P.view("in_layers.0.weight"), out=self.dxcat[:B], precision=precision)  # d[x'|temb] = dpre W1
@@ -573,12 +636,15 @@ class DiffusionEngine:
                              offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
             self._gate_fwd(m, a["xcat"][:B], feats[m], 1)
             ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
-            ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+            ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
             self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
             ops.cast_bf16(a["xcat"][:B], W[m]["xa16"][:B])
         ops.gemm_bf16_nt_batched([dict(A=W[m]["xa16"][:B], B=self.w1_16[m], out=self.act[m]["h"][:B], out_bf16=W[m]["h16"][:B],
                                        bias=self.P[m].view("in_layers.0.bias"), act=L.ACT_TANH) for m in range(M)])
-        ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self.w2_16[m], out=self.act[m]["out"][:B], bias=self.P[m].view("out_layers.0.bias"), N=I)
+        if self.mids:
+            for m in range(M):
+                ops.cast_bf16(self._mids_fwd(m, self.act[m]["h"][:B], 1), W[m]["h16"][:B])
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self.w2_16[m], out=self.act[m]["out"][:B], bias=self.P[m].view(self.L2 + ".bias"), N=I)
                                   for m in range(M)])
         for m in range(M):
             a = self.act[m]
@@ -602,16 +668,18 @@ class DiffusionEngine:
             else:
                 ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)
             ops.transpose_cast_bf16(w["dout"][:B], w["doutT16"], rows=B, cols=I, rows_pad=Bp)      # dout^T [I, B]
-            ops.transpose_cast_bf16(a["h"][:B], w["hT16"], rows=B, cols=H, rows_pad=Bp)            # h^T    [H, B]
-            ops.colsum(w["dout"][:B], B, I, P.g("out_layers.0.bias"))
+            a_last = a["mid"][-1][:B] if self.mids else a["h"][:B]                                 # input of the last layer
+            ops.transpose_cast_bf16(a_last, w["hT16"], rows=B, cols=H, rows_pad=Bp)                # h^T    [H, B]
+            ops.colsum(w["dout"][:B], B, I, P.g(self.L2 + ".bias"))
             ops.cast_bf16(w["dout"][:B], w["xb16"][:B])                                             # dout (pad columns are zero)
-            ops.transpose_cast_bf16(P.view("out_layers.0.weight"), w["w2T16"], rows=I, cols=H)     # W2^T   [H, I -> Kp]
-        ops.gemm_bf16_nt_batched([dict(A=W[m]["doutT16"][:, :Bp], B=W[m]["hT16"][:, :Bp], out=self.P[m].g("out_layers.0.weight"), N=H, K=Bp)
+            ops.transpose_cast_bf16(P.view(self.L2 + ".weight"), w["w2T16"], rows=I, cols=H)     # W2^T   [H, I -> Kp]
+        ops.gemm_bf16_nt_batched([dict(A=W[m]["doutT16"][:, :Bp], B=W[m]["hT16"][:, :Bp], out=self.P[m].g(self.L2 + ".weight"), N=H, K=Bp)
                                   for m in range(M)])                                               # dW2 = dout^T h
         ops.gemm_bf16_nt_batched([dict(A=W[m]["xb16"][:B], B=W[m]["w2T16"], out=W[m]["dh"][:B], K=Kp) for m in range(M)])  # dh = dout W2
         for m in range(M):
             a, P, w = self.act[m], self.P[m], W[m]
-            ops.tanh_bwd(w["dh"][:B], a["h"][:B], w["dpre"][:B])
+            dh = self._mids_bwd(m, a["h"][:B], w["dh"][:B], 1) if self.mids else w["dh"][:B]
+            ops.tanh_bwd(dh, a["h"][:B], w["dpre"][:B])
             ops.transpose_cast_bf16(w["dpre"][:B], w["dpreT16"], rows=B, cols=H, rows_pad=Bp)      # dpre^T [H, B]
             ops.transpose_cast_bf16(a["xcat"][:B], w["xcatT16"], rows=B, cols=Kp, rows_pad=Bp)     # xcat^T [Kp, B]
             ops.colsum(w["dpre"][:B], B, H, P.g("in_layers.0.bias"))
@@ -693,13 +761,15 @@ class DiffusionEngine:
         P = self.P[m]
         if self.w16_step[m] != P.step or P.step == 0:
             ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
-            ops.cast_bf16(P.view("out_layers.0.weight"), self.w2_16[m])
+            ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
+            for j, (nm, _, _) in enumerate(self.mids):
+                ops.cast_bf16(P.view(nm + ".weight"), self.wmid16[m][j])
             ops.temb_bias_table(P.view("emb_layer.weight"), P.view("emb_layer.bias"), P.view("in_layers.0.weight"), self.I, P.view("in_layers.0.bias"),
                                 self.bias_t[m])
             if self._w1T_chain is not None:  # CSR chain start: layer 1 of the first step gathers rows of W1^T; its layer 2 has no residual
                 ops.transpose_cast_bf16(P.view("in_layers.0.weight"), self._w1T_chain[m], rows=self.H, cols=self.Kp)
                 ops.zero_(self._b2_first[m])  # operand, so the posterior-mean scale c1 goes into alpha and into this pre-scaled bias
-                ops.add_inplace(self._b2_first[m], P.view("out_layers.0.bias"), float(self.c1[self.T - 1]))
+                ops.add_inplace(self._b2_first[m], P.view(self.L2 + ".bias"), float(self.c1[self.T - 1]))
             self.w16_step[m] = P.step
 
     def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
@@ -714,10 +784,10 @@ class DiffusionEngine:
                 cur, nxt, cur16, nxt16, h16 = self.xa[:B], self.xb[:B], self.xa16[:B], self.xb16[:B], self.h16[:B]
                 ops.zero_(nxt16)  # temb / pad columns of both ping-pong operands stay zero: temb enters through the bias table
                 ops.cast_bf16(cur, cur16, cols=I, cols_pad=self.Kp)
-                b2 = P.view("out_layers.0.bias")
+                b2 = P.view(self.L2 + ".bias")
                 for i in range(self.T - 1, -1, -1):
                     ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
-                    self._chain_layer2(m, i, h16, cur, cur16, nxt, nxt16)
+                    self._chain_layer2(m, i, self._mids_chain(m, h16), cur, cur16, nxt, nxt16)
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
             self._chain_plans[(m, B, self._bf16_state())] = plan
         L.replay(plan)
@@ -750,7 +820,7 @@ class DiffusionEngine:
                 for i in range(self.T - 1, -1, -1):
                     ops.gemm_bf16_nt_batched([dict(A=cur16[m], B=self.w1_16[m], out_bf16=h16[m], bias=self.bias_t[m][i], act=L.ACT_TANH)
                                               for m in range(M)])
-                    ops.gemm_bf16_nt_batched([self._chain_layer2_args(m, i, h16[m], cur[m], cur16[m], nxt[m], nxt16[m]) for m in range(M)])
+                    ops.gemm_bf16_nt_batched([self._chain_layer2_args(m, i, self._mids_chain(m, h16[m]), cur[m], cur16[m], nxt[m], nxt16[m]) for m in range(M)])
                     cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
             self._chain_plans[("all", B, self._bf16_state())] = plan
         L.replay(plan)
@@ -766,7 +836,7 @@ class DiffusionEngine:
 
     def _chain_layer2_args(self, m: int, i: int, h16: Tensor, cur: Tensor, cur16: Tensor, nxt: Tensor, nxt16: Tensor) -> dict:
         """Layer 2 of chain step i with the posterior mean c1[i] * pred + c2[i] * x_t as its epilogue (Model.py:375)."""
-        a = dict(A=h16, B=self.w2_16[m], bias=self.P[m].view("out_layers.0.bias"), e1=float(self.c1[i]), e2=float(self.c2[i]), N=self.I)
+        a = dict(A=h16, B=self.w2_16[m], bias=self.P[m].view(self.L2 + ".bias"), e1=float(self.c1[i]), e2=float(self.c2[i]), N=self.I)
         if not self._bf16_state():
             a.update(out=nxt, out_bf16=nxt16, residual=cur)
         elif i > 0:
@@ -802,7 +872,7 @@ class DiffusionEngine:
                     own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
                     for i in range(self.T - 1, -1, -1):
                         ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
-                        self._chain_layer2(m, i, h16, cur, cur16, nxt, nxt16)
+                        self._chain_layer2(m, i, self._mids_chain(m, h16), cur, cur16, nxt, nxt16)
                         # the first step read the shared x_0 buffers; from then on the chain ping-pongs between its own pair
                         cur, nxt, cur16, nxt16 = nxt, (own if i == self.T - 1 else cur), nxt16, (own16 if i == self.T - 1 else cur16)
                 per.append(pm)
@@ -848,7 +918,7 @@ class DiffusionEngine:
             per = []
             for m in range(M):
                 with torch.cuda.stream(self._side_streams[m]), L.Recorder() as pm:
-                    b2 = self.P[m].view("out_layers.0.bias")
+                    b2 = self.P[m].view(self.L2 + ".bias")
                     cur, nxt, cur16, nxt16, h16 = None, self.cxb[m][:B], None, self.cxb16[m][:B], self.ch16[m][:B]
                     own, own16 = self.cxa[m][:B], self.cxa16[m][:B]
                     for i in range(T - 1, -1, -1):
@@ -856,12 +926,12 @@ class DiffusionEngine:
                             # (this one step also writes the fp32 row: the sparse residual is added to it and rounded to bf16 once, like the
                             # dense chain's fused epilogue)
                             ops.csr_gather_sum_bf16(rows.ptr, rows.col, users, self._w1T_chain[m], self.bias_t[m][i], h16, act=L.ACT_TANH)
-                            ops.gemm_bf16_nt(h16, self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
+                            ops.gemm_bf16_nt(self._mids_chain(m, h16), self.w2_16[m], out=nxt, out_bf16=nxt16, bias=self._b2_first[m], alpha=float(self.c1[i]), N=I)
                             ops.csr_add_rows(rows.ptr, rows.col, users, I, float(self.c2[i]), nxt, nxt16)
                             cur, nxt, cur16, nxt16 = nxt, own, nxt16, own16
                             continue
                         ops.gemm_bf16_nt(cur16, self.w1_16[m], out_bf16=h16, bias=self.bias_t[m][i], act=L.ACT_TANH)
-                        self._chain_layer2(m, i, h16, cur, cur16, nxt, nxt16)
+                        self._chain_layer2(m, i, self._mids_chain(m, h16), cur, cur16, nxt, nxt16)
                         cur, nxt, cur16, nxt16 = nxt, cur, nxt16, cur16
                 per.append(pm)
             # chains have equal length up to the two extra launches of the first step: interleave launch by launch

@@ -129,8 +129,16 @@ def denoise_forward(P: Dict[str, Tensor], x_t: Tensor, t: Tensor, feat: Optional
         proj = x_t @ feat
         gate = torch.sigmoid(F.linear(proj, P["gate_layer.weight"], P["gate_layer.bias"]))
         x_t = x_t + (proj * gate) @ feat.t()
-    h = torch.tanh(F.linear(torch.cat([x_t, temb], dim=-1), P["in_layers.0.weight"], P["in_layers.0.bias"]))
-    return F.linear(h, P["out_layers.0.weight"], P["out_layers.0.bias"])  # no activation on the last layer, :216
+    h = torch.cat([x_t, temb], dim=-1)
+    n_in = sum(1 for k in P if k.startswith("in_layers.") and k.endswith(".weight"))
+    n_out = sum(1 for k in P if k.startswith("out_layers.") and k.endswith(".weight"))
+    for j in range(n_in):  # :210-212 -- tanh after every in-layer
+        h = torch.tanh(F.linear(h, P[f"in_layers.{j}.weight"], P[f"in_layers.{j}.bias"]))
+    for j in range(n_out):  # :213-218 -- tanh on all but the last out-layer
+        h = F.linear(h, P[f"out_layers.{j}.weight"], P[f"out_layers.{j}.bias"])
+        if j != n_out - 1:
+            h = torch.tanh(h)
+    return h
 
 
 # ================================================================================================

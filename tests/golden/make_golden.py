@@ -200,15 +200,18 @@ def gen_losses():
     np.savez_compressed(os.path.join(OUT, "losses.npz"), **save)
 
 
-def gen_diffusion(name, d, H, T, B):
+def gen_diffusion(name, d, H, T, B, dims=None, out_tag=None):
+    """dims (optional): the reference's base.denoise_dim list with more than one hidden width, e.g. [48, 64] -> in_layers (I+te -> 64),
+    (64 -> 48); out_layers (48 -> 64), (64 -> I) (Model.py:156-160); H is then dims[-1] (width next to the item dimension)."""
     g = synth.named(name)
     rng = np.random.default_rng(17)
-    cfg = mkcfg(base__latdim=d, base__denoise_dim=f"[{H}]", hyper__steps=T, hyper__noise_scale=0.5,
+    dims = [H] if dims is None else list(dims)
+    cfg = mkcfg(base__latdim=d, base__denoise_dim=str(dims), hyper__steps=T, hyper__noise_scale=0.5,
                 hyper__sim_weight=0.01, train__reg=1e-4)
     cfg.data.user_num, cfg.data.item_num = g.users, g.items
     torch.manual_seed(9)
     gd = RModel.GaussianDiffusion(cfg)
-    out_dims = [H, g.items]
+    out_dims = dims + [g.items]
     den = RModel.Denoise(out_dims[::-1], out_dims, cfg)
     dense = torch.from_numpy(coo_of(g.trn_rows, g.trn_cols, g.users, g.items).toarray())
     rows = torch.from_numpy(rng.choice(g.users, size=B, replace=False))
@@ -218,7 +221,7 @@ def gen_diffusion(name, d, H, T, B):
     noise = torch.from_numpy(rng.standard_normal((B, g.items)).astype(np.float32))
     feat = torch.from_numpy((rng.standard_normal((g.items, d)) * 0.3).astype(np.float32))
     i_embs = torch.from_numpy((rng.standard_normal((g.items, d)) * 0.1).astype(np.float32)).requires_grad_()
-    save = dict(users=g.users, items=g.items, d=d, H=H, T=T, B=B, x0=x0.numpy(), rows=rows.numpy(), t=t.numpy(),
+    save = dict(users=g.users, items=g.items, d=d, H=H, T=T, B=B, dims=np.asarray(dims), x0=x0.numpy(), rows=rows.numpy(), t=t.numpy(),
                 noise=noise.numpy(), feat=feat.numpy(), i_embs=i_embs.detach().numpy(), noise_scale=0.5,
                 sim_weight=0.01, reg=1e-4)
     save.update(sd_np("p/", den))
@@ -257,7 +260,7 @@ def gen_diffusion(name, d, H, T, B):
     save["tl/g_i_embs"] = i_embs.grad.numpy().copy()
     for k, p in den.named_parameters():
         save[f"tl/grad/{k}"] = p.grad.numpy().copy()
-    np.savez_compressed(os.path.join(OUT, f"diffusion_{name}.npz"), **save)
+    np.savez_compressed(os.path.join(OUT, f"diffusion_{out_tag or name}.npz"), **save)
 
 
 class _TrainLoader:
@@ -402,6 +405,7 @@ JOBS = {
     "gcn": lambda: [gen_gcn("toy", 8, 3), gen_gcn("mid", 32, 3), gen_gcn("mid", 32, 2)],
     "losses": gen_losses,
     "diffusion": lambda: [gen_diffusion("toy", 8, 16, 5, 8), gen_diffusion("mid", 32, 64, 5, 64)],
+    "diffusion_deep": lambda: [gen_diffusion("mid", 32, 64, 5, 64, dims=[48, 64], out_tag="mid_deep"), gen_diffusion("mid", 32, 32, 4, 64, dims=[24, 40, 32], out_tag="mid_deep3")],
     "epoch": lambda: [gen_epoch("toy", 8, 16, 5, 6, 1, True),
                       gen_epoch("mid", 16, 64, 5, 128, 2, False),
                       gen_epoch("mid", 16, 64, 3, 128, 1, False, cl_method=1, tag="mid_cl1"),

@@ -809,6 +809,53 @@ def test_csr_rows_equal_the_dense_path(dev):
         assert same > 0.995, f"modality {m}: {same:.4f} of the rebuilt edges agree"
 
 
+@pytest.mark.parametrize("name", ["mid_deep", "mid_deep3"])
+def test_deep_denoise_engine_paths(dev, name):
+    """Denoise with 2 / 3 hidden widths (the reference's ModuleLists, Model.py:156-160,210-218) through every engine path, against the
+    reference's vectors: split-precision (~fp32) training step and chain at fp32 round-off; the benchmark's bf16 paths (batched training
+    step, stream chains with the mid layers on bf16 GEMMs, CSR chain start) at the bf16 tolerances of the single-hidden-layer tests."""
+    from diffmm_amd import synth
+    from diffmm_amd.DataHandler import DiffusionData
+    from diffmm_amd.engine import DiffusionEngine
+    z = load(f"diffusion_{name}.npz")
+    I, D, H, T_, B = int(z["items"]), int(z["d"]), int(z["H"]), int(z["T"]), int(z["B"])
+    dims = [int(x) for x in z["dims"]]
+    hp = dict(noise_scale=float(z["noise_scale"]), noise_min=0.0001, noise_max=0.02, sim_weight=float(z["sim_weight"]), reg=float(z["reg"]), lr=1e-3)
+    E = DiffusionEngine(I, D, H, 10, 1, T_, hp, dev, B, hidden=dims)
+    assert len(E.mids) == 2 * (len(dims) - 1)
+    E.load_reference_state(0, {k[2:]: z[k] for k in z.files if k.startswith("p/")})
+    x0, t, noise, feat, ie = T(z["x0"]).to(dev), T(z["t"].astype(np.int32)).to(dev), T(z["noise"]).to(dev), T(z["feat"]).to(dev), T(z["i_embs"]).to(dev)
+    xt = T(z["x_t"]).to(dev)
+    close(E.denoise_forward(0, xt, t, feat, precision=3), z["gate/out"], rtol=1e-4, atol=2e-5, what="Denoise (gate)")
+    close(E.generate_view(0, x0, precision=3), z["genview/out"], rtol=2e-4, atol=5e-5, what="generate_view")
+    gscale = float(np.abs(z["genview/out"]).max())
+    for state in ("bf16", "fp32"):
+        E.hp["chain_state"] = state
+        gv = E.generate_views_bf16(x0)[0]
+        assert float((gv.cpu() - T(z["genview/out"])).abs().max()) < 3e-2 * gscale, f"bf16 chain ({state} state) within 3 % of the output scale"
+    g = synth.named("mid")
+    dd = DiffusionData(g.trn_rows, g.trn_cols, g.users, g.items, dev)
+    users = T(z["rows"].astype(np.int64)).to(dev)
+    assert torch.equal(dd.rows(users), x0)
+    E.hp["chain_state"] = "bf16"
+    dense = E.generate_views_bf16(x0)[0].clone()
+    sparse = E.generate_views_bf16_csr(dd.csr_rows(users))[0]
+    assert float((sparse - dense).abs().max()) < 2e-3 * gscale, "CSR chain start vs dense chain"
+    for prec, rtol_loss, gtol in ((3, 1e-4, None), (1, 2e-2, 6e-2)):
+        means = E.train_step(x0, [feat], ie, t=[t], noise=[noise], precision=prec, update=False)
+        close(means[0], float(z["tl/loss"].mean()), rtol=rtol_loss, what=f"loss (precision {prec})")
+        for k in [f[len("tl/grad/"):] for f in z.files if f.startswith("tl/grad/")]:
+            ref = z[f"tl/grad/{k}"]
+            got = E.P[0].g(k) * means[0]  # train_step scales by 1 / total (Main.py:176); the golden grads are of loss.mean()
+            if k == "in_layers.0.weight":
+                got = got[:, : I + 10]
+            if gtol is None:
+                close(got, ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, what="grad " + k)
+            else:
+                err = float((got.cpu() - T(ref)).abs().max()) / float(np.abs(ref).max())
+                assert err < gtol, f"bf16-path grad {k}: max err {err:.3e} of the gradient scale"
+
+
 def test_transpose_cast(dev):
     from diffmm_amd import ops
     x = torch.randn(1116, 6710, device=dev)

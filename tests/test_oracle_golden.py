@@ -85,7 +85,7 @@ def test_losses():
     close(val.detach(), z["l2/val"]); close(a.grad, z["l2/ga"]); close(b.grad, z["l2/gb"])
 
 
-@pytest.mark.parametrize("name", ["toy", "mid"])
+@pytest.mark.parametrize("name", ["toy", "mid", "mid_deep", "mid_deep3"])  # *_deep: denoise_dim with 2 / 3 hidden widths (Model.py:156-160)
 def test_diffusion_pieces(name):
     z = load(f"diffusion_{name}.npz")
     s = O.schedule(int(z["T"]), float(z["noise_scale"]), 0.0001, 0.02)

@@ -106,7 +106,8 @@ def test_model_gcn_mm(dev, fx):
 def _diffusion_objects(z, dev, precision=3):
     from diffmm_amd.Model import Denoise, GaussianDiffusion, denoise_dims
     I, D, H, T_, B = int(z["items"]), int(z["d"]), int(z["H"]), int(z["T"]), int(z["B"])
-    cfg = _config(base__latdim=D, base__denoise_dim=f"[{H}]", data__item_num=I, data__user_num=int(z["users"]), hyper__steps=T_,
+    dims = [int(x) for x in z["dims"]] if "dims" in z.files else [H]  # base.denoise_dim: one or more hidden widths (Model.py:156-160)
+    cfg = _config(base__latdim=D, base__denoise_dim=str(dims), data__item_num=I, data__user_num=int(z["users"]), hyper__steps=T_,
                   hyper__noise_scale=float(z["noise_scale"]), hyper__noise_min=0.0001, hyper__noise_max=0.02, hyper__sim_weight=float(z["sim_weight"]),
                   train__reg=float(z["reg"]), train__batch=B)
     in_dims, out_dims = denoise_dims(cfg)
@@ -115,7 +116,7 @@ def _diffusion_objects(z, dev, precision=3):
     return cfg, den, GaussianDiffusion(cfg)
 
 
-@pytest.mark.parametrize("name", ["toy", "mid"])
+@pytest.mark.parametrize("name", ["toy", "mid", "mid_deep", "mid_deep3"])  # *_deep: 2 / 3 hidden widths
 def test_denoise_and_gaussian_diffusion_api(dev, name):
     z = load(f"diffusion_{name}.npz")
     cfg, den, gd = _diffusion_objects(z, dev)
@@ -144,8 +145,9 @@ def test_denoise_and_gaussian_diffusion_api(dev, name):
     close(loss.detach(), z["tl/loss"], rtol=1e-4, atol=1e-7, what="training_losses")
     loss.mean().backward()
     g = den.grads()
-    for k in ("emb_layer.weight", "emb_layer.bias", "in_layers.0.weight", "in_layers.0.bias", "out_layers.0.weight", "out_layers.0.bias", "gate_layer.weight",
-              "gate_layer.bias"):
+    keys = [f[len("tl/grad/"):] for f in z.files if f.startswith("tl/grad/")]
+    assert set(keys) == set(g), "every parameter of the reference's Denoise has a gradient here, under the same name"
+    for k in keys:
         ref = z[f"tl/grad/{k}"]
         close(g[k], ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, what="grad " + k)
     ref = z["tl/g_i_embs"]
