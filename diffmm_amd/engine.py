@@ -634,7 +634,17 @@ class DiffusionEngine:
             ops.qsample_temb(x0p, noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, P.view("emb_layer.weight"),
                              P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None, seed=self.hp.get("seed", 1818),
                              offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
-            self._gate_fwd(m, a["xcat"][:B], feats[m], 1)
+            self._project_items(a["xcat"][:B], feats[m], a["proj"][:B], 1)
+        # the modalities' gate layers (d x d, one tile each) in one launch
+        ops.gemm_batched([dict(A=self.act[m]["proj"][:B], B=self.P[m].view("gate_layer.weight"), out=self.act[m]["gate"][:B], trans_b=True,
+                               bias=self.P[m].view("gate_layer.bias"), act=L.ACT_SIGMOID, precision=1) for m in range(M)])
+        for m in range(M):
+            a, P = self.act[m], self.P[m]
+            ops.mul(a["proj"][:B], a["gate"][:B], a["pg"][:B])
+            if self._item_kernels(1):
+                ops.item_expand(a["pg"][:B], feats[m], a["xcat"][:B], a["xcat"][:B], I)  # x_t += (proj * gate) F^T
+            else:
+                ops.gemm(a["pg"][:B], feats[m], out=a["xcat"][:B], trans_b=True, residual=a["xcat"][:B], e1=1.0, e2=1.0, precision=1, N=I)
             ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
             ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
             self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
@@ -660,7 +670,10 @@ class DiffusionEngine:
         Bp = (B + 63) & ~63
         for m in range(M):
             a, P, w = self.act[m], self.P[m], W[m]
-            ops.zero_(P.grad)
+            # only the gradients that are ACCUMULATED (atomics: the time-embedding layer, the K-split gate weight) need zeroing; every other
+            # entry of the 55 MB flat gradient buffer is overwritten by its GEMM / column sum
+            ops.zero_(P.grad[: P.offsets["in_layers.0.weight"]])
+            ops.zero_(P.g("gate_layer.weight"))
             ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
                           w["dum"][:B])
             if self._item_kernels(1):
@@ -693,9 +706,10 @@ class DiffusionEngine:
             ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
             self._project_items(w["dxcat"][:B], feats[m], w["dpg"][:B], 1)                          # d(proj*gate) = dx' F
             ops.gate_bwd(w["dpg"][:B], a["proj"][:B], a["gate"][:B], w["dproj"][:B], w["dgate"][:B])
-            # dWg = dgate_pre^T proj: a single d x d output tile with K = B -- split K over 32 workgroups (P.grad was zeroed above)
-            ops.gemm(w["dgate"][:B], a["proj"][:B], out=P.g("gate_layer.weight"), trans_a=True, precision=1, split_k=32)
             ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))
+        # dWg = dgate_pre^T proj: a single d x d output tile with K = B -- split K over 32 workgroups (zeroed above), all modalities in one launch
+        ops.gemm_batched([dict(A=W[m]["dgate"][:B], B=self.act[m]["proj"][:B], out=self.P[m].g("gate_layer.weight"), trans_a=True, precision=1, split_k=32)
+                          for m in range(M)])
 
     def reg_term(self, i_embs: Tensor) -> float:
         """l2_reg_loss(reg, [i_embs]) * reg (Model.py:421,425) as a host value.  i_embs does not move during the diffusion phase (only the
