@@ -57,6 +57,11 @@ class BatchLoader:
             perm = torch.randperm(n, device=self.device, generator=self.gen)
         else:
             perm = torch.arange(n, device=self.device)
+        if hasattr(self.dataset, "epoch"):  # gather the whole epoch once (3 launches), then hand out contiguous slices: no per-batch index kernels
+            cols = self.dataset.epoch(perm)
+            for s in range(0, n, self.batch_size):
+                yield tuple(c[s:s + self.batch_size] for c in cols)
+            return
         for s in range(0, n, self.batch_size):
             yield self.dataset.batch(perm[s:s + self.batch_size])
 
@@ -107,6 +112,10 @@ class TrainData:
 
     def batch(self, idx: torch.Tensor):
         return self._rows_d[idx].contiguous(), self._cols_d[idx].contiguous(), self._negs_d[idx].contiguous()
+
+    def epoch(self, perm: torch.Tensor):
+        """The whole shuffled epoch: (users, positives, negatives) gathered once; the loader slices minibatches out of them."""
+        return self._rows_d[perm].contiguous(), self._cols_d[perm].contiguous(), self._negs_d[perm].contiguous()
 
 
 class TestData:
