@@ -38,7 +38,7 @@ class GemmBf16Args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
                 ("Cb", C.c_void_p), ("ldcb", C.c_int64), ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64), ("Rb", C.c_void_p), ("ldrb", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("alpha", C.c_float), ("e1", C.c_float), ("e2", C.c_float),
-                ("act", C.c_int32)]
+                ("act", C.c_int32), ("bias2", C.c_void_p)]
 
 
 class GatherDesc(C.Structure):
@@ -66,6 +66,9 @@ _SIGS = {
     "dmm_gemm_bf16_nt_batched": (C.c_int, [C.POINTER(GemmBf16Args), _I, _P]),
     "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_transpose_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
+    "dmm_cast_bf16_split": (C.c_int, [_P, _L, _P, _P, _L, _I, _I, _I, _P]),
+    "dmm_transpose_cast_bf16_split": (C.c_int, [_P, _L, _P, _P, _L, _I, _I, _I, _P]),
+    "dmm_gemv_rows": (C.c_int, [_P, _L, _P, _P, _I, _I, _P]),
     "dmm_temb_bias_table": (C.c_int, [_P, _P, _I, _P, _L, _I, _P, _I, _I, _P, _P]),
     "dmm_rownorm_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "dmm_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
@@ -89,6 +92,7 @@ _SIGS = {
     "dmm_qsample_temb": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),
     "dmm_csr_dense_rows": (C.c_int, [_P, _P, _P, _I, _I, _P, _L, _P]),
     "dmm_csr_gather_sum_bf16": (C.c_int, [_P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _L, _P]),
+    "dmm_csr_gather_sum_latent": (C.c_int, [_P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P, _L, _P]),
     "dmm_csr_add_rows": (C.c_int, [_P, _P, _P, _I, _I, _F, _P, _L, _P, _L, _P]),
     "dmm_rows_axpby": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _P]),
     "dmm_temb_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),

@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void csr_dense_rows_kernel(const long long* __
 template <int ACT>
 __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
                                                              const long long* __restrict__ rows, const __bf16* __restrict__ Wt, long long ldw,
-                                                             const float* __restrict__ bias, __bf16* __restrict__ out16, long long ldo, int H) {
+                                                             const float* __restrict__ bias, __bf16* __restrict__ out16, long long ldo, int H,
+                                                             float* __restrict__ z, long long ldz) {
   const int b = blockIdx.x;
   const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
   for (int h0 = threadIdx.x * 4; h0 < H; h0 += 1024) {  // 4 columns (8 bytes of bf16) per thread per pass
-    float a[4] = {bias[h0], bias[h0 + 1], bias[h0 + 2], bias[h0 + 3]};
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!z) { a[0] = bias[h0]; a[1] = bias[h0 + 1]; a[2] = bias[h0 + 2]; a[3] = bias[h0 + 3]; }
     long long e = beg;
     for (; e + 8 <= end; e += 8) {  // 8 independent row gathers in flight (a heavy user has hundreds of items: the loop is latency-bound)
       uint2 w[8];
@@ -116,6 +118,10 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const long long* __
       const uint2 w = *reinterpret_cast<const uint2*>(Wt + (long long)col[e] * ldw + h0);
       a[0] += __uint_as_float(w.x << 16); a[1] += __uint_as_float(w.x & 0xffff0000u);
       a[2] += __uint_as_float(w.y << 16); a[3] += __uint_as_float(w.y & 0xffff0000u);
+    }
+    if (z) {  // latent chain start: the bias-free sum is the fp32 state z_T = x_0 W1x^T; the bias joins for the activation only
+      *reinterpret_cast<float4*>(z + (long long)b * ldz + h0) = make_float4(a[0], a[1], a[2], a[3]);
+      a[0] += bias[h0]; a[1] += bias[h0 + 1]; a[2] += bias[h0 + 2]; a[3] += bias[h0 + 3];
     }
     __bf16 o[4];
 #pragma unroll
@@ -749,19 +755,29 @@ extern "C" int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const 
   DMM_LAUNCH_CHECK("dmm_csr_dense_rows");
   return 0;
 }
-extern "C" int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias,
-                                       int H, int act, void* out16, int64_t ldo, void* stream) {
+static int csr_gather_sum_launch(const char* who, const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw,
+                                 const float* bias, int H, int act, void* out16, int64_t ldo, float* z, int64_t ldz, void* stream) {
   DMM_CHECK_ARG(ptr && col && rows && Wt && bias && out16 && B > 0 && H > 0 && H % 4 == 0 && ldw >= H && ldw % 4 == 0 && ldo >= H && ldo % 4 == 0,
-                "dmm_csr_gather_sum_bf16: bad arguments (H, ldw, ldo multiples of 4)");
-  DMM_CHECK_ARG(act == DMM_ACT_NONE || act == DMM_ACT_TANH, "dmm_csr_gather_sum_bf16: act must be NONE or TANH");
+                "%s: bad arguments (H, ldw, ldo multiples of 4)", who);
+  DMM_CHECK_ARG(!z || (ldz >= H && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "%s: z must be 16-byte aligned with ldz >= H, ldz %% 4 == 0", who);
+  DMM_CHECK_ARG(act == DMM_ACT_NONE || act == DMM_ACT_TANH, "%s: act must be NONE or TANH", who);
   if (act == DMM_ACT_TANH)
     hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows,
-                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H);
+                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H, z, (long long)ldz);
   else
     hipLaunchKernelGGL(csr_gather_sum_kernel<0>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows,
-                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H);
-  DMM_LAUNCH_CHECK("dmm_csr_gather_sum_bf16");
+                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H, z, (long long)ldz);
+  DMM_LAUNCH_CHECK(who);
   return 0;
+}
+extern "C" int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias,
+                                       int H, int act, void* out16, int64_t ldo, void* stream) {
+  return csr_gather_sum_launch("dmm_csr_gather_sum_bf16", ptr, col, rows, B, Wt, ldw, bias, H, act, out16, ldo, nullptr, 0, stream);
+}
+extern "C" int dmm_csr_gather_sum_latent(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias,
+                                         int H, float* z, int64_t ldz, void* out16, int64_t ldo, void* stream) {
+  DMM_CHECK_ARG(z, "dmm_csr_gather_sum_latent: z is NULL");
+  return csr_gather_sum_launch("dmm_csr_gather_sum_latent", ptr, col, rows, B, Wt, ldw, bias, H, DMM_ACT_TANH, out16, ldo, z, ldz, stream);
 }
 extern "C" int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float c, float* y, int64_t ldy, void* y16,
                                 int64_t ldy16, void* stream) {

@@ -13,6 +13,7 @@ struct GemmBf16P {
   float* C; long long ldc;
   __bf16* Cb; long long ldcb;
   const float* bias;
+  const float* bias2;  // non-null: Cb = tanh(C + bias2[n]) instead of a copy of C (needs C and Cb)
   const float* R; long long ldr;
   const __bf16* Rb; long long ldrb;  // residual given in bf16 (alternative to R)
   int M, N, K;

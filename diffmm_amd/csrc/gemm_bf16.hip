@@ -86,8 +86,8 @@ template <int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmBf16P& Pk, f32x16 (&acc)[2][BN / 64], char* smem, int m0, int n0, int wave, int lane) {
   // Every operand is copied out of the kernel-argument struct once: read through the reference, each use re-fetched its field
   // (scalar load + full wait), which made the epilogue slower than a K = 1024 main loop.
-  struct { float* C; __bf16* Cb; const float* R; const __bf16* Rb; const float* bias; long long ldc, ldcb, ldr, ldrb; int M, N, act; float alpha, e1, e2; } P;
-  P.C = Pk.C; P.Cb = Pk.Cb; P.R = Pk.R; P.Rb = Pk.Rb; P.bias = Pk.bias; P.ldc = Pk.ldc; P.ldcb = Pk.ldcb; P.ldr = Pk.ldr; P.ldrb = Pk.ldrb;
+  struct { float* C; __bf16* Cb; const float* R; const __bf16* Rb; const float* bias; const float* bias2; long long ldc, ldcb, ldr, ldrb; int M, N, act; float alpha, e1, e2; } P;
+  P.C = Pk.C; P.Cb = Pk.Cb; P.R = Pk.R; P.Rb = Pk.Rb; P.bias = Pk.bias; P.bias2 = Pk.bias2; P.ldc = Pk.ldc; P.ldcb = Pk.ldcb; P.ldr = Pk.ldr; P.ldrb = Pk.ldrb;
   P.M = Pk.M; P.N = Pk.N; P.act = Pk.act; P.alpha = Pk.alpha; P.e1 = Pk.e1; P.e2 = Pk.e2;
   constexpr int WN = BN / 2, NT = WN / 32;
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
@@ -153,6 +153,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBf16P& Pk, f32x16 (&acc)
         }
         if (P.C) *reinterpret_cast<float4*>(P.C + (long long)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (P.Cb) {
+          if (P.bias2) {  // latent chain: the bf16 output is the next activation tanh(C + bias2)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = tanh_fast_bf16(v[u] + P.bias2[n + u]);
+          }
           *reinterpret_cast<bf16x4*>(P.Cb + (long long)m * P.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         }
       } else {
@@ -161,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBf16P& Pk, f32x16 (&acc)
           if (P.R) x = P.e1 * x + P.e2 * P.R[(long long)m * P.ldr + n + u];
           else if (P.Rb) x = P.e1 * x + P.e2 * (float)P.Rb[(long long)m * P.ldrb + n + u];
           if (P.C) P.C[(long long)m * P.ldc + n + u] = x;
-          if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)x;
+          if (P.Cb) P.Cb[(long long)m * P.ldcb + n + u] = (__bf16)(P.bias2 ? tanh_fast_bf16(x + P.bias2[n + u]) : x);
         }
       }
     }
@@ -259,18 +263,22 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_nt_kernel(const GemmBf16Batc
 }
 
 // fp32 [rows, cols] (ld lds) -> bf16 (ld ldd); columns cols..cols_pad are zero-filled
+// lo (optional, same layout as dst): the bf16 of what the first rounding lost, x - float(bf16(x)); hi + lo carries 16 mantissa bits
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, long long lds, __bf16* __restrict__ dst, long long ldd,
-                                                         int rows, int cols, int cols_pad) {
+                                                         int rows, int cols, int cols_pad, __bf16* __restrict__ lo) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)rows * cols_pad; i += (long long)gridDim.x * 256) {
     const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
-    dst[(long long)r * ldd + c] = c < cols ? (__bf16)src[(long long)r * lds + c] : (__bf16)0.f;
+    const float x = c < cols ? src[(long long)r * lds + c] : 0.f;
+    const __bf16 hi = (__bf16)x;
+    dst[(long long)r * ldd + c] = hi;
+    if (lo) lo[(long long)r * ldd + c] = (__bf16)(x - (float)hi);
   }
 }
 
 // fp32 [R, C] (ld lds) -> bf16 [C, Rp] (ld ldd): tiled transpose through LDS; destination columns R..Rp are zero-filled so the
 // result can be the K-contiguous operand of the NT GEMM with K = Rp (a multiple of 8)
 __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ src, long long lds, __bf16* __restrict__ dst,
-                                                                   long long ldd, int R, int C, int Rp) {
+                                                                   long long ldd, int R, int C, int Rp, __bf16* __restrict__ lo) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -283,7 +291,12 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* _
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = c0 + ty + 4 * i, r = r0 + tx;
-    if (c < C && r < Rp) dst[(long long)c * ldd + r] = (__bf16)tile[tx][ty + 4 * i];
+    if (c < C && r < Rp) {
+      const float x = tile[tx][ty + 4 * i];
+      const __bf16 hi = (__bf16)x;
+      dst[(long long)c * ldd + r] = hi;
+      if (lo) lo[(long long)c * ldd + r] = (__bf16)(x - (float)hi);
+    }
   }
 }
 
@@ -348,6 +361,7 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   for (int i = 0; i < n_batch; ++i) {
     const dmm_gemm_bf16_args* a = args + i;
     DMM_CHECK_ARG(a->A && a->B && (a->C || a->Cb), "dmm_gemm_bf16_nt: null operand (problem %d)", i);
+    DMM_CHECK_ARG(!a->bias2 || (a->C && a->Cb), "dmm_gemm_bf16_nt: bias2 needs both outputs (problem %d)", i);
     DMM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0, "dmm_gemm_bf16_nt: K=%d must be a positive multiple of 8", a->K);
     DMM_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && (((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0,
                   "dmm_gemm_bf16_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
@@ -355,7 +369,7 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
     GemmBf16P& P = b.p[i];
     P.A = (const __bf16*)a->A; P.lda = a->lda; P.B = (const __bf16*)a->B; P.ldb = a->ldb;
     P.C = a->C; P.ldc = a->ldc; P.Cb = (__bf16*)a->Cb; P.ldcb = a->ldcb;
-    P.bias = a->bias; P.R = a->R; P.ldr = a->ldr; P.Rb = (const __bf16*)a->Rb; P.ldrb = a->ldrb; P.M = a->M; P.N = a->N; P.K = a->K;
+    P.bias = a->bias; P.bias2 = a->bias2; P.R = a->R; P.ldr = a->ldr; P.Rb = (const __bf16*)a->Rb; P.ldrb = a->ldrb; P.M = a->M; P.N = a->N; P.K = a->K;
     P.alpha = a->alpha; P.e1 = a->e1; P.e2 = a->e2; P.act = a->act;
   }
   static const int force_tile = [] { const char* e = getenv("DMM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning knobs: 64 / 128 / 256
@@ -411,16 +425,55 @@ extern "C" int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t l
   DMM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols_pad >= cols && ldd >= cols_pad, "dmm_cast_bf16: bad arguments");
   const long long n = (long long)rows * cols_pad;
   const unsigned grid = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)lds, (__bf16*)dst, (long long)ldd, rows, cols, cols_pad);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)lds, (__bf16*)dst, (long long)ldd, rows, cols, cols_pad,
+                     (__bf16*)nullptr);
   DMM_LAUNCH_CHECK("dmm_cast_bf16");
+  return 0;
+}
+
+extern "C" int dmm_cast_bf16_split(const float* src, int64_t lds, void* hi, void* lo, int64_t ldd, int rows, int cols, int cols_pad, void* stream) {
+  DMM_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && cols_pad >= cols && ldd >= cols_pad, "dmm_cast_bf16_split: bad arguments");
+  const long long n = (long long)rows * cols_pad;
+  const unsigned grid = (unsigned)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (long long)lds, (__bf16*)hi, (long long)ldd, rows, cols, cols_pad,
+                     (__bf16*)lo);
+  DMM_LAUNCH_CHECK("dmm_cast_bf16_split");
   return 0;
 }
 
 extern "C" int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream) {
   DMM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows_pad >= rows && ldd >= rows_pad, "dmm_transpose_cast_bf16: bad arguments");
   hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3(cdiv(cols, 64), cdiv(rows_pad, 64)), dim3(256), 0, (hipStream_t)stream, src, (long long)lds,
-                     (__bf16*)dst, (long long)ldd, rows, cols, rows_pad);
+                     (__bf16*)dst, (long long)ldd, rows, cols, rows_pad, (__bf16*)nullptr);
   DMM_LAUNCH_CHECK("dmm_transpose_cast_bf16");
+  return 0;
+}
+
+extern "C" int dmm_transpose_cast_bf16_split(const float* src, int64_t lds, void* hi, void* lo, int64_t ldd, int rows, int cols, int rows_pad, void* stream) {
+  DMM_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && rows_pad >= rows && ldd >= rows_pad, "dmm_transpose_cast_bf16_split: bad arguments");
+  hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3(cdiv(cols, 64), cdiv(rows_pad, 64)), dim3(256), 0, (hipStream_t)stream, src, (long long)lds,
+                     (__bf16*)hi, (long long)ldd, rows, cols, rows_pad, (__bf16*)lo);
+  DMM_LAUNCH_CHECK("dmm_transpose_cast_bf16_split");
+  return 0;
+}
+
+// out[r] = sum_c W[r, c] x[c]: one workgroup per row (the latent chain's g = W1x b2: an [H, I] matrix against the layer-2 bias)
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, long long ldw, const float* __restrict__ x, float* __restrict__ out, int cols) {
+  const float* __restrict__ w = W + (long long)blockIdx.x * ldw;
+  float a = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) a += w[c] * x[c];
+  __shared__ float part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+extern "C" int dmm_gemv_rows(const float* W, int64_t ldw, const float* x, float* out, int rows, int cols, void* stream) {
+  DMM_CHECK_ARG(W && x && out && rows > 0 && cols > 0 && ldw >= cols, "dmm_gemv_rows: bad arguments");
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, W, (long long)ldw, x, out, cols);
+  DMM_LAUNCH_CHECK("dmm_gemv_rows");
   return 0;
 }
 

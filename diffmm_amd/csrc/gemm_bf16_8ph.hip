@@ -78,7 +78,7 @@ __device__ __forceinline__ void p8_read_b(bf16x8 (&b)[2][2], const char* unit, i
 // reference the compiler re-fetched every field at every use (scalar load + full wait, ~300 of them: 27-44 us per workgroup,
 // more than the K = 1024 main loop).
 struct P8Epi {
-  float* C; __bf16* Cb; const float* R; const __bf16* Rb; const float* bias;
+  float* C; __bf16* Cb; const float* R; const __bf16* Rb; const float* bias; const float* bias2;
   long long ldc, ldcb, ldr, ldrb;
   int M, N, act;
   float alpha, e1, e2;
@@ -157,8 +157,9 @@ __device__ __forceinline__ void p8_ld_res_edge(const char* p, int nv, u32x2& r) 
   r = u32x2{w0, w1};
 }
 
-template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
-__device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const char*& pR, long long rs,
+// B2 (the latent reverse chain): the bf16 output is not a copy of C but the NEXT layer's activation tanh(C + bias2[n]).
+template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2>
+__device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float4& c4, const char*& pR, long long rs,
                                              float*& pC, __bf16*& pCb, const typename P8Res<RK>::type (&rcur)[8], typename P8Res<RK>::type (&rnext)[8],
                                              int mrow, int nv) {
   constexpr bool HAS_R = RK != 0;
@@ -185,16 +186,18 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
       const float4 r4 = p8_res_f4(rcur[it]);
       v[0] = E.e1 * v[0] + E.e2 * r4.x; v[1] = E.e1 * v[1] + E.e2 * r4.y; v[2] = E.e1 * v[2] + E.e2 * r4.z; v[3] = E.e1 * v[3] + E.e2 * r4.w;
     }
+    float w[4] = {v[0], v[1], v[2], v[3]};
+    if (B2) { w[0] = tanh_fast_bf16(v[0] + c4.x); w[1] = tanh_fast_bf16(v[1] + c4.y); w[2] = tanh_fast_bf16(v[2] + c4.z); w[3] = tanh_fast_bf16(v[3] + c4.w); }
     if (!EDGE) {
       if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-      if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, v);
+      if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w);
     } else if (mrow + PASS * 32 + it * 4 < E.M && nv > 0) {
       if (nv == 4) {
         if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-        if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, v);
+        if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w);
       } else {
         if (HAS_C) p8_st_edge(pC + (long long)(it * 4) * E.ldc, v, nv);
-        if (HAS_CB) p8_st_edge(pCb + (long long)(it * 4) * E.ldcb, v, nv);
+        if (HAS_CB) p8_st_edge(pCb + (long long)(it * 4) * E.ldcb, w, nv);
       }
     }
   }
@@ -205,7 +208,7 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
   if (HAS_CB) pCb += 32 * E.ldcb;
 }
 
-template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE>
+template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2 = false>
 __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
   constexpr bool HAS_R = RK != 0;
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
@@ -216,6 +219,8 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
   const int nv = EDGE ? max(0, min(4, E.N - n)) : 4;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (E.bias) b4 = nv == 4 ? *reinterpret_cast<const float4*>(E.bias + n) : p8_ld_edge(E.bias + n, nv);
+  float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (B2) c4 = nv == 4 ? *reinterpret_cast<const float4*>(E.bias2 + n) : p8_ld_edge(E.bias2 + n, nv);
   const long long rs = RK == 1 ? E.ldr * 4 : E.ldrb * 2;
   const char* pR = RK == 1 ? reinterpret_cast<const char*>(E.R + m * E.ldr + n) : RK == 2 ? reinterpret_cast<const char*>(E.Rb + m * E.ldrb + n) : nullptr;
   float* pC = HAS_C ? E.C + m * E.ldc + n : nullptr;
@@ -235,10 +240,10 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
       }
     }
   }
-  p8_fast_pass<0, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
-  p8_fast_pass<1, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
-  p8_fast_pass<2, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, rc, rb, mrow, nv);
-  p8_fast_pass<3, RK, HAS_C, HAS_CB, ACT, EDGE>(E, acc, tile, q, fr, b4, pR, rs, pC, pCb, ra, rb, mrow, nv);
+  p8_fast_pass<0, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
+  p8_fast_pass<1, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
+  p8_fast_pass<2, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, rc, rb, mrow, nv);
+  p8_fast_pass<3, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, ra, rb, mrow, nv);
 }
 
 // Edge tiles, unaligned operands and the rarely used operand combinations: bounds-checked, element-wise where needed.
@@ -262,13 +267,15 @@ __device__ __forceinline__ void p8_generic_pass(const P8Epi& E, const P8Acc& acc
       else if (E.Rb) x = E.e1 * x + E.e2 * (float)E.Rb[(long long)m * E.ldrb + n + u];
       v[u] = x;
     }
+    float w[4] = {v[0], v[1], v[2], v[3]};
+    if (E.bias2) for (int u = 0; u < nv; ++u) w[u] = tanh_fast_bf16(v[u] + E.bias2[n + u]);
     if (nv == 4 && vec_ok) {
       if (E.C) *reinterpret_cast<float4*>(E.C + (long long)m * E.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-      if (E.Cb) *reinterpret_cast<bf16x4*>(E.Cb + (long long)m * E.ldcb + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      if (E.Cb) *reinterpret_cast<bf16x4*>(E.Cb + (long long)m * E.ldcb + n) = bf16x4{(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
     } else {
       for (int u = 0; u < nv; ++u) {
         if (E.C) E.C[(long long)m * E.ldc + n + u] = v[u];
-        if (E.Cb) E.Cb[(long long)m * E.ldcb + n + u] = (__bf16)v[u];
+        if (E.Cb) E.Cb[(long long)m * E.ldcb + n + u] = (__bf16)w[u];
       }
     }
   }
@@ -279,10 +286,12 @@ __device__ __forceinline__ void p8_generic_pass(const P8Epi& E, const P8Acc& acc
 // Epilogue kinds.  Each gets its own kernel instantiation -- its own symbol in a rocprof trace (the chain's layer 1 and layer 2 no longer
 // share one row of the kernel stats) and only its own epilogue code and registers.  EPI_GENERIC dispatches at run time.
 enum { EPI_GENERIC = 0, EPI_TANH_CB = 1 /* chain layer 1 */, EPI_R32_C_CB = 2 /* chain layer 2, fp32 state */, EPI_R16_CB = 3 /* chain layer 2, bf16 state */,
-       EPI_R16_C = 4 /* last chain step */, EPI_TANH_C_CB = 5 /* training: h in fp32 and bf16 */, EPI_C = 6, EPI_CB = 7, EPI_C_CB = 8 /* first step of a CSR-started chain */, EPI_COUNT = 9 };
+       EPI_R16_C = 4 /* last chain step */, EPI_TANH_C_CB = 5 /* training: h in fp32 and bf16 */, EPI_C = 6, EPI_CB = 7, EPI_C_CB = 8 /* first step of a CSR-started chain */,
+       EPI_LATENT = 9 /* latent chain step: z' = e1 (acc + g) + e2 z in fp32, tanh(z' + bias2) in bf16 */, EPI_LATENT_START = 10 /* its dense start: no residual */, EPI_COUNT = 11 };
 
 static int p8_pick_epi(const GemmBf16P& P) {
   const bool noR = !P.R && !P.Rb;
+  if (P.bias2) return P.act != DMM_ACT_NONE || P.Rb ? EPI_GENERIC : P.R ? EPI_LATENT : EPI_LATENT_START;
   if (noR && !P.C && P.Cb && P.act == DMM_ACT_TANH) return EPI_TANH_CB;
   if (P.R && !P.Rb && P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_R32_C_CB;
   if (P.Rb && !P.R && !P.C && P.Cb && P.act == DMM_ACT_NONE) return EPI_R16_CB;
@@ -297,11 +306,11 @@ static int p8_pick_epi(const GemmBf16P& P) {
 template <int EPI>
 __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
   P8Epi E;
-  E.C = P.C; E.Cb = P.Cb; E.R = P.R; E.Rb = P.Rb; E.bias = P.bias;
+  E.C = P.C; E.Cb = P.Cb; E.R = P.R; E.Rb = P.Rb; E.bias = P.bias; E.bias2 = P.bias2;
   E.ldc = P.ldc; E.ldcb = P.ldcb; E.ldr = P.ldr; E.ldrb = P.ldrb;
   E.M = P.M; E.N = P.N; E.act = P.act; E.alpha = P.alpha; E.e1 = P.e1; E.e2 = P.e2;
   const bool vec_ok = (!E.C || (E.ldc % 4 == 0 && ((uintptr_t)E.C & 15) == 0)) && (!E.Cb || (E.ldcb % 4 == 0 && ((uintptr_t)E.Cb & 7) == 0));
-  const bool fast = vec_ok && (!E.bias || ((uintptr_t)E.bias & 15) == 0) && (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0)) &&
+  const bool fast = vec_ok && (!E.bias || ((uintptr_t)E.bias & 15) == 0) && (!E.bias2 || ((uintptr_t)E.bias2 & 15) == 0) && (!E.R || (E.ldr % 4 == 0 && ((uintptr_t)E.R & 15) == 0)) &&
                     (!E.Rb || (!E.R && E.ldrb % 4 == 0 && ((uintptr_t)E.Rb & 7) == 0));
   const bool interior = m0 + 256 <= E.M && n0 + 256 <= E.N;
 #define P8_FAST(R_, C_, CB_, ACT_)                                                                   \
@@ -323,6 +332,12 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
     P8_FAST(0, true, false, DMM_ACT_NONE);
   } else if (fast && EPI == EPI_C_CB) {
     P8_FAST(0, true, true, DMM_ACT_NONE);
+  } else if (fast && EPI == EPI_LATENT) {
+    if (interior) p8_epilogue_fast<1, true, true, DMM_ACT_NONE, false, true>(E, acc, smem, m0, n0, wave, lane);
+    else p8_epilogue_fast<1, true, true, DMM_ACT_NONE, true, true>(E, acc, smem, m0, n0, wave, lane);
+  } else if (fast && EPI == EPI_LATENT_START) {
+    if (interior) p8_epilogue_fast<0, true, true, DMM_ACT_NONE, false, true>(E, acc, smem, m0, n0, wave, lane);
+    else p8_epilogue_fast<0, true, true, DMM_ACT_NONE, true, true>(E, acc, smem, m0, n0, wave, lane);
   } else if (fast && EPI == EPI_TANH_C_CB) {  // training forward: h in fp32 (for the backward) and bf16 (next operand)
     P8_FAST(0, true, true, DMM_ACT_TANH);
 #undef P8_FAST
@@ -496,6 +511,8 @@ void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
     case EPI_C: p8_launch<EPI_C>(b, s); break;
     case EPI_CB: p8_launch<EPI_CB>(b, s); break;
     case EPI_C_CB: p8_launch<EPI_C_CB>(b, s); break;
+    case EPI_LATENT: p8_launch<EPI_LATENT>(b, s); break;
+    case EPI_LATENT_START: p8_launch<EPI_LATENT_START>(b, s); break;
     default: p8_launch<EPI_GENERIC>(b, s); break;
   }
 }

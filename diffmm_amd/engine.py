@@ -426,6 +426,7 @@ class DiffusionEngine:
         self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
         self._w1T_chain = None  # bf16 W1^T per modality, allocated by the first CSR chain start
+        self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
@@ -784,7 +785,95 @@ class DiffusionEngine:
                 ops.transpose_cast_bf16(P.view("in_layers.0.weight"), self._w1T_chain[m], rows=self.H, cols=self.Kp)
                 ops.zero_(self._b2_first[m])  # operand, so the posterior-mean scale c1 goes into alpha and into this pre-scaled bias
                 ops.add_inplace(self._b2_first[m], P.view(self.L2 + ".bias"), float(self.c1[self.T - 1]))
+            if self._lat is not None:  # latent chain: G = W1x W2 [H, H] (bf16 operand), g = W1x b2, and the last step's pre-scaled bias
+                # G on the bf16 MFMA GEMM at fp32 grade: both factors split hi + lo (16 mantissa bits), hi*hi + lo*hi + hi*lo as three problems
+                # of one launch, summed small terms first, then rounded to bf16 ONCE (what the stepwise chain rounds twice per step)
+                lat, W1, b2 = self._lat, P.view("in_layers.0.weight"), P.view(self.L2 + ".bias")
+                ops.cast_bf16_split(W1, self.w1_16[m], lat["w1lo"])
+                ops.transpose_cast_bf16_split(P.view(self.L2 + ".weight"), lat["w2Thi"], lat["w2Tlo"], rows=self.I, cols=self.H, rows_pad=self.Kp)
+                T3 = lat["G32"]
+                ops.gemm_bf16_nt_batched([dict(A=self.w1_16[m], B=lat["w2Thi"], out=T3[0]), dict(A=lat["w1lo"], B=lat["w2Thi"], out=T3[1]),
+                                          dict(A=self.w1_16[m], B=lat["w2Tlo"], out=T3[2])])
+                ops.add_inplace(T3[1], T3[2])
+                ops.add_inplace(T3[0], T3[1])
+                ops.cast_bf16(T3[0], lat["G16"][m])
+                ops.gemv_rows(W1, b2, lat["g"][m], cols=self.I)
+                ops.zero_(lat["b2_last"][m])
+                ops.add_inplace(lat["b2_last"][m], b2, float(self.c1[0]))
             self.w16_step[m] = P.step
+
+    # -- latent reverse chain ---------------------------------------------------------------------------
+    def _latent_mode(self) -> bool:
+        """hp chain_mode / DMM_CHAIN_MODE: "latent" (default) or "stepwise".  The latent chain needs the schedule's c2[0] == 0 (always true
+        for the reference's schedule: posterior_mean_coef2[0] = (1 - alphas_cumprod_prev[0]) ... = 0, Model.py:256-262)."""
+        return self.hp.get("chain_mode", os.environ.get("DMM_CHAIN_MODE", "latent")) == "latent" and float(self.c2[0]) == 0.0
+
+    def _latent_alloc(self):
+        if self._lat is not None:
+            return
+        M, R, H, I = self.M, self.chain_rows, self.H, self.I
+        z = lambda *s_: torch.zeros(s_, dtype=torch.float32, device=self.dev)
+        zb = lambda *s_: torch.zeros(s_, dtype=torch.bfloat16, device=self.dev)
+        self._lat = dict(za=[z(R, H) for _ in range(M)], zb=[z(R, H) for _ in range(M)], hb=[zb(R, H) for _ in range(M)], G32=z(3, H, H),
+                         G16=[zb(H, H) for _ in range(M)], g=[z(H) for _ in range(M)], b2_last=[z(I) for _ in range(M)],
+                         w1lo=zb(H, self.Kp), w2Thi=zb(H, self.Kp), w2Tlo=zb(H, self.Kp))  # (scratch of the once-per-epoch G refresh)
+        if self._w1T_chain is None:
+            self._w1T_chain = [zb(self.Kp, H) for _ in range(M)]
+            self._b2_first = [z(I) for _ in range(M)]
+            self._csr_users = torch.zeros(R, dtype=torch.int64, device=self.dev)
+        self.w16_step = [-1] * M
+
+    def generate_views_latent(self, rows: Optional[CsrRows] = None, xT=None, B: Optional[int] = None, mods: Optional[Sequence[int]] = None) -> List[Tensor]:
+        """The reverse chain (GaussianDiffusion.p_sample without sampling noise, Model.py:300-322) in the H-dimensional space of layer 1's
+        pre-activation.  Between two tanh's every step is affine in x_t:
+            x_{t-1} = c1[t] (h_t W2^T + b2) + c2[t] x_t         (posterior mean of the Denoise prediction, Model.py:375)
+            pre_{t-1} = x_{t-1} W1x^T + bias_t[t-1]              (layer 1 of the next step; bias_t = b1 + W1e temb(t))
+        so with z_t := x_t W1x^T [B, H], G := W1x W2 [H, H] and g := W1x b2 the chain never needs x_t itself:
+            z_{t-1} = c2[t] z_t + c1[t] (h_t G^T + g),   h_{t-1} = tanh(z_{t-1} + bias_t[t-1]),
+        and, c2[0] being 0, its result is x_0' = c1[0] (h_0 W2^T + b2): T - 1 GEMMs of [B, H] x [H, H] (one launch per step for all
+        modalities, fp32 z in the epilogue, bf16 h for the next step) and ONE item-sized GEMM, instead of 2 T item-sized ones.  The start
+        z_T is a gather of W1x^T rows when x_T = x_0 comes as CSR rows, else one layer-1 GEMM on the dense x_T (sampling_step > 0).  Any
+        mid layers (k > 1 hidden widths) run between h_t and the latent GEMM as in the stepwise chain.  Returns [B, I] fp32 views."""
+        mods = list(range(self.M)) if mods is None else list(mods)
+        T, I, H = self.T, self.I, self.H
+        self._latent_alloc()
+        lat = self._lat
+        for m in mods:
+            self._refresh_bf16_weights(m)
+        if rows is not None:
+            B = rows.shape[0]
+            self._csr_users[:B].copy_(rows.users)
+            key = ("latent-csr", B, rows.ptr.data_ptr(), rows.col.data_ptr(), tuple(mods))
+        else:
+            for m, x in zip(mods, xT):  # fp32 staging; cast to the bf16 operand inside the plan
+                self.cxb[m][:B, :I].copy_(x)
+            key = ("latent-dense", B, tuple(mods))
+        plan = self._chain_plans.get(key)
+        if plan is None:
+            with L.Recorder() as plan:
+                z, z2 = {m: lat["za"][m][:B] for m in mods}, {m: lat["zb"][m][:B] for m in mods}
+                if os.environ.get("DMM_LATENT_INPLACE", "0") == "1":
+                    z2 = z
+                h, h2 = {m: self.ch16[m][:B] for m in mods}, {m: lat["hb"][m][:B] for m in mods}
+                if rows is not None:
+                    users = self._csr_users[:B]
+                    for m in mods:
+                        ops.csr_gather_sum_latent(rows.ptr, rows.col, users, self._w1T_chain[m], self.bias_t[m][T - 1], z[m], h[m])
+                else:
+                    for m in mods:
+                        ops.cast_bf16(self.cxb[m][:B], self.cxa16[m][:B], cols=I, cols_pad=self.Kp)  # temb / pad columns zero: temb enters through bias_t
+                    ops.gemm_bf16_nt_batched([dict(A=self.cxa16[m][:B], B=self.w1_16[m], out=z[m], out_bf16=h[m], bias2=self.bias_t[m][T - 1]) for m in mods])
+                for i in range(T - 1, 0, -1):
+                    ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h[m]), B=lat["G16"][m], out=z2[m], out_bf16=h2[m], bias=lat["g"][m], residual=z[m],
+                                                   e1=float(self.c1[i]), e2=float(self.c2[i]), bias2=self.bias_t[m][i - 1]) for m in mods])
+                    z, z2, h, h2 = z2, z, h2, h
+                ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h[m]), B=self.w2_16[m], out=self.cxa[m][:B], bias=lat["b2_last"][m], alpha=float(self.c1[0]), N=I)
+                                          for m in mods])
+            if len(self._chain_plans) > 16:
+                self._chain_plans.clear()
+            self._chain_plans[key] = plan
+        L.replay(plan)
+        return [self.cxa[m][:B, :I] for m in mods]
 
     def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
         """Reverse chain on the dedicated bf16 NT GEMM: bf16 weights / activations as MFMA operands, fp32 accumulation, the
@@ -968,7 +1057,7 @@ class DiffusionEngine:
     def generate_view(self, m: int, x0: Tensor, precision: int = 1) -> Tensor:
         """sampling_step == 0 path: x_T = x0, then T deterministic posterior-mean steps.  Returns a [B, I] view (ld = Kp)."""
         if precision == 1:
-            return self.generate_view_bf16(m, x0)
+            return self.generate_views_latent(xT=[x0], B=x0.shape[0], mods=[m])[0] if self._latent_mode() else self.generate_view_bf16(m, x0)
         B, I, P = x0.shape[0], self.I, self.P[m]
         cur, nxt = self.xa[:B], self.xb[:B]
         cur[:, :I].copy_(x0)
@@ -1008,15 +1097,23 @@ class DiffusionEngine:
             n_chunks = max(1, -(-n // self.chain_rows))
             per = max(1, -(-n // n_chunks))
             user_batches = [all_users[s:s + per] for s in range(0, n, per)]
+        latent = precision == 1 and self._latent_mode()
         for ub in user_batches:
             if ub.numel() == 0:
                 continue
             if csr is not None and precision == 1 and sampling_step == 0:  # x_0 stays CSR: no dense [rows, I] operand is built
-                views = self.generate_views_bf16_csr(CsrRows(csr[0], csr[1], ub + int(csr[2])))
+                rows = CsrRows(csr[0], csr[1], ub + int(csr[2]))
+                views = self.generate_views_latent(rows=rows) if latent else self.generate_views_bf16_csr(rows)
                 for m in range(self.M):
                     ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
                 continue
             x0 = dense_rows(ub)
+            if latent:  # dense start: x_0 itself, or each modality's own noised x_T (drawn one at a time into a shared buffer)
+                starts = (self.noised_start(m, x0, sampling_step) for m in range(self.M)) if sampling_step else [x0] * self.M
+                views = self.generate_views_latent(xT=starts, B=x0.shape[0])
+                for m in range(self.M):
+                    ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
+                continue
             if precision == 1 and sampling_step == 0:
                 views = self.generate_views_bf16(x0)
                 for m in range(self.M):

@@ -179,7 +179,8 @@ def _gemm_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, *, trans_a: b
 
 def _bf16_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Optional[Tensor] = None, *, bias: Optional[Tensor] = None,
                act: int = L.ACT_NONE, alpha: float = 1.0, residual: Optional[Tensor] = None, e1: float = 1.0, e2: float = 1.0,
-               N: Optional[int] = None, K: Optional[int] = None, residual_bf16: Optional[Tensor] = None) -> "L.GemmBf16Args":
+               N: Optional[int] = None, K: Optional[int] = None, residual_bf16: Optional[Tensor] = None,
+               bias2: Optional[Tensor] = None) -> "L.GemmBf16Args":
     for nm, t in (("A", A), ("B", B)):
         if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
             raise ValueError(f"gemm_bf16_nt {nm}: need a 2-D bfloat16 tensor with unit inner stride")
@@ -201,6 +202,10 @@ def _bf16_args(A: Tensor, B: Tensor, out: Optional[Tensor] = None, out_bf16: Opt
         if bias.numel() < n:
             raise ValueError("gemm_bf16_nt bias too short")
         g.bias = L.ptr(_f32c(bias, "bias"))
+    if bias2 is not None:  # out_bf16 = tanh(out + bias2) instead of a copy of out (latent reverse chain)
+        if bias2.numel() < n or out is None or out_bf16 is None:
+            raise ValueError("gemm_bf16_nt bias2: needs both outputs and N entries")
+        g.bias2 = L.ptr(_f32c(bias2, "bias2"))
     if residual is not None:
         if residual.dtype != torch.float32 or residual.stride(1) != 1 or residual.shape[0] < m or residual.shape[1] < n:
             raise ValueError("gemm_bf16_nt residual: bad shape / dtype / stride")
@@ -244,6 +249,35 @@ def transpose_cast_bf16(src: Tensor, dst: Tensor, rows: Optional[int] = None, co
     if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] < cols or dst.stride(0) < rp:
         raise ValueError("transpose_cast_bf16: bad operands")
     L.call("dmm_transpose_cast_bf16", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), rows, cols, rp, L.stream())
+
+
+def cast_bf16_split(src: Tensor, hi: Tensor, lo: Tensor, cols: Optional[int] = None, cols_pad: Optional[int] = None) -> None:
+    """hi = bf16(src), lo = bf16(src - hi): together 16 mantissa bits of src (columns cols..cols_pad zero)."""
+    cols = src.shape[1] if cols is None else cols
+    cols_pad = cols if cols_pad is None else cols_pad
+    if src.dtype != torch.float32 or src.stride(1) != 1 or any(t.dtype != torch.bfloat16 or t.stride(1) != 1 or t.shape[0] < src.shape[0] for t in (hi, lo)) or \
+            hi.stride(0) != lo.stride(0):
+        raise ValueError("cast_bf16_split: bad operands")
+    L.call("dmm_cast_bf16_split", L.ptr(src), src.stride(0), L.ptr(hi), L.ptr(lo), hi.stride(0), src.shape[0], cols, cols_pad, L.stream())
+
+
+def transpose_cast_bf16_split(src: Tensor, hi: Tensor, lo: Tensor, rows: Optional[int] = None, cols: Optional[int] = None, rows_pad: Optional[int] = None) -> None:
+    """hi[c, r] = bf16(src[r, c]), lo[c, r] = bf16(src[r, c] - hi[c, r]); destination columns rows..rows_pad zeroed."""
+    rows = src.shape[0] if rows is None else rows
+    cols = src.shape[1] if cols is None else cols
+    rp = (rows + 7) & ~7 if rows_pad is None else rows_pad
+    if rp < rows or rp % 8 or src.dtype != torch.float32 or src.stride(1) != 1 or hi.stride(0) != lo.stride(0) or \
+            any(t.dtype != torch.bfloat16 or t.stride(1) != 1 or t.shape[0] < cols or t.stride(0) < rp for t in (hi, lo)):
+        raise ValueError("transpose_cast_bf16_split: bad operands")
+    L.call("dmm_transpose_cast_bf16_split", L.ptr(src), src.stride(0), L.ptr(hi), L.ptr(lo), hi.stride(0), rows, cols, rp, L.stream())
+
+
+def gemv_rows(W: Tensor, x: Tensor, out: Tensor, cols: Optional[int] = None) -> None:
+    """out[r] = sum_{c < cols} W[r, c] x[c] (fp32)."""
+    cols = W.shape[1] if cols is None else cols
+    if W.dtype != torch.float32 or W.stride(1) != 1 or cols > W.shape[1] or x.numel() < cols or out.numel() < W.shape[0]:
+        raise ValueError("gemv_rows: bad operands")
+    L.call("dmm_gemv_rows", L.ptr(W), W.stride(0), L.ptr(_f32c(x, "x")), L.ptr(_f32c(out, "out")), W.shape[0], cols, L.stream())
 
 
 def temb_bias_table(w_emb: Tensor, b_emb: Tensor, w1: Tensor, I: int, b1: Tensor, table: Tensor) -> None:
@@ -419,6 +453,17 @@ def csr_gather_sum_bf16(ptr: Tensor, col: Tensor, rows: Tensor, Wt: Tensor, bias
     if Wt.dtype != torch.bfloat16 or out16.dtype != torch.bfloat16 or Wt.stride(1) != 1 or out16.stride(1) != 1 or Wt.shape[1] < H or out16.shape[1] < H or out16.shape[0] < B:
         raise ValueError("csr_gather_sum_bf16: bad operands")
     L.call("dmm_csr_gather_sum_bf16", p, c, r, B, L.ptr(Wt), Wt.stride(0), L.ptr(_f32c(bias, "bias")), H, act, L.ptr(out16), out16.stride(0), L.stream())
+
+
+def csr_gather_sum_latent(ptr: Tensor, col: Tensor, rows: Tensor, Wt: Tensor, bias: Tensor, z: Tensor, out16: Tensor) -> None:
+    """z[b] = sum of the rows Wt[j] over user rows[b]'s items (fp32); out16[b] = bf16(tanh(z[b] + bias)).  Start of the latent chain."""
+    p, c, r, B = _csr_args(ptr, col, rows)
+    H = bias.numel()
+    if Wt.dtype != torch.bfloat16 or out16.dtype != torch.bfloat16 or Wt.stride(1) != 1 or out16.stride(1) != 1 or Wt.shape[1] < H or out16.shape[1] < H or \
+            out16.shape[0] < B or z.dtype != torch.float32 or z.stride(1) != 1 or z.shape[0] < B or z.shape[1] < H:
+        raise ValueError("csr_gather_sum_latent: bad operands")
+    L.call("dmm_csr_gather_sum_latent", p, c, r, B, L.ptr(Wt), Wt.stride(0), L.ptr(_f32c(bias, "bias")), H, L.ptr(z), z.stride(0), L.ptr(out16), out16.stride(0),
+           L.stream())
 
 
 def csr_add_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, c_: float, y: Optional[Tensor], y16: Optional[Tensor] = None) -> None:

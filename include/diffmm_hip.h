@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 200
+#define DMM_VERSION 201
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -141,6 +141,8 @@ typedef struct dmm_gemm_bf16_args {
   int32_t M, N, K;
   float alpha, e1, e2;
   int32_t act;
+  const float* bias2; /* [N] or NULL.  Non-NULL (needs C and Cb): Cb = tanh(C + bias2[n]) instead of a bf16 copy of C -- a step of the
+                       * latent reverse chain writes its fp32 state z' and the next step's layer-1 activation at once */
 } dmm_gemm_bf16_args;
 int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a /*host*/, void* stream);
 /* up to 4 problems of one shape in one launch (the modalities' large GEMMs go out together: enough tiles to fill the chip) */
@@ -148,6 +150,12 @@ int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* a /*host array*/, int n_b
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
 int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream);
+/* The same casts keeping what the rounding lost: lo = bf16(x - float(hi)), laid out like hi (hi + lo carries 16 mantissa bits).  Used once per
+ * epoch for the latent chain's G = W1x W2: hi*hi + lo*hi + hi*lo on the bf16 MFMA GEMM is fp32-grade before G's own rounding. */
+int dmm_cast_bf16_split(const float* src, int64_t lds, void* hi, void* lo, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
+int dmm_transpose_cast_bf16_split(const float* src, int64_t lds, void* hi, void* lo, int64_t ldd, int rows, int cols, int rows_pad, void* stream);
+/* out[r] = sum_c W[r, c] x[c], fp32 (the latent chain's g = W1x b2) */
+int dmm_gemv_rows(const float* W, int64_t ldw, const float* x, float* out, int rows, int cols, void* stream);
 /* table[t][h] = b1[h] + sum_c W1[h][I+c] * emb_layer(features(t))[c]: the layer-1 bias of chain step t (all rows share t), T x H */
 int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int te, const float* w1, int64_t ldw1, int I, const float* b1, int H,
                         int T, float* table, void* stream);
@@ -259,6 +267,10 @@ int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_
                             int act, void* out16, int64_t ldo, void* stream);
 int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float c, float* y, int64_t ldy, void* y16, int64_t ldy16,
                      void* stream);
+/* start of the latent reverse chain (GaussianDiffusion.p_sample with sampling_steps == 0, Model.py:300-322): z[b, :H] = sum_{j in
+ * items(rows[b])} Wt[j, :H] (fp32, = x_0 W1x^T) and out16 = bf16(tanh(z + bias)), the first step's layer-1 activation */
+int dmm_csr_gather_sum_latent(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias, int H,
+                              float* z, int64_t ldz, void* out16, int64_t ldo, void* stream);
 /* out[b, :I] = a_table[t_b] * x[b, :I] + c_table[t_b] * y[b, :I] (per-row timesteps): forward_cal_xt with explicit noise (Model.py:339-341)
  * and the posterior mean c1[t] * Denoise(x_t, t) + c2[t] * x_t of p_mean_variance (Model.py:375), for the reference-named Python API
  * (the training / rebuild engines fuse both into their GEMM operands and epilogues). */

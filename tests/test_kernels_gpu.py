@@ -753,6 +753,90 @@ def test_reverse_chains_on_streams_match_single_chain(dev):
         assert float((first[m] - wide[m]).abs().max()) < 1e-2 * float(wide[m].abs().max()), f"modality {m}: bf16 state vs fp32 state"
 
 
+def test_split_casts_and_gemv(dev):
+    """dmm_cast_bf16_split / dmm_transpose_cast_bf16_split: hi is the plain cast, hi + lo recovers the fp32 value to 2^-16 relative;
+    dmm_gemv_rows against fp64."""
+    from diffmm_amd import ops
+    torch.manual_seed(3)
+    R, Cc, ld = 70, 100, 104
+    x = torch.randn(R, ld, device=dev)
+    hi, lo = torch.full((R, ld), 7.0, device=dev, dtype=torch.bfloat16), torch.full((R, ld), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.cast_bf16_split(x, hi, lo, cols=Cc, cols_pad=ld)
+    assert torch.equal(hi[:, :Cc], x[:, :Cc].bfloat16()) and float(hi[:, Cc:].abs().max()) == 0.0 and float(lo[:, Cc:].abs().max()) == 0.0
+    err = (hi.float() + lo.float() - x)[:, :Cc].abs() / x[:, :Cc].abs().clamp_min(1e-20)
+    assert float(err.max()) < 2.0 ** -15
+    Rp = 72
+    thi, tlo = torch.full((Cc, Rp), 7.0, device=dev, dtype=torch.bfloat16), torch.full((Cc, Rp), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.transpose_cast_bf16_split(x, thi, tlo, rows=R, cols=Cc, rows_pad=Rp)
+    assert torch.equal(thi[:, :R], x[:, :Cc].t().bfloat16()) and float(thi[:, R:].abs().max()) == 0.0 and float(tlo[:, R:].abs().max()) == 0.0
+    assert torch.equal(tlo[:, :R], lo[:, :Cc].t())
+    v, out = torch.randn(Cc, device=dev), torch.zeros(R, device=dev)
+    ops.gemv_rows(x, v, out, cols=Cc)
+    close(out, x[:, :Cc].double() @ v.double(), rtol=1e-5, atol=1e-5, what="gemv_rows")
+
+
+def test_latent_chain_matches_stepwise_chain(dev):
+    """generate_views_latent (the reverse chain carried as z_t = x_t W1x^T: T - 1 GEMMs of [B, H] x [H, H] and one item-sized GEMM)
+    against the stepwise chains it replaces and against the reference's vectors:
+      * synthetic weights, M = 3: latent vs the ~fp32 stepwise chain (precision 3) -- and no further from it than the stepwise bf16
+        chain is (the latent state is fp32; the stepwise state is re-rounded to bf16 every step);
+      * CSR start (gather of W1^T rows) vs dense start (layer-1 GEMM): the same products in another summation order;
+      * bit-identical from call to call (recorded plan, static buffers);
+      * Denoise with 1, 2 and 3 hidden widths against the reference's generate_view output (tests/golden);
+      * the rebuilt edges (per-user top-k): the latent chain reproduces the ~fp32 chain's edges at least as well as the stepwise bf16 chain."""
+    from diffmm_amd import synth
+    from diffmm_amd.DataHandler import DiffusionData
+    from diffmm_amd.engine import DiffusionEngine
+    torch.manual_seed(21)
+    g = synth.named("mid")
+    U, I, D, H, M, T_, B = g.users, g.items, 64, 1024, 3, 9, 300
+    hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3, seed=5)
+    E = DiffusionEngine(I, D, H, 10, M, T_, hp, dev, B)
+    assert E._latent_mode() and float(E.c2[0]) == 0.0
+    for m in range(M):
+        E.P[m].data.normal_(0, 0.04)
+        E.P[m].view("in_layers.0.weight")[:, I + 10:].zero_()
+    dd = DiffusionData(g.trn_rows, g.trn_cols, U, I, dev)
+    users = torch.randperm(U, device=dev)[:B]
+    x0 = dd.rows(users)
+    lat = [v.clone() for v in E.generate_views_latent(xT=[x0] * M, B=B)]
+    again = E.generate_views_latent(xT=[x0] * M, B=B)
+    assert all(torch.equal(lat[m], again[m]) for m in range(M)), "latent chain reproducible"
+    sparse = [v.clone() for v in E.generate_views_latent(rows=dd.csr_rows(users))]
+    E.hp["chain_state"] = "bf16"
+    step16 = [v.clone() for v in E.generate_views_bf16(x0)]
+    for m in range(M):
+        exact = E.generate_view(m, x0, precision=3)
+        scale = float(exact.abs().max())
+        e_lat, e_step = float((lat[m] - exact).abs().max()) / scale, float((step16[m] - exact).abs().max()) / scale
+        assert e_lat < 2e-2, f"modality {m}: latent chain vs fp32 stepwise chain: {e_lat:.3e} of the output scale"
+        assert e_lat < 1.5 * e_step + 1e-3, f"modality {m}: latent {e_lat:.3e} vs stepwise bf16 {e_step:.3e}"
+        assert float((sparse[m] - lat[m]).abs().max()) < 2e-3 * scale, f"modality {m}: CSR start vs dense start"
+        one = E.generate_view(m, x0, precision=1)  # the single-modality surface takes the latent chain too
+        assert float((one - lat[m]).abs().max()) < 2e-3 * scale, f"modality {m}: single-modality latent chain"
+    ptr32 = dd.deg_ptr32
+    e_lat = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1, csr=(dd.ptr, dd.col32, 0))
+    E.hp["chain_mode"] = "stepwise"
+    assert not E._latent_mode()
+    e_step = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1, csr=(dd.ptr, dd.col32, 0))
+    e_exact = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=3)  # ~fp32 stepwise chain: the reference's arithmetic
+    for m in range(M):  # (random weights: scores are dense in near-ties, so a few per cent of the ranked slots differ for either bf16 chain)
+        a_lat, a_step = float((e_lat[m] == e_exact[m]).float().mean()), float((e_step[m] == e_exact[m]).float().mean())
+        print(f"modality {m}: edges equal to the fp32 chain's: latent {a_lat:.4f}, stepwise bf16 {a_step:.4f}")
+        assert a_lat > 0.95 and a_lat > a_step - 0.01, f"modality {m}: latent {a_lat:.4f} vs stepwise {a_step:.4f} of the fp32 chain's edges"
+    for name in ("toy", "mid", "mid_deep", "mid_deep3"):
+        z = load(f"diffusion_{name}.npz")
+        dims = [int(x) for x in z["dims"]] if "dims" in z.files else [int(z["H"])]
+        Eg = DiffusionEngine(int(z["items"]), int(z["d"]), int(z["H"]), 10, 1, int(z["T"]),
+                             dict(noise_scale=float(z["noise_scale"]), noise_min=0.0001, noise_max=0.02, sim_weight=float(z["sim_weight"]), reg=float(z["reg"]), lr=1e-3),
+                             dev, int(z["B"]), hidden=dims)
+        Eg.load_reference_state(0, {k[2:]: z[k] for k in z.files if k.startswith("p/")})
+        gv = Eg.generate_views_latent(xT=[T(z["x0"]).to(dev)], B=int(z["B"]))[0]
+        gscale = float(np.abs(z["genview/out"]).max())
+        err = float((gv.cpu() - T(z["genview/out"])).abs().max()) / gscale
+        assert err < 3e-2, f"{name}: latent chain vs the reference's generate_view: {err:.3e} of the output scale"
+
+
 def test_csr_rows_equal_the_dense_path(dev):
     """x_0 as CSR rows (the I = 1e6 configuration cannot hold dense user rows): dmm_csr_dense_rows against the index
     arithmetic it replaces; a training step fed CSR rows against the same step fed the dense rows (the same operand buffer);
