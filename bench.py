@@ -31,6 +31,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+PMC_CHAIN_JSON = "r2c_pmc_chain_gemm.json"  # committed PMC summary of tools/roofline_target.py (tools/final_profile.sh)
 
 
 def make_coach(args, rank: int, world: int):
@@ -61,60 +62,98 @@ def timed_launches(fn, n: int) -> float:
 
 
 def roofline(coach, args):
-    """Live measurement of the two kernels that bound the epoch: the Denoise layer-1 GEMM (MFMA bound; the reverse
-    chain issues it T * batches * modalities times per epoch) and the CSR SpMM (HBM bound; north_star's figure)."""
+    """Live measurement of the kernels that bound the epoch (HIP events on the launch stream, operands as the epoch has them):
+      * the latent reverse-chain step -- the dominant kernel of the epoch: (T - 1) launches per rebuild, all modalities and
+        all users per launch; [rows, H] x [H, H] bf16 MFMA GEMM whose epilogue streams the fp32 state z in and out and writes the next
+        activation in bf16: 12 bytes per element against 2 H flops -> HBM-bound (58.6 GFLOP = 23 us of MFMA vs 349 MB = 44 us of HBM);
+      * the item-sized GEMM that remains per chain (last step, h_0 W2^T -> fp32 view for the top-k; MFMA-bound) and, for reference, the
+        stepwise chain's layer 1 (what every chain step cost before the latent form; still the chain for DMM_CHAIN_MODE=stepwise);
+      * the CSR SpMM (HBM bound; north_star's figure)."""
     from diffmm_amd import ops, _lib as L
     DE, J = coach.diff_engine, coach.model.engine
     B, H, I, Kp = args.batch, DE.H, DE.I, DE.Kp
     P = DE.P[0]
-    x, h = DE.xa[:B], DE.dh[:B]
-    x.normal_()
-    rows, nb = B, 1
-    if args.precision == 1:  # the launches the reverse chain really issues: all modalities batched, all users (chain_rows), random operands
-        M = DE.M
-        rows, nb = min(DE.chain_rows, coach.handler.graph.users), M
-        for m in range(M):
-            DE._refresh_bf16_weights(m)
-            DE.cxa[m][:rows].normal_()
-            ops.cast_bf16(DE.cxa[m][:rows], DE.cxa16[m][:rows])
-        t1 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.cxa16[m][:rows], B=DE.w1_16[m], out_bf16=DE.ch16[m][:rows], bias=DE.bias_t[m][0],
-                                                                   act=L.ACT_TANH) for m in range(M)]), 10)
-        # layer 2 exactly as the chain issues it (an inner step: i = 1 -- the running x_t in bf16 by default, DiffusionEngine._bf16_state)
-        t2 = timed_launches(lambda: ops.gemm_bf16_nt_batched([DE._chain_layer2_args(m, 1, DE.ch16[m][:rows], DE.cxa[m][:rows], DE.cxa16[m][:rows],
-                                                                                    DE.cxb[m][:rows], DE.cxb16[m][:rows]) for m in range(M)]), 10)
-    else:
-        t1 = timed_launches(lambda: ops.gemm(x, P.view("in_layers.0.weight"), out=h, trans_b=True, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH,
-                                             precision=args.precision), 20)
-        t2 = timed_launches(lambda: ops.gemm(h, P.view("out_layers.0.weight"), out=DE.xb[:B], trans_b=True, bias=P.view("out_layers.0.bias"),
-                                             precision=args.precision, N=I, residual=x, e1=0.5, e2=0.5), 20)
-    flops1 = 2.0 * rows * nb * Kp * H * (3 if args.precision == 3 else 1)
-    flops2 = 2.0 * rows * nb * H * I * (3 if args.precision == 3 else 1)
     A = J.adj
     emb = J.P.view("emb")
     with L.Recorder() as spmm_plan:  # pre-marshalled launch, like the engines' steady state: the timed loop is kernel time, not Python
         ops.spmm_batched([ops.SpmmOp(A, emb, y=J.Bx)])
     ts = timed_launches(lambda: L.replay(spmm_plan), 200)
     sb = A.algorithmic_bytes(4)
-    gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_8ph_kernel (256x256 LDS-DMA tile): Denoise layer 1 of the reverse chain, {nb} modalities x ({rows} x {Kp}) x ({H} x {Kp})^T per launch", "achieved": flops1 / t1 / 1e12, "peak": MFMA_BF16_PEAK_TF,
-            "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6,
-            "layer2_tflops": flops2 / t2 / 1e12, "layer2_avg_launch_us": t2 * 1e6, "layer2_state": "bf16" if DE._bf16_state() else "fp32"}
     spmm = {"bound": "hbm", "kernel": "spmm_kernel<64> base adjacency", "achieved": sb / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": sb / ts / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": ts * 1e6, "algorithmic_bytes": sb}
+    if args.precision != 1:  # ~fp32 mode: the stepwise chain on the split-precision GEMM
+        x, h = DE.xa[:B], DE.dh[:B]
+        x.normal_()
+        t1 = timed_launches(lambda: ops.gemm(x, P.view("in_layers.0.weight"), out=h, trans_b=True, bias=P.view("in_layers.0.bias"), act=L.ACT_TANH,
+                                             precision=args.precision), 20)
+        flops1 = 2.0 * B * Kp * H * 3
+        gemm = {"bound": "mfma", "kernel": "gemm_kernel (bf16 hi/lo split, 3 MFMA products per element): Denoise layer 1", "achieved": flops1 / t1 / 1e12,
+                "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": t1 * 1e6}
+        return gemm, spmm, None
+    M = DE.M
+    rows = min(DE.chain_rows, coach.handler.graph.users)
+    DE._latent_alloc()
+    lat = DE._lat
+    for m in range(M):
+        DE._refresh_bf16_weights(m)
+        lat["za"][m][:rows].normal_()
+        DE.cxa[m][:rows].normal_()
+        ops.cast_bf16(DE.cxa[m][:rows], DE.cxa16[m][:rows])
+        ops.cast_bf16(lat["za"][m][:rows], DE.ch16[m][:rows])
+    i_mid = max(1, DE.T // 2)
+    tl = timed_launches(lambda: ops.gemm_bf16_nt_batched([DE._latent_step_args(m, i_mid, DE.ch16[m][:rows], lat["za"][m][:rows], lat["zb"][m][:rows],
+                                                                               lat["hb"][m][:rows]) for m in range(M)]), 20)
+    lat_bytes = M * (rows * H * (4 + 4 + 2 + 2) + H * H * 2)  # z in + z out (fp32), h in + h out (bf16), G (bf16); biases negligible
+    lat_flops = 2.0 * rows * M * H * H
+    # the item-sized GEMMs: the chain's last step as the chain issues it, and the stepwise chain's layer 1 for reference
+    t2 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.ch16[m][:rows], B=DE.w2_16[m], out=DE.cxa[m][:rows], bias=lat["b2_last"][m],
+                                                               alpha=float(DE.c1[0]), N=I) for m in range(M)]), 10)
+    for m in range(M):
+        DE.cxa[m][:rows].normal_()
+    t1 = timed_launches(lambda: ops.gemm_bf16_nt_batched([dict(A=DE.cxa16[m][:rows], B=DE.w1_16[m], out_bf16=DE.ch16[m][:rows], bias=DE.bias_t[m][0],
+                                                               act=L.ACT_TANH) for m in range(M)]), 10)
+    flops1, flops2 = 2.0 * rows * M * Kp * H, 2.0 * rows * M * H * I
+    # the chain as the epoch runs it: all T - 1 steps in the persistent kernel (z in registers; per step each workgroup writes its h tile and
+    # re-reads the row block from its XCD's L2).  Algorithmic HBM bytes: z_T in, h in / out once -- the kernel is MFMA-bound.
+    T = DE.T
+    fused = DE._latent_fused()
+    if fused:
+        tc = timed_launches(lambda: ops.latent_chain([dict(G=lat["G16"][m], g=lat["g"][m], z=lat["za"][m][:rows], h_a=DE.ch16[m][:rows], h_b=lat["hb"][m][:rows],
+                                                           bias_t=DE.bias_t[m]) for m in range(M)], rows=rows, T=T, coef=lat["coef"], s_init=lat["s_init"],
+                                                     flags=lat["flags"]), 5)
+        DE.check_chain_error()
+        chain_flops = (T - 1) * lat_flops
+        step = {"bound": "mfma", "kernel": f"latent_chain_8ph_kernel (persistent 256x256 LDS-DMA tiles, z in registers, group barrier per step): {T - 1} steps of "
+                                           f"{M} modalities x ({rows} x {H}) x ({H} x {H})^T per rebuild", "achieved": chain_flops / tc / 1e12, "peak": MFMA_BF16_PEAK_TF,
+                "unit": "TFLOP/s", "frac": chain_flops / tc / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_us": tc * 1e6, "us_per_step": tc * 1e6 / (T - 1),
+                "launches_per_call": -(-(M * -(-rows // 256)) // max(8, (256 // (H // 256)) & ~7)),
+                "per_step_launch_us": tl * 1e6, "per_step_launch_GBps": lat_bytes / tl / 1e9, "per_step_launch_hbm_frac": lat_bytes / tl / 1e9 / HBM_PEAK_GBS,
+                "note": f"one launch per step (DMM_LATENT_FUSED=0, gemm_bf16_nt_8ph_kernel<9>) is HBM-bound: {lat_bytes / 1e6:.0f} MB per step, fp32 z in and out"}
+    else:
+        step = {"bound": "hbm", "kernel": f"gemm_bf16_nt_8ph_kernel<9> (256x256 LDS-DMA tile, latent-chain epilogue): {M} modalities x ({rows} x {H}) x ({H} x {H})^T per launch, "
+                                          f"{T - 1} launches per rebuild", "achieved": lat_bytes / tl / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": lat_bytes / tl / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tl * 1e6, "algorithmic_bytes": lat_bytes,
+                "tflops": lat_flops / tl / 1e12, "mfma_frac": lat_flops / tl / 1e12 / MFMA_BF16_PEAK_TF}
+    gemm = {"bound": "mfma", "kernel": f"gemm_bf16_nt_8ph_kernel<6>: last chain step h_0 W2^T -> fp32 view, {M} modalities x ({rows} x {H}) x ({I} x {H})^T, once per rebuild",
+            "achieved": flops2 / t2 / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops2 / t2 / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None,
+            "avg_launch_us": t2 * 1e6, "stepwise_layer1_tflops": flops1 / t1 / 1e12, "stepwise_layer1_avg_launch_us": t1 * 1e6,
+            "stepwise_layer1_frac": flops1 / t1 / 1e12 / MFMA_BF16_PEAK_TF}
     try:  # fabric-side traffic per launch from the committed PMC passes (profiles/README.md); bench.py itself cannot run rocprofv3
-        if args.precision == 1 and args.batch == 4096 and args.workload == "tiktok" and nb == 3:
+        if args.batch == 4096 and args.workload == "tiktok" and M == 3:
             pmc = json.load(open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")))
             spmm["traffic"] = pmc["spmm_kernel_64"]["traffic_bytes"]
-            chain = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_chain_gemm.json")))
-            l1, l2 = chain["layer1_tanh_bf16"], chain["layer2_bf16_state" if DE._bf16_state() else "layer2_fp32_state"]
-            gemm["traffic"] = l1["traffic_bytes"]
-            gemm["traffic_source"] = "profiles/r2_pmc_chain_gemm.json (committed rocprofv3 --pmc passes of tools/roofline_target.py; bench.py cannot run a PMC pass on itself)"
             spmm["traffic_source"] = "profiles/r1_pmc_traffic.json (committed rocprofv3 --pmc passes of this launch)"
-            gemm["traffic_note"] = (f"layer 1: {l1['traffic_bytes'] / 1e6:.0f} MB fabric-side per launch vs {l1['algorithmic_bytes'] / 1e6:.0f} MB of operands + output "
-                                    f"(L2 hit rate {l1['l2_hit_rate']:.0%}, MFMA pipe busy {l1['mfma_busy']:.0%}); layer 2 ({gemm['layer2_state']} state): "
-                                    f"{l2['traffic_bytes'] / 1e6:.0f} MB vs {l2['algorithmic_bytes'] / 1e6:.0f} MB (L2 hit rate {l2['l2_hit_rate']:.0%}, MFMA pipe busy {l2['mfma_busy']:.0%})")
+            chain = json.load(open(os.path.join(REPO, "profiles", PMC_CHAIN_JSON)))
+            src = f"profiles/{PMC_CHAIN_JSON} (committed rocprofv3 --pmc passes of tools/roofline_target.py; bench.py cannot run a PMC pass on itself)"
+            for obj, key in ((step, "latent_chain" if fused else "latent_step"), (gemm, "last_step_fp32_out")):
+                if key in chain:
+                    e = chain[key]
+                    obj["traffic"], obj["traffic_source"] = e["traffic_bytes"], src
+                    obj["traffic_note"] = (f"{e['traffic_bytes'] / 1e6:.0f} MB fabric-side per launch vs {e['algorithmic_bytes'] / 1e6:.0f} MB algorithmic "
+                                           f"(L2 hit rate {e.get('l2_hit_rate', float('nan')):.0%}, MFMA pipe busy {e.get('mfma_busy', float('nan')):.0%})")
     except Exception:
         pass
-    return gemm, spmm
+    return step, spmm, gemm
 
 
 def roofline_spmm_shard(users: int = 1_000_000, items: int = 500_000, D: int = 64):
@@ -284,8 +323,10 @@ def main():
     if replicas_identical is not None:
         out["replicated_params_identical"] = replicas_identical
     if not args.no_roofline:
-        g, s = roofline(coach, args)
+        g, s, g2 = roofline(coach, args)
         out["roofline"], out["roofline_spmm"] = g, s
+        if g2 is not None:
+            out["roofline_item_gemm"] = g2
         if world == 1 and not args.no_shard_roofline and args.workload == "tiktok":
             out["roofline_spmm_shard"] = roofline_spmm_shard()
     if world == 1 and args.precision == 1 and not args.no_fp32_like:  # the same epochs in split-bf16 (~fp32) arithmetic, next to the bf16 headline

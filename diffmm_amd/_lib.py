@@ -41,6 +41,11 @@ class GemmBf16Args(C.Structure):
                 ("act", C.c_int32), ("bias2", C.c_void_p)]
 
 
+class LatentChainArgs(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("ldg", C.c_int64), ("g", C.c_void_p), ("z", C.c_void_p), ("ldz", C.c_int64), ("h_a", C.c_void_p), ("h_b", C.c_void_p),
+                ("ldh", C.c_int64), ("bias_t", C.c_void_p), ("ldbt", C.c_int64)]
+
+
 class GatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("grad", C.c_void_p)]
 
@@ -64,6 +69,7 @@ _SIGS = {
     "dmm_gemm_batched": (C.c_int, [C.POINTER(GemmArgs), _I, _P]),
     "dmm_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmBf16Args), _P]),
     "dmm_gemm_bf16_nt_batched": (C.c_int, [C.POINTER(GemmBf16Args), _I, _P]),
+    "dmm_latent_chain": (C.c_int, [C.POINTER(LatentChainArgs), _I, _I, _I, _I, _P, C.c_float, _P, _I, _P]),
     "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_transpose_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_cast_bf16_split": (C.c_int, [_P, _L, _P, _P, _L, _I, _I, _I, _P]),

@@ -26,6 +26,10 @@
 //   WAR: a unit read in phase p is refilled in phase p+2 or later (the other row's reads of phase p retire one barrier later).
 // Loads past the last K tile are still issued (clamped to the last tile, into units nobody reads any more) so the counts stay
 // constant; everything is drained before the epilogue reuses LDS.
+#include <string.h>
+
+#include <algorithm>
+
 #include "gemm_bf16.h"
 
 namespace dmm {
@@ -158,7 +162,11 @@ __device__ __forceinline__ void p8_ld_res_edge(const char* p, int nv, u32x2& r) 
 }
 
 // B2 (the latent reverse chain): the bf16 output is not a copy of C but the NEXT layer's activation tanh(C + bias2[n]).
-template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2>
+__device__ __forceinline__ void p8_st_keep(__bf16* p, const float (&v)[4]) {  // plain store: the line is meant to be re-read from L2
+  const bf16x4 b = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *reinterpret_cast<u32x2*>(p) = __builtin_bit_cast(u32x2, b);
+}
+template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2, bool KEEP = false>
 __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float4& c4, const char*& pR, long long rs,
                                              float*& pC, __bf16*& pCb, const typename P8Res<RK>::type (&rcur)[8], typename P8Res<RK>::type (&rnext)[8],
                                              int mrow, int nv) {
@@ -190,11 +198,11 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
     if (B2) { w[0] = tanh_fast_bf16(v[0] + c4.x); w[1] = tanh_fast_bf16(v[1] + c4.y); w[2] = tanh_fast_bf16(v[2] + c4.z); w[3] = tanh_fast_bf16(v[3] + c4.w); }
     if (!EDGE) {
       if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-      if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w);
+      if (HAS_CB) { if (KEEP) p8_st_keep(pCb + (long long)(it * 4) * E.ldcb, w); else p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w); }
     } else if (mrow + PASS * 32 + it * 4 < E.M && nv > 0) {
       if (nv == 4) {
         if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-        if (HAS_CB) p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w);
+        if (HAS_CB) { if (KEEP) p8_st_keep(pCb + (long long)(it * 4) * E.ldcb, w); else p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w); }
       } else {
         if (HAS_C) p8_st_edge(pC + (long long)(it * 4) * E.ldc, v, nv);
         if (HAS_CB) p8_st_edge(pCb + (long long)(it * 4) * E.ldcb, w, nv);
@@ -208,7 +216,7 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
   if (HAS_CB) pCb += 32 * E.ldcb;
 }
 
-template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2 = false>
+template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2 = false, bool KEEP = false>
 __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
   constexpr bool HAS_R = RK != 0;
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
@@ -240,10 +248,10 @@ __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& ac
       }
     }
   }
-  p8_fast_pass<0, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
-  p8_fast_pass<1, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
-  p8_fast_pass<2, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, rc, rb, mrow, nv);
-  p8_fast_pass<3, RK, HAS_C, HAS_CB, ACT, EDGE, B2>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, ra, rb, mrow, nv);
+  p8_fast_pass<0, RK, HAS_C, HAS_CB, ACT, EDGE, B2, KEEP>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, ra, rc, mrow, nv);  // uses ra, requests pass 2 into rc
+  p8_fast_pass<1, RK, HAS_C, HAS_CB, ACT, EDGE, B2, KEEP>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, rb, ra, mrow, nv);  // uses rb, requests pass 3 into ra
+  p8_fast_pass<2, RK, HAS_C, HAS_CB, ACT, EDGE, B2, KEEP>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, rc, rb, mrow, nv);
+  p8_fast_pass<3, RK, HAS_C, HAS_CB, ACT, EDGE, B2, KEEP>(E, acc, tile, q, fr, b4, c4, pR, rs, pC, pCb, ra, rb, mrow, nv);
 }
 
 // Edge tiles, unaligned operands and the rarely used operand combinations: bounds-checked, element-wise where needed.
@@ -357,6 +365,71 @@ __device__ unsigned long long p8_stamps[8 * 8192];
 #define P8_STAMP(i)
 #endif
 
+// The K loop of one 256 x 256 tile: LDS-DMA prologue, nk K tiles of 4 phases, drain.  On return every LDS-DMA has landed and every fragment
+// read is done (LDS is free) and the wave rows are re-aligned.  acc is accumulated into (the caller initialises it).
+template <bool STAMP>
+__device__ __forceinline__ void p8_main_loop(P8Acc& acc, const __bf16* const (&offX)[2][2], const __bf16* const (&offY)[2][2], int nk, char* smem, int wave,
+                                             int wr, int wc, const int (&lo)[2]) {
+  [[maybe_unused]] const int lane = threadIdx.x & 63;  // (P8_STAMP)
+  auto issue = [&](const __bf16* const (&src)[2], int kt, char* unit) {
+    const int k0 = (kt < nk ? kt : nk - 1) * 64;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[0] + k0), (lds_ptr_t)(unit + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[1] + k0), (lds_ptr_t)(unit + (wave + 8) * 1024), 16, 0, 0);
+  };
+  char* const buf0 = smem;
+  char* const buf1 = smem + 4 * P8_UNIT;
+  constexpr int X0 = 0, X1 = P8_UNIT, Y0 = 2 * P8_UNIT, Y1 = 3 * P8_UNIT;
+  // prologue: the issue sequence up to (not including) phase 0 of tile 0
+  issue(offX[0], 0, buf0 + X0);
+  issue(offY[0], 0, buf0 + Y0);
+  issue(offY[1], 0, buf0 + Y1);
+  issue(offX[1], 0, buf0 + X1);
+  issue(offX[0], 1, buf1 + X0);
+  issue(offY[0], 1, buf1 + Y0);
+  P8_VMCNT8();   // X0(0), Y0(0) have landed (this wave's part)
+  P8_BARRIER();  // ... every wave's part
+  if (STAMP && threadIdx.x < 64) { P8_STAMP(1); }
+  if (wr == 1) P8_BARRIER();  // row 1 runs one barrier behind row 0 from here on
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  for (int t = 0; t < nk; ++t) {
+    char* const cur = (t & 1) ? buf1 : buf0;
+    char* const oth = (t & 1) ? buf0 : buf1;
+    // ---- phase 0
+    p8_read_b(fb0, cur + Y0, wc, lo);
+    p8_read_a(fa, cur + X0, wr, lo);
+    issue(offY[1], t + 1, oth + Y1);
+    P8_VMCNT8();
+    P8_BARRIER();
+    P8_LGKM0();
+    p8_mma<0, 0>(acc, fa, fb0);
+    P8_BARRIER();
+    // ---- phase 1
+    p8_read_b(fb1, cur + Y1, wc, lo);
+    issue(offX[1], t + 1, oth + X1);
+    P8_VMCNT8();
+    P8_BARRIER();
+    P8_LGKM0();
+    p8_mma<0, 1>(acc, fa, fb1);
+    P8_BARRIER();
+    // ---- phase 2
+    p8_read_a(fa, cur + X1, wr, lo);
+    issue(offX[0], t + 2, cur + X0);
+    P8_BARRIER();
+    P8_LGKM0();
+    p8_mma<1, 1>(acc, fa, fb1);
+    P8_BARRIER();
+    // ---- phase 3
+    issue(offY[0], t + 2, cur + Y0);
+    P8_VMCNT8();
+    P8_BARRIER();
+    p8_mma<1, 0>(acc, fa, fb0);
+    P8_BARRIER();
+  }
+  if (wr == 0) P8_BARRIER();  // row 0 waits for row 1's last phase
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every LDS-DMA landed, every read done: LDS is free
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Batch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -404,11 +477,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
       offY[h][i] = P.B + (long long)(rb < P.N ? rb : P.N - 1) * P.ldb + cs;
     }
   }
-  auto issue = [&](const __bf16* const (&src)[2], int kt, char* unit) {
-    const int k0 = (kt < nk ? kt : nk - 1) * 64;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[0] + k0), (lds_ptr_t)(unit + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[1] + k0), (lds_ptr_t)(unit + (wave + 8) * 1024), 16, 0, 0);
-  };
   // ---- fragment read offsets inside a unit (the row-dependent swizzle term depends only on the lane: rows step by 16)
   int lo[2];
   {
@@ -427,58 +495,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc.v[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  char* const buf0 = smem;
-  char* const buf1 = smem + 4 * P8_UNIT;
-  constexpr int X0 = 0, X1 = P8_UNIT, Y0 = 2 * P8_UNIT, Y1 = 3 * P8_UNIT;
-  // prologue: the issue sequence up to (not including) phase 0 of tile 0
-  issue(offX[0], 0, buf0 + X0);
-  issue(offY[0], 0, buf0 + Y0);
-  issue(offY[1], 0, buf0 + Y1);
-  issue(offX[1], 0, buf0 + X1);
-  issue(offX[0], 1, buf1 + X0);
-  issue(offY[0], 1, buf1 + Y0);
-  P8_VMCNT8();   // X0(0), Y0(0) have landed (this wave's part)
-  P8_BARRIER();  // ... every wave's part
-  if (threadIdx.x < 64) { P8_STAMP(1); }
-  if (wr == 1) P8_BARRIER();  // row 1 runs one barrier behind row 0 from here on
-
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-  for (int t = 0; t < nk; ++t) {
-    char* const cur = (t & 1) ? buf1 : buf0;
-    char* const oth = (t & 1) ? buf0 : buf1;
-    // ---- phase 0
-    p8_read_b(fb0, cur + Y0, wc, lo);
-    p8_read_a(fa, cur + X0, wr, lo);
-    issue(offY[1], t + 1, oth + Y1);
-    P8_VMCNT8();
-    P8_BARRIER();
-    P8_LGKM0();
-    p8_mma<0, 0>(acc, fa, fb0);
-    P8_BARRIER();
-    // ---- phase 1
-    p8_read_b(fb1, cur + Y1, wc, lo);
-    issue(offX[1], t + 1, oth + X1);
-    P8_VMCNT8();
-    P8_BARRIER();
-    P8_LGKM0();
-    p8_mma<0, 1>(acc, fa, fb1);
-    P8_BARRIER();
-    // ---- phase 2
-    p8_read_a(fa, cur + X1, wr, lo);
-    issue(offX[0], t + 2, cur + X0);
-    P8_BARRIER();
-    P8_LGKM0();
-    p8_mma<1, 1>(acc, fa, fb1);
-    P8_BARRIER();
-    // ---- phase 3
-    issue(offY[0], t + 2, cur + Y0);
-    P8_VMCNT8();
-    P8_BARRIER();
-    p8_mma<1, 0>(acc, fa, fb0);
-    P8_BARRIER();
-  }
-  if (wr == 0) P8_BARRIER();  // row 0 waits for row 1's last phase
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every LDS-DMA landed, every read done: LDS is free
+  p8_main_loop<true>(acc, offX, offY, nk, smem, wave, wr, wc, lo);
   if (threadIdx.x < 64) { P8_STAMP(2); }
   p8_epilogue<EPI>(P, acc, smem, m0, n0, wave, lane);
   if (threadIdx.x < 64) { P8_STAMP(3); }
@@ -486,6 +503,167 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x < 64) { P8_STAMP(4); }
 #endif
+}
+
+// ---- latent reverse chain: all T - 1 steps of  z' = c2 z + c1 (h G^T + g),  h' = tanh(z' + bias_t)  in ONE launch -------------------------------
+// A step launched on its own (EPI_LATENT) is bound by streaming the fp32 state z through HBM: 8 of its 12 bytes per element.  Here a workgroup keeps its
+// 256 x 256 tile of z in the accumulator registers for the whole chain (as a = z / c1: the MFMAs of a step accumulate h G^T straight onto
+// a_init = (c2 / c1) z + g, and the next step's a_init is one FMA per register) -- z never touches memory again.  What a step still exchanges is h: the
+// H / 256 workgroups that share a row block (a "group") each write their 256 columns of h' (bf16) and read the whole row block back as the next A
+// operand, so a step ends in a group barrier: release fence, one atomic per workgroup on the group's counter, a BOUNDED spin (a partner that never
+// arrives -- it cannot, see below -- sets the error word instead of hanging the GPU), acquire fence.
+// Placement: workgroup b belongs to group 8 (b / 8 / nt) + b % 8 -- the members of a group are nt CONSECUTIVE workgroups of one XCD's dispatch queue
+// (workgroups are dealt round-robin over the 8 XCDs), so they share that XCD's L2 (h' is re-read from it) and, dispatch being in order per XCD, the
+// earliest unfinished group of an XCD always has all its members resident: no wait can be circular.  The host launches at most CUs / nt groups at a time.
+struct LatentP {
+  const __bf16* G; long long ldg;   // [H, H]
+  const float* g;                   // [H]
+  const float* z; long long ldz;    // [rows, H] fp32: z_T, read once
+  __bf16* ha; __bf16* hb; long long ldh;  // [rows, H] bf16 ping-pong: ha holds h_{T-1} on entry
+  const float* bias_t; long long ldbt;    // [T, H]
+};
+struct LatentBatch {
+  LatentP p[GB_MAX_BATCH];
+  const float* coef;  // [2 T]: coef[2 i] = c1[i] (h' = tanh(c1[i] a + bias_t[i - 1])), coef[2 i + 1] = c2[i - 1] c1[i] / c1[i - 1] (a <- that * a + g)
+  int* flags;         // [n_groups] counters (zero on entry), flags[err_at] = error word
+  float s_init;       // c2[T - 1] / c1[T - 1]
+  int rows, H, T, rbs, g0, n_groups, err_at;
+};
+constexpr int LATENT_SPIN_MAX = 1 << 22;  // x (s_sleep(2) + an L2 round trip, ~0.3 us): about a second, then give up (the step kernel path takes a few ms in total)
+
+__global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch Lb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = Lb.H >> 8;
+  const int slot = blockIdx.x >> 3;
+  const int gl = (slot / nt) * 8 + (blockIdx.x & 7);
+  if (gl >= Lb.n_groups) return;  // (uniform over the workgroup; such workgroups belong to no group)
+  const int group = Lb.g0 + gl;
+  const LatentP& P = Lb.p[group / Lb.rbs];
+  const int m0 = (group % Lb.rbs) * 256, n0 = (slot % nt) * 256;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
+  const int nk = Lb.H / 64, rows = Lb.rows, T = Lb.T;
+  const float* const coef = Lb.coef;
+  const float* const bias_t = P.bias_t;
+  const long long ldbt = P.ldbt, ldh = P.ldh;
+  __bf16* const hbuf[2] = {P.ha, P.hb};
+  int* const flag = Lb.flags + gl;
+  int* const err = Lb.flags + Lb.err_at;
+
+  const __bf16* offA[2][2];  // [unit][load] into h_a; h_b is `hdelta` elements further
+  const __bf16* offY[2][2];
+  const long long hdelta = P.hb - P.ha;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = 8 * (wave + 8 * i) + (lane >> 3);
+    const int cs = ((lane & 7) ^ ((u >> 1) & 7)) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ra = m0 + (u >> 6) * 128 + h * 64 + (u & 63);
+      const int rb = n0 + (u >> 5) * 64 + h * 32 + (u & 31);
+      const long long ro = (long long)(ra < rows ? ra : rows - 1) * ldh + cs;
+      offA[h][i] = P.ha + ro;
+      offY[h][i] = P.G + (long long)rb * P.ldg + cs;
+    }
+  }
+  int lo[2];
+  {
+    const int sw = (fr >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) lo[ks] = fr * 128 + (((q | (ks << 2)) ^ sw) << 4);
+  }
+  // a_init = (c2 / c1)[T - 1] z_T + g in the accumulator layout: acc.v[qa][qb][c][n][r] is row m0 + wr 128 + qa 64 + c 16 + q 4 + r,
+  // column n0 + wc 64 + qb 32 + n 16 + fr (p8_acc_to_lds)
+  P8Acc acc;
+  float gcol[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) gcol[qb][n] = P.g[n0 + wc * 64 + qb * 32 + n * 16 + fr];
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 128 + qa * 64 + c * 16 + q * 4 + r;
+        const float* zr = P.z + (long long)(row < rows ? row : rows - 1) * P.ldz + n0 + wc * 64 + fr;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc.v[qa][qb][c][n][r] = Lb.s_init * zr[qb * 32 + n * 16] + gcol[qb][n];
+      }
+
+  const bool interior = m0 + 256 <= rows;
+  for (int step = 0; step < T - 1; ++step) {
+    const int i = T - 1 - step, src = step & 1;
+    {
+      const long long hd = src ? hdelta : 0;
+      const __bf16* offX[2][2] = {{offA[0][0] + hd, offA[0][1] + hd}, {offA[1][0] + hd, offA[1][1] + hd}};
+      p8_main_loop<false>(acc, offX, offY, nk, smem, wave, wr, wc, lo);
+    }
+    P8Epi E;
+    E.C = nullptr; E.Cb = hbuf[src ^ 1]; E.R = nullptr; E.Rb = nullptr; E.bias = nullptr; E.bias2 = bias_t + (long long)(i - 1) * ldbt;
+    E.ldc = 0; E.ldcb = ldh; E.ldr = 0; E.ldrb = 0; E.M = rows; E.N = Lb.H; E.act = DMM_ACT_NONE; E.alpha = coef[2 * i]; E.e1 = 1.f; E.e2 = 1.f;
+    if (interior) p8_epilogue_fast<0, false, true, DMM_ACT_NONE, false, true, true>(E, acc, smem, m0, n0, wave, lane);
+    else p8_epilogue_fast<0, false, true, DMM_ACT_NONE, true, true, true>(E, acc, smem, m0, n0, wave, lane);
+    if (step + 1 == T - 1) break;  // h_0 is written; nothing follows in this kernel
+    const float sc = coef[2 * i + 1];
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.v[qa][qb][c][n][r] = sc * acc.v[qa][qb][c][n][r] + gcol[qb][n];
+    // ---- group barrier (MI355X_MICROARCH.md, inter-workgroup visibility): plain stores (h' stays in this XCD's L2 for the group's re-read) ->
+    // every wave waits for its stores -> workgroup barrier -> ONE lane: agent release (L2 write-back), wait, arrive, poll, agent acquire (this
+    // CU's L1 invalidated), wait -> workgroup barrier -> the next step's loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: the flag must not overtake the write-back)
+      __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int target = (step + 1) * nt;
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > LATENT_SPIN_MAX) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+}
+
+int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    return true;
+  }();
+  (void)once;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int nt = base.H / 256;
+  const int per = std::max(8, (cus / nt) & ~7);  // groups per launch: every member workgroup gets a CU of its own
+  const int total = n_mod * base.rbs;
+  for (int g0 = 0; g0 < total; g0 += per) {
+    LatentBatch b = base;
+    b.g0 = g0;
+    b.n_groups = std::min(per, total - g0);
+    hipError_t e = hipMemsetAsync(b.flags, 0, sizeof(int) * b.n_groups, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(latent_chain_8ph_kernel, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
+  }
+  return 0;
 }
 
 template <int EPI>
@@ -518,6 +696,31 @@ void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
 }
 
 }  // namespace dmm
+
+extern "C" int dmm_latent_chain(const dmm_latent_chain_args* a, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
+                                int flags_len, void* stream) {
+  using namespace dmm;
+  DMM_CHECK_ARG(a && coef && flags && n_mod >= 1 && n_mod <= GB_MAX_BATCH && rows > 0 && T >= 1, "dmm_latent_chain: bad arguments");
+  DMM_CHECK_ARG(H >= 256 && H % 256 == 0 && H <= 2048, "dmm_latent_chain: H=%d must be a multiple of 256 in 256..2048", H);
+  DMM_CHECK_ARG(flags_len >= 258, "dmm_latent_chain: flags needs 258 int32 entries (256 group counters, a spare, the error word)");
+  if (T == 1) return 0;  // h_0 = h_{T-1}: nothing to do
+  LatentBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < n_mod; ++i) {
+    DMM_CHECK_ARG(a[i].G && a[i].g && a[i].z && a[i].h_a && a[i].h_b && a[i].bias_t, "dmm_latent_chain: null operand (problem %d)", i);
+    DMM_CHECK_ARG(a[i].ldg >= H && a[i].ldg % 8 == 0 && a[i].ldh >= H && a[i].ldh % 8 == 0 && a[i].ldz >= H && a[i].ldbt >= H && a[i].ldbt % 4 == 0 &&
+                      (((uintptr_t)a[i].G | (uintptr_t)a[i].h_a | (uintptr_t)a[i].h_b | (uintptr_t)a[i].bias_t) & 15) == 0,
+                  "dmm_latent_chain: G / h / bias_t must be 16-byte aligned with leading dimensions >= H (bf16: multiples of 8, bias_t: of 4)");
+    LatentP& P = b.p[i];
+    P.G = (const __bf16*)a[i].G; P.ldg = a[i].ldg; P.g = a[i].g; P.z = a[i].z; P.ldz = a[i].ldz;
+    P.ha = (__bf16*)a[i].h_a; P.hb = (__bf16*)a[i].h_b; P.ldh = a[i].ldh; P.bias_t = a[i].bias_t; P.ldbt = a[i].ldbt;
+  }
+  b.coef = coef; b.flags = flags; b.s_init = s_init; b.rows = rows; b.H = H; b.T = T; b.rbs = (rows + 255) / 256; b.err_at = flags_len - 1;
+  const int rc = launch_latent_chain_8ph(b, n_mod, (hipStream_t)stream);
+  if (rc) { dmm::set_error("dmm_latent_chain: hipMemsetAsync failed (%d)", rc); return rc; }
+  DMM_LAUNCH_CHECK("dmm_latent_chain");
+  return 0;
+}
 
 #ifdef P8_TIMING
 extern "C" int dmm_debug_p8_stamps(unsigned long long* host, int n) {

@@ -808,6 +808,24 @@ class DiffusionEngine:
         for the reference's schedule: posterior_mean_coef2[0] = (1 - alphas_cumprod_prev[0]) ... = 0, Model.py:256-262)."""
         return self.hp.get("chain_mode", os.environ.get("DMM_CHAIN_MODE", "latent")) == "latent" and float(self.c2[0]) == 0.0
 
+    def _latent_step_args(self, m: int, i: int, h16: Tensor, z: Tensor, z_out: Tensor, h_out: Tensor) -> dict:
+        """Latent chain step i (> 0): z_out = c2[i] z + c1[i] (h16 G^T + g) in fp32, h_out = bf16(tanh(z_out + bias_t[i - 1]))."""
+        lat = self._lat
+        return dict(A=h16, B=lat["G16"][m], out=z_out, out_bf16=h_out, bias=lat["g"][m], residual=z, e1=float(self.c1[i]), e2=float(self.c2[i]),
+                    bias2=self.bias_t[m][i - 1])
+
+    def _latent_fused(self) -> bool:
+        """The persistent kernel covers the shipped Denoise shape (one hidden width, a multiple of 256); hp latent_fused / DMM_LATENT_FUSED=0
+        forces one launch per step (also the path for k > 1 hidden widths: their mid layers run between the steps)."""
+        on = self.hp.get("latent_fused", os.environ.get("DMM_LATENT_FUSED", "1") != "0")
+        return bool(on) and not self.mids and self.H % 256 == 0 and 256 <= self.H <= 2048 and self.T >= 2
+
+    def check_chain_error(self):
+        """Raises if a group barrier of the persistent latent-chain kernel ever timed out (its results would be invalid).  Reads one device
+        word: call it where the host synchronises anyway (the trainer does, once per epoch)."""
+        if self._lat is not None and int(self._lat["flags"][-1]) != 0:
+            raise RuntimeError("dmm_latent_chain: a group barrier timed out -- the rebuilt views of this epoch are invalid")
+
     def _latent_alloc(self):
         if self._lat is not None:
             return
@@ -816,7 +834,15 @@ class DiffusionEngine:
         zb = lambda *s_: torch.zeros(s_, dtype=torch.bfloat16, device=self.dev)
         self._lat = dict(za=[z(R, H) for _ in range(M)], zb=[z(R, H) for _ in range(M)], hb=[zb(R, H) for _ in range(M)], G32=z(3, H, H),
                          G16=[zb(H, H) for _ in range(M)], g=[z(H) for _ in range(M)], b2_last=[z(I) for _ in range(M)],
-                         w1lo=zb(H, self.Kp), w2Thi=zb(H, self.Kp), w2Tlo=zb(H, self.Kp))  # (scratch of the once-per-epoch G refresh)
+                         w1lo=zb(H, self.Kp), w2Thi=zb(H, self.Kp), w2Tlo=zb(H, self.Kp),  # (scratch of the once-per-epoch G refresh)
+                         flags=torch.zeros(258, dtype=torch.int32, device=self.dev))
+        # per-step scalars of the persistent kernel (fp64 on the host, then fp32): coef[2 i] = c1[i], coef[2 i + 1] = c2[i-1] c1[i] / c1[i-1]
+        c1, c2, T = np.asarray(self.sched["posterior_mean_coef1"], dtype=np.float64), np.asarray(self.sched["posterior_mean_coef2"], dtype=np.float64), self.T
+        coef = np.zeros(2 * T, dtype=np.float64)
+        coef[0::2] = c1
+        coef[3::2] = c2[: T - 1] * c1[1:] / np.maximum(c1[: T - 1], 1e-300)
+        self._lat["coef"] = torch.from_numpy(coef.astype(np.float32)).to(self.dev)
+        self._lat["s_init"] = float(c2[T - 1] / c1[T - 1])
         if self._w1T_chain is None:
             self._w1T_chain = [zb(self.Kp, H) for _ in range(M)]
             self._b2_first = [z(I) for _ in range(M)]
@@ -863,10 +889,15 @@ class DiffusionEngine:
                     for m in mods:
                         ops.cast_bf16(self.cxb[m][:B], self.cxa16[m][:B], cols=I, cols_pad=self.Kp)  # temb / pad columns zero: temb enters through bias_t
                     ops.gemm_bf16_nt_batched([dict(A=self.cxa16[m][:B], B=self.w1_16[m], out=z[m], out_bf16=h[m], bias2=self.bias_t[m][T - 1]) for m in mods])
-                for i in range(T - 1, 0, -1):
-                    ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h[m]), B=lat["G16"][m], out=z2[m], out_bf16=h2[m], bias=lat["g"][m], residual=z[m],
-                                                   e1=float(self.c1[i]), e2=float(self.c2[i]), bias2=self.bias_t[m][i - 1]) for m in mods])
-                    z, z2, h, h2 = z2, z, h2, h
+                if self._latent_fused():  # all T - 1 steps inside one persistent launch sequence, z in registers (dmm_latent_chain)
+                    ops.latent_chain([dict(G=lat["G16"][m], g=lat["g"][m], z=z[m], h_a=h[m], h_b=h2[m], bias_t=self.bias_t[m]) for m in mods],
+                                     rows=B, T=T, coef=lat["coef"], s_init=lat["s_init"], flags=lat["flags"])
+                    if (T - 1) % 2:
+                        h, h2 = h2, h
+                else:
+                    for i in range(T - 1, 0, -1):
+                        ops.gemm_bf16_nt_batched([self._latent_step_args(m, i, self._mids_chain(m, h[m]), z[m], z2[m], h2[m]) for m in mods])
+                        z, z2, h, h2 = z2, z, h2, h
                 ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h[m]), B=self.w2_16[m], out=self.cxa[m][:B], bias=lat["b2_last"][m], alpha=float(self.c1[0]), N=I)
                                           for m in mods])
             if len(self._chain_plans) > 16:

@@ -230,6 +230,27 @@ def gemm_bf16_nt_batched(problems: Sequence[dict]) -> None:
     L.call("dmm_gemm_bf16_nt_batched", arr, len(problems), L.stream())
 
 
+def latent_chain(problems: Sequence[dict], rows: int, T: int, coef: Tensor, s_init: float, flags: Tensor) -> None:
+    """All T - 1 latent-chain steps of up to 4 modalities in one persistent launch sequence (dmm_latent_chain).  problems: dicts with G (bf16
+    [H, H]), g (fp32 [H]), z (fp32 [rows, H]: z_T), h_a / h_b (bf16 [rows, H]; h_a = h_{T-1} on entry), bias_t (fp32 [T, H]).  h_0 ends up in h_a when
+    T - 1 is even, else in h_b."""
+    H = problems[0]["G"].shape[0]
+    arr = (L.LatentChainArgs * len(problems))()
+    for a, p in zip(arr, problems):
+        G, g, z, ha, hb, bt = p["G"], p["g"], p["z"], p["h_a"], p["h_b"], p["bias_t"]
+        if G.dtype != torch.bfloat16 or ha.dtype != torch.bfloat16 or hb.dtype != torch.bfloat16 or z.dtype != torch.float32 or bt.dtype != torch.float32 or \
+                any(t.stride(1) != 1 for t in (G, z, ha, hb, bt)) or G.shape != (H, H) or any(t.shape[0] < rows or t.shape[1] < H for t in (z, ha, hb)) or \
+                bt.shape[0] < T or bt.shape[1] < H or g.numel() < H:
+            raise ValueError("latent_chain: bad operands")
+        a.G, a.ldg, a.g, a.z, a.ldz = L.ptr(G), G.stride(0), L.ptr(_f32c(g, "g")), L.ptr(z), z.stride(0)
+        a.h_a, a.h_b, a.ldh, a.bias_t, a.ldbt = L.ptr(ha), L.ptr(hb), ha.stride(0), L.ptr(bt), bt.stride(0)
+        if hb.stride(0) != ha.stride(0):
+            raise ValueError("latent_chain: h_a and h_b must share one leading dimension")
+    if coef.dtype != torch.float32 or coef.numel() < 2 * T or flags.dtype != torch.int32 or not flags.is_contiguous():
+        raise ValueError("latent_chain: coef must be fp32 [2 T], flags int32")
+    L.call("dmm_latent_chain", arr, len(problems), rows, H, T, L.ptr(coef), float(s_init), L.ptr(flags), flags.numel(), L.stream())
+
+
 def cast_bf16(src: Tensor, dst: Tensor, cols: Optional[int] = None, cols_pad: Optional[int] = None) -> None:
     cols = src.shape[1] if cols is None else cols
     cols_pad = cols if cols_pad is None else cols_pad

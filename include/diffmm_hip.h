@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 201
+#define DMM_VERSION 202
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -147,6 +147,23 @@ typedef struct dmm_gemm_bf16_args {
 int dmm_gemm_bf16_nt(const dmm_gemm_bf16_args* a /*host*/, void* stream);
 /* up to 4 problems of one shape in one launch (the modalities' large GEMMs go out together: enough tiles to fill the chip) */
 int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* a /*host array*/, int n_batch, void* stream);
+
+/* The latent reverse chain as one persistent launch sequence: GaussianDiffusion.p_sample's T posterior-mean steps (Model.py:300-322,
+ * :375) for up to 4 modalities.  With z_t = x_t W1x^T, G = W1x W2, g = W1x b2:   z_{t-1} = c2[t] z_t + c1[t] (h_t G^T + g),  h_{t-1} = tanh(z_{t-1} +
+ * bias_t[t-1]).  On entry z holds z_T (fp32) and h_a holds h_{T-1} (bf16); the T - 1 steps t = T-1 .. 1 run inside the kernel with z in registers
+ * (it is never written back) and h exchanged through h_a / h_b; on return h_0 is in h_a when T - 1 is even, else in h_b.  The caller then forms
+ * x_0' = c1[0] (h_0 W2^T + b2) with dmm_gemm_bf16_nt.  coef (device, [2 T]): coef[2 t] = c1[t], coef[2 t + 1] = c2[t-1] c1[t] / c1[t-1];
+ * s_init = c2[T-1] / c1[T-1].  flags: device int32 scratch, >= 258 entries; flags[flags_len - 1] is an error word the kernel sets to 1 if a group
+ * barrier timed out (the results are then invalid; it never hangs).  H must be a multiple of 256 (<= 2048). */
+typedef struct dmm_latent_chain_args {
+  const void* G; int64_t ldg;      /* bf16 [H, H] */
+  const float* g;                  /* [H] */
+  const float* z; int64_t ldz;     /* fp32 [rows, H] */
+  void* h_a; void* h_b; int64_t ldh; /* bf16 [rows, H] each */
+  const float* bias_t; int64_t ldbt; /* fp32 [T, H]: per-timestep layer-1 bias (dmm_temb_bias_table) */
+} dmm_latent_chain_args;
+int dmm_latent_chain(const dmm_latent_chain_args* a /*host array*/, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
+                     int flags_len, void* stream);
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
 int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream);

@@ -803,6 +803,17 @@ def test_latent_chain_matches_stepwise_chain(dev):
     again = E.generate_views_latent(xT=[x0] * M, B=B)
     assert all(torch.equal(lat[m], again[m]) for m in range(M)), "latent chain reproducible"
     sparse = [v.clone() for v in E.generate_views_latent(rows=dd.csr_rows(users))]
+    E.check_chain_error()
+    # the persistent kernel (all T - 1 steps in one launch sequence, z in registers) against one launch per step (z through memory)
+    assert E._latent_fused()
+    E.hp["latent_fused"] = False
+    E._chain_plans.clear()
+    per_step = [v.clone() for v in E.generate_views_latent(xT=[x0] * M, B=B)]
+    E.hp["latent_fused"] = True
+    E._chain_plans.clear()
+    for m in range(M):
+        sc = float(per_step[m].abs().max())
+        assert float((per_step[m] - lat[m]).abs().max()) < 6e-3 * sc, f"modality {m}: persistent latent kernel vs per-step launches"
     E.hp["chain_state"] = "bf16"
     step16 = [v.clone() for v in E.generate_views_bf16(x0)]
     for m in range(M):
@@ -835,6 +846,34 @@ def test_latent_chain_matches_stepwise_chain(dev):
         gscale = float(np.abs(z["genview/out"]).max())
         err = float((gv.cpu() - T(z["genview/out"])).abs().max()) / gscale
         assert err < 3e-2, f"{name}: latent chain vs the reference's generate_view: {err:.3e} of the output scale"
+
+
+@pytest.mark.parametrize("rows,T_", [(5700, 4), (1100, 7), (256, 2)])
+def test_persistent_latent_kernel_group_barriers(dev, rows, T_):
+    """dmm_latent_chain with more groups than one launch holds (3 x 23 row blocks > 64 groups: two launches), an odd and an even number of
+    steps (the result lands in either ping-pong buffer), a ragged last row block and the minimal T = 2; against one launch per step.  The error
+    word stays clear (no barrier timed out) and the call is bit-reproducible."""
+    from diffmm_amd.engine import DiffusionEngine
+    torch.manual_seed(rows + T_)
+    I, D, H, M = 264, 64, 1024, 3
+    hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3, seed=5)
+    E = DiffusionEngine(I, D, H, 10, M, T_, hp, dev, rows)
+    for m in range(M):
+        E.P[m].data.normal_(0, 0.05)
+        E.P[m].view("in_layers.0.weight")[:, I + 10:].zero_()
+    x0 = (torch.rand(rows, I, device=dev) < 0.03).float()
+    fused = [v.clone() for v in E.generate_views_latent(xT=[x0] * M, B=rows)]
+    again = E.generate_views_latent(xT=[x0] * M, B=rows)
+    assert all(torch.equal(fused[m], again[m]) for m in range(M)), "persistent kernel reproducible"
+    E.check_chain_error()
+    E.hp["latent_fused"] = False
+    E._chain_plans.clear()
+    per_step = E.generate_views_latent(xT=[x0] * M, B=rows)
+    for m in range(M):
+        sc = float(per_step[m].abs().max())
+        err = float((per_step[m] - fused[m]).abs().max()) / sc
+        # (fp32 sums in another order: where a bf16 h rounds the other way, one bf16 ulp = 4e-3 relative enters the next step)
+        assert err < 6e-3, f"modality {m}: persistent kernel vs per-step launches: {err:.3e} of the output scale"
 
 
 def test_csr_rows_equal_the_dense_path(dev):

@@ -4,11 +4,13 @@ epilogue kind of the 256 x 256 GEMM the fabric-side bytes per launch (FETCH_SIZE
 coalesced reads on gfx950; WRITE_SIZE exact; both reported in KiB), the L2 hit rate and the MFMA-pipe busy share."""
 import collections, csv, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
-NAMES = {"1": "layer1_tanh_bf16", "3": "layer2_bf16_state", "2": "layer2_fp32_state"}
+NAMES = {"1": "layer1_tanh_bf16", "3": "layer2_bf16_state", "2": "layer2_fp32_state", "9": "latent_step", "6": "last_step_fp32_out"}
 ALG = {  # operands read once + outputs written once (+ residual read once), bytes per batched launch of 3 modalities
     "layer1_tanh_bf16": 3 * (9308 * 6720 * 2 + 1024 * 6720 * 2 + 9308 * 1024 * 2),
     "layer2_bf16_state": 3 * (9308 * 1024 * 2 + 6710 * 1024 * 2 + 2 * 9308 * 6710 * 2),
     "layer2_fp32_state": 3 * (9308 * 1024 * 2 + 6710 * 1024 * 2 + 9308 * 6710 * (4 + 4 + 2)),
+    "latent_step": 3 * (9308 * 1024 * (4 + 4 + 2 + 2) + 1024 * 1024 * 2),
+    "last_step_fp32_out": 3 * (9308 * 1024 * 2 + 6710 * 1024 * 2 + 9308 * 6710 * 4),
 }
 
 

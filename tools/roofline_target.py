@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """The launches bench.py's `roofline` times, alone and as the reverse chain issues them (bench shapes: 3 modalities x 9308 users,
-I = 6710, Kp = 6720, H = 1024): N x the batched layer-1 GEMM (tanh -> bf16), N x layer 2 with the running x_t in bf16 (the default
-chain state), N x layer 2 with the fp32 state of round 1.  Each epilogue kind is its own kernel instantiation, so a profile separates them:
+I = 6710, Kp = 6720, H = 1024): N x the latent chain step ([rows, H] x [H, H], fp32 z in / out, bf16 tanh out), N x the chain's last step
+(h_0 W2^T -> fp32 view), and the stepwise chain's launches: N x layer 1 (tanh -> bf16), N x layer 2 with the running x_t in bf16, N x layer 2
+with the fp32 state of round 1.  Each epilogue kind is its own kernel instantiation, so a profile separates them:
     rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/roofline_target.py [N]
-    gemm_bf16_nt_8ph_kernel<1> = layer 1, <3> = layer 2 (bf16 state), <2> = layer 2 (fp32 state)."""
+    gemm_bf16_nt_8ph_kernel<9> = latent step, <6> = last step, <1> = layer 1, <3> = layer 2 (bf16 state), <2> = layer 2 (fp32 state)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffmm_amd import ops, _lib as L
@@ -21,7 +22,12 @@ y16 = [torch.zeros(Mc, Kp, dtype=torch.bfloat16, device=dev) for _ in range(3)]
 l1 = lambda: ops.gemm_bf16_nt_batched([dict(A=x16[m], B=w1[m], out_bf16=h16[m], bias=b1, act=L.ACT_TANH) for m in range(3)])
 l2 = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=w2[m], out_bf16=y16[m], bias=b2, residual_bf16=x16[m], e1=0.9, e2=0.1, N=I) for m in range(3)])
 l2_fp32 = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=w2[m], out=y32[m], out_bf16=y16[m], bias=b2, residual=x32[m], e1=0.9, e2=0.1, N=I) for m in range(3)])
-for fn in (l1, l2, l2_fp32):
+G = [(torch.randn(H, H, device=dev) * 0.02).bfloat16() for _ in range(3)]; g = torch.zeros(H, device=dev); bt = torch.zeros(H, device=dev)
+z32 = [torch.randn(Mc, H, device=dev) for _ in range(3)]; z32b = [torch.zeros(Mc, H, device=dev) for _ in range(3)]
+hb16 = [torch.zeros(Mc, H, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+latent = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=G[m], out=z32b[m], out_bf16=hb16[m], bias=g, residual=z32[m], e1=0.9, e2=0.1, bias2=bt) for m in range(3)])
+last = lambda: ops.gemm_bf16_nt_batched([dict(A=h16[m], B=w2[m], out=y32[m], bias=b2, N=I) for m in range(3)])
+for fn in (l1, latent, last, l2, l2_fp32):
     fn(); torch.cuda.synchronize()
     for _ in range(N):
         fn()
