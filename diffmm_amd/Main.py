@@ -251,6 +251,7 @@ class Coach:
             dist.all_reduce(acc[nT + 1:nT + 2], group=self.group)
             acc = torch.cat([acc[:nT + 1], acc[nT + 1:nT + 2] + acc[nT + 2:nT + 3]])
         a = acc.cpu().numpy()
+        DE.check_chain_error()  # (the host has just synchronised: one more word) a timed-out group barrier of dmm_latent_chain invalidates the epoch
         self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]
         cl, bpr, reg = float(a[:nT].sum()), float(a[nT]), float(a[nT + 1])
         result = {"Loss": (bpr + reg + cl) / train_steps, "BPR Loss": bpr / train_steps, "reg loss": reg / train_steps, "CL loss": cl / train_steps}
