@@ -46,6 +46,11 @@ class LatentChainArgs(C.Structure):
                 ("ldh", C.c_int64), ("bias_t", C.c_void_p), ("ldbt", C.c_int64)]
 
 
+class ProjectProblem(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("F", C.c_void_p), ("ldf", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64), ("bias", C.c_void_p),
+                ("rows", C.c_int32), ("K", C.c_int32)]
+
+
 class GatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("grad", C.c_void_p)]
 
@@ -111,6 +116,7 @@ _SIGS = {
     "dmm_topk_rows": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _P]),
     "dmm_noised_start": (C.c_int, [_P, _L, _P, _F, _F, _P, _L, _I, _I, _U64, _U64, _P]),
     "dmm_item_project": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
+    "dmm_item_project_batched": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _I, _I, _P]),
     "dmm_item_expand": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_graph_build_scratch_bytes": (C.c_int, [_I, _I, _L, _I, _P]),
     "dmm_graph_build_task_capacity": (C.c_int, [_I, _I, _L, _I, _I, _P, _P]),

@@ -8,6 +8,9 @@
 //                                                           and the gradient  dout += dum @ model_feats.T
 // Arithmetic: operands rounded to bf16 as they are loaded (the "precision 1" mode of dmm_gemm), MFMA 16x16x32, fp32 accumulation.
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "common.h"
 
@@ -20,56 +23,108 @@ __device__ __forceinline__ bf16x8 is_cvt8(const float4& a, const float4& b) {
   return bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
 }
 
-// ---- project: 256 rows x D per workgroup (4 waves x 64 rows), one K slice of `kchunk` items; F is staged transposed in LDS -----------
+// ---- project: (64 MT) rows x D per workgroup (4 waves x 16 MT rows), one K slice of `kchunk` items; F is staged transposed in LDS -------
+// MT = 4: the [B, I] x [I, d] products of the diffusion step (few, long rows of X).  MT = 1: the modality-feature projections of the joint
+// step (Model.py:84-85,103: many short rows), where FT says F is given as [D, K] (an nn.Linear weight) and OUT_T stores the result
+// transposed (the weight gradient dW = dfeat^T E as  E^T[F, I] x dfeat[I, D]  written into the [D, F] gradient).  Up to 4 problems per launch.
 constexpr int IP_KS = 128;  // items per LDS stage
+struct ProjP {
+  const float* X; long long ldx; const float* F; long long ldf; float* out; long long ldo; const float* bias; int rows, K, kchunk;
+};
+struct ProjBatch { ProjP p[4]; };
 
-template <int D>
-__global__ __launch_bounds__(256) void item_project_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ F, long long ldf,
-                                                           float* __restrict__ out, long long ldo, int B, int I, int kchunk) {
+template <int D, int MT, bool FT, bool OUT_T>
+__global__ __launch_bounds__(256) void item_project_kernel(const ProjBatch batch) {
   constexpr int NT = D / 16;
   constexpr int LDT = IP_KS * 2 + 16;  // bytes per feature column in LDS (+16: the 16 columns of a fragment read hit distinct banks)
   __shared__ __attribute__((aligned(16))) char ft[D * LDT];
+  const ProjP& P = batch.p[blockIdx.z];
+  const float* __restrict__ X = P.X; const float* __restrict__ F = P.F; float* __restrict__ out = P.out;
+  const long long ldx = P.ldx, ldf = P.ldf, ldo = P.ldo;
+  const int B = P.rows, I = P.K, kchunk = P.kchunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, kg = lane >> 4;
-  const int row0 = blockIdx.x * 256 + wave * 64;
+  const int row0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
   const int kbeg = blockIdx.y * kchunk, kend = min(I, kbeg + kchunk);
-  if (kbeg >= kend) return;
-  f32x4 acc[4][NT];
+  if (kbeg >= kend || blockIdx.x * (64 * MT) >= B) return;
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* xrow[4];
+  const float* xrow[MT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) xrow[mt] = X + (long long)min(row0 + mt * 16 + fr, B - 1) * ldx + kg * 8;
+  for (int mt = 0; mt < MT; ++mt) xrow[mt] = X + (long long)min(row0 + mt * 16 + fr, B - 1) * ldx + kg * 8;
 
   for (int k0 = kbeg; k0 < kend; k0 += IP_KS) {
+    const int steps = min(IP_KS, (kend - k0 + 31) & ~31) / 32;
+    // MT == 1 (one 16-row tile per wave: two loads per lane and k-step would leave the loop latency-bound): the X fragments of the WHOLE stage
+    // are requested up front, under the staging of F
+    float4 xs[MT == 1 ? 4 : 1][2];
+    if (MT == 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kq = k0 + min(s, steps - 1) * 32;
+        xs[s][0] = *reinterpret_cast<const float4*>(xrow[0] + kq);
+        xs[s][1] = *reinterpret_cast<const float4*>(xrow[0] + kq + 4);
+      }
+    }
     __syncthreads();  // the previous stage's fragment reads are done
     // stage F[k0 .. k0+KS, :] transposed (column-major, bf16); items past the slice are zero, so whatever X holds there is ignored
-    for (int idx = threadIdx.x; idx < IP_KS * (D / 4); idx += 256) {
-      const int kk = idx / (D / 4), c4 = idx % (D / 4);
-      const int k = k0 + kk;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < kend) v = *reinterpret_cast<const float4*>(F + (long long)k * ldf + c4 * 4);
-      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 0) * LDT + kk * 2) = (__bf16)v.x;
-      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 1) * LDT + kk * 2) = (__bf16)v.y;
-      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 2) * LDT + kk * 2) = (__bf16)v.z;
-      *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 3) * LDT + kk * 2) = (__bf16)v.w;
+    if (!FT) {
+      for (int idx = threadIdx.x; idx < IP_KS * (D / 4); idx += 256) {
+        const int kk = idx / (D / 4), c4 = idx % (D / 4);
+        const int k = k0 + kk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kend) v = *reinterpret_cast<const float4*>(F + (long long)k * ldf + c4 * 4);
+        *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 0) * LDT + kk * 2) = (__bf16)v.x;
+        *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 1) * LDT + kk * 2) = (__bf16)v.y;
+        *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 2) * LDT + kk * 2) = (__bf16)v.z;
+        *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 3) * LDT + kk * 2) = (__bf16)v.w;
+      }
+    } else {  // F is [D, K]: column c of the stage is a contiguous piece of row c
+      for (int idx = threadIdx.x; idx < D * (IP_KS / 4); idx += 256) {
+        const int c = idx / (IP_KS / 4), k4 = (idx % (IP_KS / 4)) * 4;
+        const int k = k0 + k4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* f = F + (long long)c * ldf + k;
+        if (k + 3 < kend) v = *reinterpret_cast<const float4*>(f);
+        else {
+          if (k < kend) v.x = f[0];
+          if (k + 1 < kend) v.y = f[1];
+          if (k + 2 < kend) v.z = f[2];
+        }
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4v*>(ft + c * LDT + k4 * 2) = bf16x4v{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      }
     }
     __syncthreads();
-    const int steps = min(IP_KS, (kend - k0 + 31) & ~31) / 32;
+    if (MT == 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < steps) {
+          const bf16x8 fa = is_cvt8(xs[s][0], xs[s][1]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(ft + (nt * 16 + fr) * LDT + (s * 32 + kg * 8) * 2);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[0][nt], 0, 0, 0);
+          }
+        }
+      }
+      continue;
+    }
     // the X fragments of k-step s+1 are requested before the MFMAs of step s (the request past the last step repeats it: no branch
     // around a load, so the compiler keeps counted waits)
-    float4 xa[4][2], xn[4][2];
+    float4 xa[MT][2], xn[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       xa[mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + k0);
       xa[mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + k0 + 4);
     }
     for (int s = 0; s < steps; ++s) {
       const int kn = k0 + min(s + 1, steps - 1) * 32;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         xn[mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + kn);
         xn[mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + kn + 4);
       }
@@ -77,26 +132,48 @@ __global__ __launch_bounds__(256) void item_project_kernel(const float* __restri
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const bf16x8*>(ft + (nt * 16 + fr) * LDT + (s * 32 + kg * 8) * 2);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const bf16x8 fa = is_cvt8(xa[mt][0], xa[mt][1]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[nt], acc[mt][nt], 0, 0, 0);
       }
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         xa[mt][0] = xn[mt][0];
         xa[mt][1] = xn[mt][1];
       }
     }
   }
+  if (OUT_T) {
+    // transposed result: through LDS, so that consecutive lanes add to consecutive addresses of out[c, row0 ..] (the accumulator layout
+    // has consecutive lanes on consecutive COLUMNS: 16 cache lines per atomic instruction instead of 1-2)
+    static_assert(!OUT_T || MT == 1, "transposed output: 64-row workgroups only");
+    float* tile = reinterpret_cast<float*>(ft);  // [D][65] floats <= D * LDT bytes
+    __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) tile[(nt * 16 + fr) * 65 + wave * 16 + kg * 4 + r] = acc[0][nt][r];
+    __syncthreads();
+    const int rbase = blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < D * 64; idx += 256) {
+      const int col = idx >> 6, rl = idx & 63;
+      if (rbase + rl < B) atomicAdd(out + (long long)col * ldo + rbase + rl, tile[col * 65 + rl]);
+    }
+    return;
+  }
+  const bool add_bias = P.bias != nullptr && blockIdx.y == 0;  // (one K slice carries the bias)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + mt * 16 + kg * 4 + r;
       if (row < B) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) atomicAdd(out + (long long)row * ldo + nt * 16 + fr, acc[mt][nt][r]);
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = nt * 16 + fr;
+          atomicAdd(out + (long long)row * ldo + col, acc[mt][nt][r] + (add_bias ? P.bias[col] : 0.f));
+        }
       }
     }
 }
@@ -167,6 +244,12 @@ __global__ __launch_bounds__(256) void item_expand_kernel(const float* __restric
 }  // namespace dmm
 using namespace dmm;
 
+template <int MT, bool FT, bool OUT_T>
+static void project_launch(const ProjBatch& b, int n, int D, int rb, int ks, hipStream_t s) {
+  if (D == 64) hipLaunchKernelGGL((item_project_kernel<64, MT, FT, OUT_T>), dim3(rb, ks, n), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((item_project_kernel<128, MT, FT, OUT_T>), dim3(rb, ks, n), dim3(256), 0, s, b);
+}
+
 extern "C" int dmm_item_project(const float* X, int64_t ldx, const float* F, int64_t ldf, float* out, int64_t ldo, int B, int I, int D, void* stream) {
   DMM_CHECK_ARG(X && F && out && B > 0 && I > 0, "dmm_item_project: bad arguments");
   DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_project: D=%d unsupported (64 or 128)", D);
@@ -178,10 +261,47 @@ extern "C" int dmm_item_project(const float* X, int64_t ldx, const float* F, int
   int ks = force_ks > 0 ? force_ks : std::max(1, std::min(64, 384 / rb));
   int kchunk = (((I + ks - 1) / ks) + 31) & ~31;
   ks = (I + kchunk - 1) / kchunk;
-  hipStream_t s = (hipStream_t)stream;
-  if (D == 64) hipLaunchKernelGGL(item_project_kernel<64>, dim3(rb, ks), dim3(256), 0, s, X, (long long)ldx, F, (long long)ldf, out, (long long)ldo, B, I, kchunk);
-  else hipLaunchKernelGGL(item_project_kernel<128>, dim3(rb, ks), dim3(256), 0, s, X, (long long)ldx, F, (long long)ldf, out, (long long)ldo, B, I, kchunk);
+  ProjBatch b;
+  memset(&b, 0, sizeof(b));
+  b.p[0] = ProjP{X, (long long)ldx, F, (long long)ldf, out, (long long)ldo, nullptr, B, I, kchunk};
+  project_launch<4, false, false>(b, 1, D, rb, ks, (hipStream_t)stream);
   DMM_LAUNCH_CHECK("dmm_item_project");
+  return 0;
+}
+
+extern "C" int dmm_item_project_batched(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, void* stream) {
+  DMM_CHECK_ARG(p && n >= 1 && n <= 4, "dmm_item_project_batched: 1..4 problems per launch");
+  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_project_batched: D=%d unsupported (64 or 128)", D);
+  ProjBatch b;
+  memset(&b, 0, sizeof(b));
+  int rb = 0, ks = 0, rows_all = 0;
+  for (int i = 0; i < n; ++i) rows_all += (p[i].rows + 63) / 64;
+  for (int i = 0; i < n; ++i) {
+    const dmm_project_problem& q = p[i];
+    DMM_CHECK_ARG(q.X && q.F && q.out && q.rows > 0 && q.K > 0, "dmm_item_project_batched: bad arguments (problem %d)", i);
+    DMM_CHECK_ARG(q.ldx % 4 == 0 && q.ldf % 4 == 0 && (((uintptr_t)q.X | (uintptr_t)q.F) & 15) == 0 && q.ldx >= ((q.K + 31) & ~31),
+                  "dmm_item_project_batched: X and F rows must be 16-byte aligned and X rows readable up to round_up(K, 32) (problem %d)", i);
+    DMM_CHECK_ARG(f_transposed ? q.ldf >= q.K : q.ldf >= D, "dmm_item_project_batched: ldf too small (problem %d)", i);
+    // K slices of whole 32-item steps: about 1024 workgroups per launch over all problems
+    static const int wgs_fwd = [] { const char* e = getenv("DMM_PROJ_WGS"); return e ? atoi(e) : 1024; }();      // tuning knobs
+    static const int wgs_bwd = [] { const char* e = getenv("DMM_PROJ_WGS_T"); return e ? atoi(e) : 1024; }();  // (256 / 1024 / 4096 measured: 23.0 / 21.3 / 21.7 us)
+    int want = std::max(1, std::min(64, (out_transposed ? wgs_bwd : wgs_fwd) / std::max(1, rows_all)));
+    // the forward projections feed replicated state of the user-sharded engine: at most TWO slices, so that the atomic sum is a single
+    // commutative addition and the result does not depend on arrival order (bit-identical on every replica)
+    if (!out_transposed) want = std::min(want, 2);
+    int kchunk = (((q.K + want - 1) / want) + 31) & ~31;
+    kchunk = std::max(kchunk, 32);
+    b.p[i] = ProjP{q.X, (long long)q.ldx, q.F, (long long)q.ldf, q.out, (long long)q.ldo, q.bias, q.rows, q.K, kchunk};
+    rb = std::max(rb, (q.rows + 63) / 64);
+    ks = std::max(ks, (q.K + kchunk - 1) / kchunk);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (f_transposed && !out_transposed) project_launch<1, true, false>(b, n, D, rb, ks, s);
+  else if (!f_transposed && out_transposed) project_launch<1, false, true>(b, n, D, rb, ks, s);
+  else if (!f_transposed && !out_transposed) project_launch<1, false, false>(b, n, D, rb, ks, s);
+  else project_launch<1, true, true>(b, n, D, rb, ks, s);
+  (void)&project_launch<4, false, false>;
+  DMM_LAUNCH_CHECK("dmm_item_project_batched");
   return 0;
 }
 

@@ -93,7 +93,10 @@ class JointEngine:
         self.P = FlatParams(shapes, self.dev)
         N, M = self.N, self.M
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
-        self.feat = [z(items, D) for _ in range(M)]
+        self._feat_block = z(M, items, D)  # the projections are accumulated by K slices: one memset for all modalities
+        self.feat = [self._feat_block[m] for m in range(M)]
+        # E_m^T [F_m, round_up(I, 32)] (constant): the weight gradient dW_m = dfeat_m^T E_m runs as E_m^T x dfeat_m on the item-space kernel
+        self._featsT = None
         self.nf = [z(items, D) for _ in range(M)]
         self.fnorm = [z(items) for _ in range(M)]
         self.Z = [z(N, D) for _ in range(M)]
@@ -157,11 +160,30 @@ class JointEngine:
             del self._plans[k]
 
     # -- forward of gcn_MM (+ optionally the 3 perturbed CL layers) ---------------------------------
+    def _feat_kernels(self, precision: int) -> bool:
+        """bf16 single-product mode at d = 64 / 128 with feature widths that are whole 32-wide K steps (every shipped feature file)."""
+        return precision == 1 and self.D in (64, 128) and all(f.shape[1] % 32 == 0 for f in self.feats) and \
+            self.hp.get("feat_kernels", os.environ.get("DMM_FEAT_KERNELS", "1") != "0")
+
+    def _features_T(self) -> List[Tensor]:
+        if self._featsT is None:
+            Ip = (self.I + 31) & ~31
+            self._featsT = []
+            for f in self.feats:
+                t = torch.zeros(f.shape[1], Ip, dtype=torch.float32, device=self.dev)
+                t[:, : self.I].copy_(f.t())
+                self._featsT.append(t)
+        return self._featsT
+
     def _project(self, precision: int):
         names = modality_names(self.M)
-        # Linear_m(E_m) of every modality in ONE launch (each alone is 53 workgroups: a fifth of the chip; K split measured: no gain)
-        ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{n}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{n}_layer.bias"),
-                               precision=precision) for m, n in enumerate(names)])
+        if self._feat_kernels(precision):  # skinny products (N = d): the item-space MFMA kernel, 64 rows per workgroup, all modalities in one launch
+            ops.zero_(self._feat_block)
+            ops.item_project_batched([dict(X=self.feats[m], F=self.P.view(f"{n}_layer.weight"), out=self.feat[m], bias=self.P.view(f"{n}_layer.bias"),
+                                           K=self.feats[m].shape[1]) for m, n in enumerate(names)], self.D, f_transposed=True)
+        else:  # Linear_m(E_m) of every modality in ONE launch of the generic GEMM
+            ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{n}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{n}_layer.bias"),
+                                   precision=precision) for m, n in enumerate(names)])
         for m in range(self.M):
             ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
 
@@ -268,9 +290,14 @@ class JointEngine:
         ops.zero_(self.P.grad[ne:self.P.offsets["modal_weight"]])
         for m, n in enumerate(names):
             ops.rownorm_bwd(self.T[m][U:], self.nf[m], self.fnorm[m], self.dfeat[m])
-        # dW_m = dfeat_m^T E_m: 64 x F outputs with K = I the parallel axis (split 32 / 64 / 128 / 256 measured: 128); one launch for all m
-        ops.gemm_batched([dict(A=self.dfeat[m], B=self.feats[m], out=self.P.g(f"{n}_layer.weight"), trans_a=True, precision=precision, split_k=128)
-                          for m, n in enumerate(names)])
+        # dW_m = dfeat_m^T E_m: 64 x F outputs with K = I the parallel axis; one launch for all m
+        if self._feat_kernels(precision):  # as E_m^T [F_m, I] x dfeat_m [I, d], stored transposed into the [d, F_m] gradient
+            FT = self._features_T()
+            ops.item_project_batched([dict(X=FT[m], F=self.dfeat[m], out=self.P.g(f"{n}_layer.weight"), K=self.I) for m, n in enumerate(names)], D,
+                                     out_transposed=True)
+        else:  # generic GEMM, K split 128 (32 / 64 / 128 / 256 measured)
+            ops.gemm_batched([dict(A=self.dfeat[m], B=self.feats[m], out=self.P.g(f"{n}_layer.weight"), trans_a=True, precision=precision, split_k=128)
+                              for m, n in enumerate(names)])
         for m, n in enumerate(names):
             ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"))
         if update:

@@ -32,7 +32,7 @@ import torch
 
 from . import _lib as L
 from . import graph, ops, shard
-from .engine import FlatParams, modality_names
+from .engine import FlatParams, JointEngine, modality_names
 
 Tensor = torch.Tensor
 
@@ -124,7 +124,8 @@ class ShardedJointEngine:
         self.P = FlatParams(shapes, self.dev)
         n, M, I = self.n, self.M, self.I
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
-        self.feat = [z(I, D) for _ in range(M)]
+        self._feat_block = z(M, I, D)
+        self.feat = [self._feat_block[m] for m in range(M)]
         self.nf = [z(I, D) for _ in range(M)]
         self.fnorm = [z(I) for _ in range(M)]
         self.Z = [z(n, D) for _ in range(M)]
@@ -244,10 +245,29 @@ class ShardedJointEngine:
     # -- forward of gcn_MM (+ the 3 perturbed CL layers) ---------------------------------------------------
     def _project(self, precision: int):
         # replicated: every replica needs all normalised item features as SpMM operand; one launch for the modalities' projections
-        ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
-                               precision=precision) for m, nm in enumerate(modality_names(self.M))])
+        if self._feat_kernels(precision):  # (at most two K slices: order-independent, so the replicas' copies stay bit-identical)
+            ops.zero_(self._feat_block)
+            ops.item_project_batched([dict(X=self.feats[m], F=self.P.view(f"{nm}_layer.weight"), out=self.feat[m], bias=self.P.view(f"{nm}_layer.bias"),
+                                           K=self.feats[m].shape[1]) for m, nm in enumerate(modality_names(self.M))], self.D, f_transposed=True)
+        else:
+            ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
+                                   precision=precision) for m, nm in enumerate(modality_names(self.M))])
         for m in range(self.M):
             ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
+
+    _feat_kernels = JointEngine._feat_kernels
+
+    def _features_T_slice(self) -> List[Tensor]:
+        """E_m^T restricted to this replica's item slice, [F_m, round_up(i1 - i0, 32)] (constant)."""
+        if getattr(self, "_featsT", None) is None:
+            i0, i1 = self.layout.item_slice()
+            Kp = (max(i1 - i0, 1) + 31) & ~31
+            self._featsT = []
+            for f in self.feats:
+                t = torch.zeros(f.shape[1], Kp, dtype=torch.float32, device=self.dev)
+                t[:, : i1 - i0].copy_(f[i0:i1].t())
+                self._featsT.append(t)
+        return self._featsT
 
     def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3):
         """noise (parity tests): 3 tensors already in the LOCAL row order [own users ; items]."""
@@ -392,8 +412,13 @@ class ShardedJointEngine:
         if i1 > i0:  # projection backward: this replica's slice of the items, the modalities' weight gradients in one launch
             for m in range(M):
                 ops.rownorm_bwd(self.T[m][nu + i0:nu + i1], self.nf[m][i0:i1], self.fnorm[m][i0:i1], self.dfeat[m][i0:i1])
-            ops.gemm_batched([dict(A=self.dfeat[m][i0:i1], B=self.feats[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), trans_a=True, precision=precision,
-                                   split_k=128) for m, nm in enumerate(names)])
+            if self._feat_kernels(precision):
+                FT = self._features_T_slice()
+                ops.item_project_batched([dict(X=FT[m], F=self.dfeat[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), K=i1 - i0) for m, nm in enumerate(names)],
+                                         D, out_transposed=True)
+            else:
+                ops.gemm_batched([dict(A=self.dfeat[m][i0:i1], B=self.feats[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), trans_a=True, precision=precision,
+                                       split_k=128) for m, nm in enumerate(names)])
             for m, nm in enumerate(names):
                 ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, self.P.g(f"{nm}_layer.bias"))
         self._exchange_end()

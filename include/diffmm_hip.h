@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 202
+#define DMM_VERSION 203
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -334,6 +334,19 @@ int dmm_noised_start(const float* x0, int64_t ldx0, const float* randn, float sq
 int dmm_item_project(const float* X, int64_t ldx, const float* F, int64_t ldf, float* out, int64_t ldo, int B, int I, int D, void* stream);
 int dmm_item_expand(const float* P, int64_t ldp, const float* F, int64_t ldf, const float* R, int64_t ldr, float* Y, int64_t ldy, int B, int I, int D,
                     void* stream);
+/* The same product for up to 4 problems in one launch, 64 rows per workgroup (many short rows), with the layouts of the joint step's
+ * modality-feature projections (Model.py:48-57,84-85,103):   out[r, c] += sum_k X[r, k] Fm(k, c) (+ bias[c], added once)
+ *   f_transposed:   Fm(k, c) = F[c * ldf + k]  (F is an nn.Linear weight [D, K]);  else F[k * ldf + c]
+ *   out_transposed: the result is stored at out[c * ldo + r]  (the weight gradient dW[D, F] = dfeat^T E  as  E^T[F, I] x dfeat[I, D])
+ * out must hold the value to accumulate into (K is cut into slices added with fp32 atomics); X rows readable up to round_up(K, 32). */
+typedef struct dmm_project_problem {
+  const float* X; int64_t ldx;
+  const float* F; int64_t ldf;
+  float* out; int64_t ldo;
+  const float* bias; /* [D] or NULL */
+  int32_t rows, K;
+} dmm_project_problem;
+int dmm_item_project_batched(const dmm_project_problem* p /*host array*/, int n, int D, int f_transposed, int out_transposed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Rebuild, second half: the modality graph of Main.py:232-253 (coo_matrix of the top-k edges -> DataHandler.makeTorchAdj,

@@ -721,6 +721,37 @@ def test_item_project_and_expand(dev, B, I, D):
     assert torch.equal(Rc[:, I:], R[:, I:])
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_item_project_batched_layouts(dev, D):
+    """dmm_item_project_batched (the joint step's modality projections and their weight gradients) against fp64 products of the bf16-rounded
+    operands: F given as an nn.Linear weight [D, K] with a bias (forward), the result stored transposed (weight gradient), three problems of
+    different K / rows in one launch, accumulation into a non-zero output."""
+    from diffmm_amd import ops
+    torch.manual_seed(D)
+    rows, Ks = 700, (128, 768, 96)
+    Xs = [torch.randn(rows, k, device=dev) for k in Ks]
+    Ws = [torch.randn(D, k, device=dev) * 0.1 for k in Ks]
+    bs = [torch.randn(D, device=dev) for _ in Ks]
+    outs = [torch.full((rows, D), 0.5, device=dev) for _ in Ks]
+    ops.item_project_batched([dict(X=Xs[i], F=Ws[i], out=outs[i], bias=bs[i], K=Ks[i]) for i in range(3)], D, f_transposed=True)
+    for i in range(3):
+        ref = 0.5 + Xs[i].bfloat16().double() @ Ws[i].bfloat16().double().t() + bs[i].double()
+        close(outs[i], ref, rtol=1e-5, atol=2e-4 * np.sqrt(Ks[i] / 64), what=f"projection {i}")
+    # weight gradient: E^T [F, I] x dfeat [I, D] -> dW [D, F]
+    I = 1000
+    Ip = (I + 31) // 32 * 32
+    ETs = [torch.zeros(k, Ip, device=dev) for k in Ks]
+    for t in ETs:
+        t[:, :I].normal_()
+        t[:, I:] = 7.0  # readable padding: ignored (the F operand has no rows there)
+    dfs = [torch.randn(I, D, device=dev) for _ in Ks]
+    dWs = [torch.zeros(D, k, device=dev) for k in Ks]
+    ops.item_project_batched([dict(X=ETs[i], F=dfs[i], out=dWs[i], K=I) for i in range(3)], D, out_transposed=True)
+    for i in range(3):
+        ref = (ETs[i][:, :I].bfloat16().double() @ dfs[i].bfloat16().double()).t()
+        close(dWs[i], ref, rtol=1e-5, atol=2e-4 * np.sqrt(I / 64), what=f"weight gradient {i}")
+
+
 def test_reverse_chains_on_streams_match_single_chain(dev):
     """generate_views_bf16 (one HIP stream per modality, shared x_0 copies, recorded launch plan) against the single-modality chain:
     the same arithmetic on the same operands -- equal up to the summation order of differently tiled GEMMs -- and bit-identical
