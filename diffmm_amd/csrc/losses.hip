@@ -91,24 +91,27 @@ __global__ __launch_bounds__(256) void scatter_normalize_bwd_kernel(SlotTable S,
   if (!grad) return;
   const int32_t* __restrict__ idx = S.idx[s];
   const int l = threadIdx.x % LANES;
+  // a lane owns columns l, l + LANES, l + 2 LANES, l + 3 LANES: every atomic instruction then covers one contiguous 4 LANES-byte segment per
+  // row (with 4 consecutive columns per lane it touched LANES scattered dwords of a 16 LANES-byte span: 60 -> ~25 us at B = 4096, 12 slots)
   for (int b = blockIdx.x * G + threadIdx.x / LANES; b < B; b += gridDim.x * G) {
-    const size_t off = ((size_t)s * B + b) * D + 4 * l;
-    const float4 g = *reinterpret_cast<const float4*>(dzhat + off);
-    const float4 y = *reinterpret_cast<const float4*>(zhat + off);
+    const size_t off = ((size_t)s * B + b) * D + l;
+    float g[4], y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { g[j] = dzhat[off + j * LANES]; y[j] = zhat[off + j * LANES]; }
     const float nrm = norm[(size_t)s * B + b];
-    float4 o;
+    float o[4];
     if (nrm < 1e-12f) {
-      o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = g[j] * 1e12f;
     } else {
-      const float dot = group_sum<LANES>(g.x * y.x + g.y * y.y + g.z * y.z + g.w * y.w);
+      const float dot = group_sum<LANES>(g[0] * y[0] + g[1] * y[1] + g[2] * y[2] + g[3] * y[3]);
       const float inv = 1.0f / nrm;
-      o = make_float4((g.x - y.x * dot) * inv, (g.y - y.y * dot) * inv, (g.z - y.z * dot) * inv, (g.w - y.w * dot) * inv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (g[j] - y[j] * dot) * inv;
     }
-    float* dst = grad + (size_t)idx[b] * D + 4 * l;
-    atomicAdd(dst + 0, o.x);
-    atomicAdd(dst + 1, o.y);
-    atomicAdd(dst + 2, o.z);
-    atomicAdd(dst + 3, o.w);
+    float* dst = grad + (size_t)idx[b] * D + l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(dst + j * LANES, o[j]);
   }
 }
 
@@ -127,10 +130,11 @@ __global__ __launch_bounds__(256) void rows_move_kernel(SlotTable S, int B, cons
   const int32_t* __restrict__ idx = S.idx[s];
   for (int b = b0 + blockIdx.x * G + threadIdx.x / LANES; b < b1; b += gridDim.x * G) {
     float* t = buf + ((size_t)s * B + b) * D + 4 * l;
-    if (SCATTER) {
-      float* dst = S.grad[s] + (size_t)idx[b] * D + 4 * l;
-      const float4 v = *reinterpret_cast<const float4*>(t);
-      atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+    if (SCATTER) {  // columns l + j LANES per lane: contiguous atomic segments (scatter_normalize_bwd_kernel)
+      float* dst = S.grad[s] + (size_t)idx[b] * D + l;
+      const float* ts = buf + ((size_t)s * B + b) * D + l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dst + j * LANES, ts[j * LANES]);
     } else {
       *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(S.src[s] + (size_t)idx[b] * D + 4 * l);
     }
@@ -668,22 +672,24 @@ __global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ fin_
   const int l = threadIdx.x % LANES;
   const float invB = 1.0f / (float)B;
   for (int b = blockIdx.x * G + threadIdx.x / LANES; b < B; b += gridDim.x * G) {
-    const size_t ou = (size_t)users[b] * D + 4 * l, op = (size_t)pos[b] * D + 4 * l, on = (size_t)neg[b] * D + 4 * l;
-    const float4 u = *reinterpret_cast<const float4*>(fin_u + ou);
-    const float4 p = *reinterpret_cast<const float4*>(fin_i + op);
-    const float4 n = *reinterpret_cast<const float4*>(fin_i + on);
-    const float sp = group_sum<LANES>(u.x * p.x + u.y * p.y + u.z * p.z + u.w * p.w);
-    const float sn = group_sum<LANES>(u.x * n.x + u.y * n.y + u.z * n.z + u.w * n.w);
+    // a lane owns columns l + j LANES (j = 0..3): each load and each atomic instruction covers one contiguous segment per row (see
+    // scatter_normalize_bwd_kernel)
+    const size_t ou = (size_t)users[b] * D + l, op = (size_t)pos[b] * D + l, on = (size_t)neg[b] * D + l;
+    float u[4], p[4], n[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u[j] = fin_u[ou + j * LANES]; p[j] = fin_i[op + j * LANES]; n[j] = fin_i[on + j * LANES]; }
+    const float sp = group_sum<LANES>(u[0] * p[0] + u[1] * p[1] + u[2] * p[2] + u[3] * p[3]);
+    const float sn = group_sum<LANES>(u[0] * n[0] + u[1] * n[1] + u[2] * n[2] + u[3] * n[3]);
     const float sg = 1.0f / (1.0f + expf(-(sp - sn)));
     if (l == 0) row_loss[b] = -logf(1e-5f + sg) * invB;
     if (dfin_u) {
       const float g = -(sg * (1.0f - sg)) / (1e-5f + sg) * invB;  // d row_loss / d (sp - sn)
-      atomicAdd(dfin_u + ou + 0, g * (p.x - n.x)); atomicAdd(dfin_u + ou + 1, g * (p.y - n.y));
-      atomicAdd(dfin_u + ou + 2, g * (p.z - n.z)); atomicAdd(dfin_u + ou + 3, g * (p.w - n.w));
-      atomicAdd(dfin_i + op + 0, g * u.x); atomicAdd(dfin_i + op + 1, g * u.y);
-      atomicAdd(dfin_i + op + 2, g * u.z); atomicAdd(dfin_i + op + 3, g * u.w);
-      atomicAdd(dfin_i + on + 0, -g * u.x); atomicAdd(dfin_i + on + 1, -g * u.y);
-      atomicAdd(dfin_i + on + 2, -g * u.z); atomicAdd(dfin_i + on + 3, -g * u.w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dfin_u + ou + j * LANES, g * (p[j] - n[j]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dfin_i + op + j * LANES, g * u[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dfin_i + on + j * LANES, -g * u[j]);
     }
   }
 }
