@@ -112,6 +112,7 @@ _SIGS = {
     "dmm_tanh_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "dmm_add_inplace": (C.c_int, [_P, _P, _F, _L, _P]),
     "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),
+    "dmm_colsum_add": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P]),
     "dmm_topk_rows": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _P]),
     "dmm_noised_start": (C.c_int, [_P, _L, _P, _F, _F, _P, _L, _I, _I, _U64, _U64, _P]),

@@ -381,13 +381,19 @@ extern "C" int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n,
   DMM_LAUNCH_CHECK("dmm_add_inplace");
   return 0;
 }
-extern "C" int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, void* stream) {
-  DMM_CHECK_ARG(x && out && rows > 0 && cols > 0, "dmm_colsum: bad arguments");
+static int colsum_launch(const char* who, const float* x, int64_t ldx, int rows, int cols, float* out, bool zero_first, void* stream) {
+  DMM_CHECK_ARG(x && out && rows > 0 && cols > 0, "%s: bad arguments", who);
   const int chunk = rows > 64 ? 64 : rows;
-  (void)hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+  if (zero_first) (void)hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), cdiv(rows, chunk)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, chunk, out);
-  DMM_LAUNCH_CHECK("dmm_colsum");
+  DMM_LAUNCH_CHECK(who);
   return 0;
+}
+extern "C" int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, void* stream) {
+  return colsum_launch("dmm_colsum", x, ldx, rows, cols, out, true, stream);
+}
+extern "C" int dmm_colsum_add(const float* x, int64_t ldx, int rows, int cols, float* out, void* stream) {
+  return colsum_launch("dmm_colsum_add", x, ldx, rows, cols, out, false, stream);
 }
 
 extern "C" int dmm_fill_zero(void* p, int64_t bytes, void* stream) {

@@ -93,7 +93,11 @@ class JointEngine:
         self.P = FlatParams(shapes, self.dev)
         N, M = self.N, self.M
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
-        self._feat_block = z(M, items, D)  # the projections are accumulated by K slices: one memset for all modalities
+        # everything a step fills by ACCUMULATION lives in one arena: one memset per step (scatter-added gradient rows, the InfoNCE row
+        # gradients, the K-sliced projections)
+        n_slots = 2 + 2 * M + 4
+        self._zero_arena = z((M + 3) * N * D + n_slots * B_max * D + M * items * D)
+        self._feat_block = self._zero_arena[(M + 3) * N * D + n_slots * B_max * D:].view(M, items, D)
         self.feat = [self._feat_block[m] for m in range(M)]
         # E_m^T [F_m, round_up(I, 32)] (constant): the weight gradient dW_m = dfeat_m^T E_m runs as E_m^T x dfeat_m on the item-space kernel
         self._featsT = None
@@ -102,7 +106,7 @@ class JointEngine:
         self.Z = [z(N, D) for _ in range(M)]
         self.Bx, self.X1p, self.Mx, self.Fin, self.X2p, self.X3p, self.CL1 = (z(N, D) for _ in range(7))
         # gradient accumulators filled by scatter-adds: one block, one memset per step
-        self.gblock = z(M + 3, N, D)
+        self.gblock = self._zero_arena[: (M + 3) * N * D].view(M + 3, N, D)
         self.dFin, self.dCl1, self.dCl2 = self.gblock[0], self.gblock[1], self.gblock[2]
         self.dZ = [self.gblock[3 + m] for m in range(M)]
         self.dMx, self.dX2p, self.dX1p, self.dBx = (z(N, D) for _ in range(4))
@@ -114,7 +118,7 @@ class JointEngine:
         self.n_slots = 2 + 2 * M + 4
         self.zhat = z(self.n_slots, B_max, D)
         self.znorm = z(self.n_slots, B_max)
-        self.dzhat = z(self.n_slots, B_max, D)
+        self.dzhat = self._zero_arena[(M + 3) * N * D: (M + 3) * N * D + self.n_slots * B_max * D].view(self.n_slots, B_max, D)
         self.mfma_cl = D in (32, 64, 128, 256)  # MFMA InfoNCE kernels; smaller widths use the fp32 VALU kernels
         self.pack = ops.infonce_pack(self.n_slots, B_max, D, self.dev) if self.mfma_cl else None
         pairs = M * (M - 1) // 2
@@ -175,10 +179,12 @@ class JointEngine:
                 self._featsT.append(t)
         return self._featsT
 
-    def _project(self, precision: int):
+    def _project(self, precision: int, zeroed: bool = False):
+        """zeroed: the caller has just cleared the whole accumulation arena (step()), the projections' block included."""
         names = modality_names(self.M)
         if self._feat_kernels(precision):  # skinny products (N = d): the item-space MFMA kernel, 64 rows per workgroup, all modalities in one launch
-            ops.zero_(self._feat_block)
+            if not zeroed:
+                ops.zero_(self._feat_block)
             ops.item_project_batched([dict(X=self.feats[m], F=self.P.view(f"{n}_layer.weight"), out=self.feat[m], bias=self.P.view(f"{n}_layer.bias"),
                                            K=self.feats[m].shape[1]) for m, n in enumerate(names)], self.D, f_transposed=True)
         else:  # Linear_m(E_m) of every modality in ONE launch of the generic GEMM
@@ -187,10 +193,10 @@ class JointEngine:
         for m in range(self.M):
             ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
 
-    def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3):
+    def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3, _arena_zeroed: bool = False):
         hp, A, emb = self.hp, self.adj, self.P.view("emb")
         nd = hp["noise_degree"]
-        self._project(precision)
+        self._project(precision, zeroed=_arena_zeroed)
         lanes = self.D // 4
         seed, base = hp.get("seed", 1818), self.rng_step * 3 * self.N * lanes
         nz = lambda k: dict(noise=noise[k]) if noise is not None else dict(noise=None, seed=seed, offset=base + k * self.N * lanes)
@@ -252,9 +258,8 @@ class JointEngine:
         assert B <= self.B_max
         if noise is None and update and self._philox_refs is None:
             return self._step_planned(users, pos, neg, precision)
-        ops.zero_(self.gblock)
-        ops.zero_(self.dzhat)
-        self.forward(noise=noise, with_cl=True, precision=precision)
+        ops.zero_(self._zero_arena)  # gradient rows filled by scatter-adds, InfoNCE row gradients, K-sliced projections: one memset
+        self.forward(noise=noise, with_cl=True, precision=precision, _arena_zeroed=True)
         slots, terms = self._slots_terms(users, pos)
         nT = self.n_terms
         zhat, znorm, dzhat = self.zhat[:, :B], self.znorm[:, :B], self.dzhat[:, :B]
@@ -299,7 +304,7 @@ class JointEngine:
             ops.gemm_batched([dict(A=self.dfeat[m], B=self.feats[m], out=self.P.g(f"{n}_layer.weight"), trans_a=True, precision=precision, split_k=128)
                               for m, n in enumerate(names)])
         for m, n in enumerate(names):
-            ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"))
+            ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"), add=True)  # (inside the region zeroed above)
         if update:
             self.apply_adam()
         self.rng_step += 1

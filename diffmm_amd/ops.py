@@ -535,8 +535,9 @@ def add_inplace(y: Tensor, x: Tensor, alpha: float = 1.0) -> None:
     L.call("dmm_add_inplace", L.ptr(y), L.ptr(x), alpha, y.numel(), L.stream())
 
 
-def colsum(x: Tensor, rows: int, cols: int, out: Tensor) -> None:
-    L.call("dmm_colsum", L.ptr(x), x.stride(0), rows, cols, L.ptr(out), L.stream())
+def colsum(x: Tensor, rows: int, cols: int, out: Tensor, add: bool = False) -> None:
+    """out[c] = sum_r x[r, c]; add=True: accumulated into out (which the caller has zeroed: no memset launch)."""
+    L.call("dmm_colsum_add" if add else "dmm_colsum", L.ptr(x), x.stride(0), rows, cols, L.ptr(out), L.stream())
 
 
 def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, gscale: float,

@@ -420,7 +420,7 @@ class ShardedJointEngine:
                 ops.gemm_batched([dict(A=self.dfeat[m][i0:i1], B=self.feats[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), trans_a=True, precision=precision,
                                        split_k=128) for m, nm in enumerate(names)])
             for m, nm in enumerate(names):
-                ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, self.P.g(f"{nm}_layer.bias"))
+                ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, self.P.g(f"{nm}_layer.bias"), add=True)  # (inside the region zeroed above)
         self._exchange_end()
         ops.spmm_epilogue_rows(arr_b, 1, D)
         self._ar(self.P.grad[ne:])  # projections + modal_weight: partial sums over disjoint node sets

@@ -305,6 +305,8 @@ int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* 
 int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n, void* stream);   /* y += alpha * x */
 int dmm_fill_zero(void* p, int64_t bytes, void* stream);                                /* hipMemsetAsync(p, 0, bytes) */
 int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out /*[cols], overwritten*/, void* stream);
+/* the same sums ADDED to out (no memset launch: for outputs inside a region the caller has just zeroed, e.g. the bias gradients of nn.Linear) */
+int dmm_colsum_add(const float* x, int64_t ldx, int rows, int cols, float* out /*[cols], accumulated into*/, void* stream);
 /* Diffusion loss, Model.py:407-425.  per row b: mse_b = mean_j (out - x0)^2; cos_b = cosine(um_b, ui_b);
  * loss_b = w_b * mse_b + sim_weight * (1 - cos_b) + reg_term  (float64 out, like the reference).
  * Also emits d loss / d out (the direct MSE part) and d loss / d um scaled by gscale (= 1 / (B * total)). */
