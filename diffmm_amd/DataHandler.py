@@ -114,8 +114,10 @@ class TrainData:
         return self._rows_d[idx].contiguous(), self._cols_d[idx].contiguous(), self._negs_d[idx].contiguous()
 
     def epoch(self, perm: torch.Tensor):
-        """The whole shuffled epoch: (users, positives, negatives) gathered once; the loader slices minibatches out of them."""
-        return self._rows_d[perm].contiguous(), self._cols_d[perm].contiguous(), self._negs_d[perm].contiguous()
+        """The whole shuffled epoch: (users, positives, negatives) gathered once into the rows of ONE [3, E] tensor; the loader slices
+        minibatches out of them (and the engine, seeing three equally spaced views of one buffer, moves a minibatch with one copy)."""
+        rec = torch.stack([self._rows_d[perm], self._cols_d[perm], self._negs_d[perm]])
+        return rec[0], rec[1], rec[2]
 
 
 class TestData:

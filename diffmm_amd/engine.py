@@ -130,8 +130,8 @@ class JointEngine:
         self.adj: Optional[Adjacency] = None
         self.modal_adj: List[Adjacency] = []
         self.rng_step = 0
-        zi = lambda: torch.zeros(B_max, dtype=torch.int32, device=self.dev)
-        self.users_s, self.pos_s, self.neg_s = zi(), zi(), zi()  # static index buffers of the recorded launch plans
+        self._batch_s = torch.zeros(3, B_max, dtype=torch.int32, device=self.dev)  # static index buffers of the recorded launch plans
+        self.users_s, self.pos_s, self.neg_s = self._batch_s[0], self._batch_s[1], self._batch_s[2]
         self._plans: Dict[tuple, dict] = {}
         self._philox_refs: Optional[list] = None
 
@@ -331,7 +331,7 @@ class JointEngine:
             self.rng_step -= 1  # recording ran step()'s bookkeeping once without launching anything
             self.P.step -= 1
             self._plans[key] = plan
-        self.users_s[:B].copy_(users); self.pos_s[:B].copy_(pos); self.neg_s[:B].copy_(neg)
+        self._set_batch(users, pos, neg)
         lanes = self.D // 4
         base = self.rng_step * 3 * self.N * lanes
         for arr, i, k in plan["philox"]:
@@ -342,6 +342,17 @@ class JointEngine:
         L.replay(plan["calls"])
         self.rng_step += 1
         return self.loss_parts
+
+    def _set_batch(self, users: Tensor, pos: Tensor, neg: Tensor):
+        """The minibatch into the plans' static index buffers: one strided copy when the three arrays are equally spaced int32 views of one
+        buffer (the loader's per-epoch record, TrainData.epoch), else one copy each."""
+        B = int(users.shape[0])
+        d1, d2 = pos.data_ptr() - users.data_ptr(), neg.data_ptr() - pos.data_ptr()
+        if users.dtype == pos.dtype == neg.dtype == torch.int32 and d1 == d2 and d1 > 0 and d1 % 4 == 0 and users.is_contiguous() and pos.is_contiguous() and \
+                neg.is_contiguous() and users.untyped_storage().data_ptr() == neg.untyped_storage().data_ptr():
+            self._batch_s[:, :B].copy_(torch.as_strided(users, (3, B), (d1 // 4, 1)))
+        else:
+            self.users_s[:B].copy_(users); self.pos_s[:B].copy_(pos); self.neg_s[:B].copy_(neg)
 
     def apply_adam(self):
         P, U, D = self.P, self.U, self.D
