@@ -525,7 +525,7 @@ struct LatentP {
 struct LatentBatch {
   LatentP p[GB_MAX_BATCH];
   const float* coef;  // [2 T]: coef[2 i] = c1[i] (h' = tanh(c1[i] a + bias_t[i - 1])), coef[2 i + 1] = c2[i - 1] c1[i] / c1[i - 1] (a <- that * a + g)
-  int* flags;         // [n_groups] counters (zero on entry), flags[err_at] = error word
+  int* flags;         // [0, 256): group counters, [256, 512): per-group XCC-id masks (both zero on entry), flags[err_at] = error word
   float s_init;       // c2[T - 1] / c1[T - 1]
   int rows, H, T, rbs, g0, n_groups, err_at;
 };
@@ -549,6 +549,11 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
   __bf16* const hbuf[2] = {P.ha, P.hb};
   int* const flag = Lb.flags + gl;
   int* const err = Lb.flags + Lb.err_at;
+  // placement check: the members of a group are expected on ONE XCD (they re-read each other's h' from its L2).  Every member ORs its
+  // XCC id into the group's mask before its first arrival; after the first barrier a mask with more than one bit sets error word bit 1
+  // (the hand-off below is agent-scope and stays correct across XCDs; the bit reports that the speed assumption did not hold).
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_or(Lb.flags + 256 + gl, 1 << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   const __bf16* offA[2][2];  // [unit][load] into h_a; h_b is `hdelta` elements further
   const __bf16* offY[2][2];
@@ -632,7 +637,11 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > LATENT_SPIN_MAX) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > LATENT_SPIN_MAX) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      if (step == 0) {
+        const int mask = __hip_atomic_load(Lb.flags + 256 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mask & (mask - 1)) __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -659,7 +668,7 @@ int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
     LatentBatch b = base;
     b.g0 = g0;
     b.n_groups = std::min(per, total - g0);
-    hipError_t e = hipMemsetAsync(b.flags, 0, sizeof(int) * b.n_groups, s);
+    hipError_t e = hipMemsetAsync(b.flags, 0, sizeof(int) * 512, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(latent_chain_8ph_kernel, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
   }
@@ -702,7 +711,7 @@ extern "C" int dmm_latent_chain(const dmm_latent_chain_args* a, int n_mod, int r
   using namespace dmm;
   DMM_CHECK_ARG(a && coef && flags && n_mod >= 1 && n_mod <= GB_MAX_BATCH && rows > 0 && T >= 1, "dmm_latent_chain: bad arguments");
   DMM_CHECK_ARG(H >= 256 && H % 256 == 0 && H <= 2048, "dmm_latent_chain: H=%d must be a multiple of 256 in 256..2048", H);
-  DMM_CHECK_ARG(flags_len >= 258, "dmm_latent_chain: flags needs 258 int32 entries (256 group counters, a spare, the error word)");
+  DMM_CHECK_ARG(flags_len >= 514, "dmm_latent_chain: flags needs 514 int32 entries (256 group counters, 256 placement masks, a spare, the error word)");
   if (T == 1) return 0;  // h_0 = h_{T-1}: nothing to do
   LatentBatch b;
   memset(&b, 0, sizeof(b));

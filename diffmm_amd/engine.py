@@ -866,8 +866,14 @@ class DiffusionEngine:
     def check_chain_error(self):
         """Raises if a group barrier of the persistent latent-chain kernel ever timed out (its results would be invalid).  Reads one device
         word: call it where the host synchronises anyway (the trainer does, once per epoch)."""
-        if self._lat is not None and int(self._lat["flags"][-1]) != 0:
-            raise RuntimeError("dmm_latent_chain: a group barrier timed out -- the rebuilt views of this epoch are invalid")
+        if self._lat is not None:
+            e = int(self._lat["flags"][-1])
+            if e & 1:
+                raise RuntimeError("dmm_latent_chain: a group barrier timed out -- the rebuilt views of this epoch are invalid")
+            if e & 2 and not getattr(self, "_warned_xcd", False):
+                self._warned_xcd = True
+                import warnings
+                warnings.warn("dmm_latent_chain: the workgroups of a group were placed on different XCDs (results are valid; h is re-read across XCDs)")
 
     def _latent_alloc(self):
         if self._lat is not None:
@@ -878,7 +884,7 @@ class DiffusionEngine:
         self._lat = dict(za=[z(R, H) for _ in range(M)], zb=[z(R, H) for _ in range(M)], hb=[zb(R, H) for _ in range(M)], G32=z(3, H, H),
                          G16=[zb(H, H) for _ in range(M)], g=[z(H) for _ in range(M)], b2_last=[z(I) for _ in range(M)],
                          w1lo=zb(H, self.Kp), w2Thi=zb(H, self.Kp), w2Tlo=zb(H, self.Kp),  # (scratch of the once-per-epoch G refresh)
-                         flags=torch.zeros(258, dtype=torch.int32, device=self.dev))
+                         flags=torch.zeros(514, dtype=torch.int32, device=self.dev))
         # per-step scalars of the persistent kernel (fp64 on the host, then fp32): coef[2 i] = c1[i], coef[2 i + 1] = c2[i-1] c1[i] / c1[i-1]
         c1, c2, T = np.asarray(self.sched["posterior_mean_coef1"], dtype=np.float64), np.asarray(self.sched["posterior_mean_coef2"], dtype=np.float64), self.T
         coef = np.zeros(2 * T, dtype=np.float64)

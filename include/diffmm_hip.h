@@ -153,8 +153,9 @@ int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* a /*host array*/, int n_b
  * bias_t[t-1]).  On entry z holds z_T (fp32) and h_a holds h_{T-1} (bf16); the T - 1 steps t = T-1 .. 1 run inside the kernel with z in registers
  * (it is never written back) and h exchanged through h_a / h_b; on return h_0 is in h_a when T - 1 is even, else in h_b.  The caller then forms
  * x_0' = c1[0] (h_0 W2^T + b2) with dmm_gemm_bf16_nt.  coef (device, [2 T]): coef[2 t] = c1[t], coef[2 t + 1] = c2[t-1] c1[t] / c1[t-1];
- * s_init = c2[T-1] / c1[T-1].  flags: device int32 scratch, >= 258 entries; flags[flags_len - 1] is an error word the kernel sets to 1 if a group
- * barrier timed out (the results are then invalid; it never hangs).  H must be a multiple of 256 (<= 2048). */
+ * s_init = c2[T-1] / c1[T-1].  flags: device int32 scratch, >= 514 entries; flags[flags_len - 1] is an error word: bit 0 = a group barrier timed
+ * out (the results are then invalid; the kernel never hangs), bit 1 = the workgroups of a group did not share an XCD (results valid, the kernel's
+ * L2 re-read assumption did not hold).  H must be a multiple of 256 (<= 2048). */
 typedef struct dmm_latent_chain_args {
   const void* G; int64_t ldg;      /* bf16 [H, H] */
   const float* g;                  /* [H] */

@@ -157,15 +157,25 @@ def test_checkpoint_resume_continues_the_run(tmp_path, sampling_step):
     assert b.epoch_idx == 1 and b.best == a.best and b.his_max == a.his_max
     assert b.diff_engine._xT_calls == (a.M if sampling_step else 0), "Philox position of the noised chain starts"
     res_b = b.trainEpoch()
+    # Two runs from one state differ by the summation order of fp32 atomics (measured: weights 1e-8 .. 3e-7, losses 1e-8 relative, identical
+    # graphs in 5 runs of 6) -- unless that noise flips a near-tie of the rebuild's top-k, which one run in six showed: then a few EDGES differ
+    # and the epoch's weights follow (measured 2.7e-4, losses 3e-5).  The bars admit such a flip, not a lost optimiser / generator state
+    # (which moves the losses by per cent and the graphs wholesale).
     for k in res_a:
-        assert abs(res_a[k] - res_b[k]) <= 1e-4 * abs(res_a[k]) + 1e-7, (k, res_a[k], res_b[k])
+        assert abs(res_a[k] - res_b[k]) <= 1e-3 * abs(res_a[k]) + 1e-7, (k, res_a[k], res_b[k])
     for (na, pa), (nb, pb) in zip(a._flat_models(), b._flat_models()):
         assert pa.step == pb.step
         d = float((pa.data - pb.data).abs().max())
-        assert d <= 1e-4, f"{na}: weights differ by {d:.3e} after the resumed epoch"
+        assert d <= 2e-3, f"{na}: weights differ by {d:.3e} after the resumed epoch"
     for ea, eb in zip([a.image_adj, a.text_adj, a.audio_adj], [b.image_adj, b.text_adj, b.audio_adj]):
-        same = float((ea.col == eb.col).float().mean())
-        assert same > 0.99, f"rebuilt graphs agree on {same:.4f} of their entries"
+        def edge_keys(adj):  # (row, column) pairs as one integer each: an edge SET (a flipped edge shifts every later position of its row)
+            counts = (adj.rowptr[1:] - adj.rowptr[:-1]).long()
+            rows = torch.repeat_interleave(torch.arange(counts.numel(), device=adj.col.device), counts)
+            return rows * int(counts.numel()) + adj.col.long()
+        ka, kb = edge_keys(ea), edge_keys(eb)
+        assert ka.numel() == kb.numel()
+        same = float(torch.isin(ka, kb).float().mean())
+        assert same > 0.99, f"rebuilt graphs share {same:.4f} of their edges"
 
 
 @pytest.mark.parametrize("fx", ["epoch_mid", "epoch_mid_M2"])
