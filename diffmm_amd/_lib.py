@@ -51,6 +51,12 @@ class ProjectProblem(C.Structure):
                 ("rows", C.c_int32), ("K", C.c_int32)]
 
 
+class ExpandFusedArgs(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("F", C.c_void_p), ("ldf", C.c_int64), ("R", C.c_void_p), ("ldr", C.c_int64), ("X0", C.c_void_p),
+                ("ldx0", C.c_int64), ("w", C.c_void_p), ("gscale", C.c_double), ("Y16", C.c_void_p), ("ldy", C.c_int64), ("YT", C.c_void_p), ("ldt", C.c_int64),
+                ("csum", C.c_void_p), ("B", C.c_int32), ("I", C.c_int32), ("Kc", C.c_int32), ("Kt", C.c_int32)]
+
+
 class GatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("grad", C.c_void_p)]
 
@@ -119,6 +125,7 @@ _SIGS = {
     "dmm_item_project": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_item_project_batched": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _I, _I, _P]),
     "dmm_item_expand": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
+    "dmm_item_expand_fused": (C.c_int, [C.POINTER(ExpandFusedArgs), _I, _I, _P]),
     "dmm_graph_build_scratch_bytes": (C.c_int, [_I, _I, _L, _I, _P]),
     "dmm_graph_build_task_capacity": (C.c_int, [_I, _I, _L, _I, _I, _P, _P]),
     "dmm_graph_build": (C.c_int, [_P, _P, _P, _I, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -244,10 +244,12 @@ __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict_
   const double wb = w[b];
   const float gcoef = (float)(gscale * wb * 2.0 / (double)I);
   double a = 0.0;
-  for (int j = threadIdx.x; j < I; j += 256) {
-    const float df = o[j] - x[j];
-    a += (double)(df * df);
-    if (dout) dout[(long long)b * ld + j] = gcoef * df;
+  if (loss || dout) {  // (loss == NULL and dout == NULL: only d loss / d um is wanted -- the rows are not read at all)
+    for (int j = threadIdx.x; j < I; j += 256) {
+      const float df = o[j] - x[j];
+      a += (double)(df * df);
+      if (dout) dout[(long long)b * ld + j] = gcoef * df;
+    }
   }
   const double sse = block_sum_256d(a, smd);
   // cosine similarity of the two d-vectors
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict_
   ni = sqrtf(block_sum_256(ni, smf));
   const float cu = fmaxf(nu, 1e-8f), ci = fmaxf(ni, 1e-8f);
   const float cosv = dot / (cu * ci);
-  if (threadIdx.x == 0) loss[b] = wb * (sse / (double)I) + (double)sim_weight * (1.0 - (double)cosv) + reg_term;
+  if (threadIdx.x == 0 && loss) loss[b] = wb * (sse / (double)I) + (double)sim_weight * (1.0 - (double)cosv) + reg_term;
   if (dum) {
     const float gs = (float)gscale * sim_weight;
     for (int c = threadIdx.x; c < d; c += 256) {
@@ -817,7 +819,7 @@ extern "C" int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, i
 
 extern "C" int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w, const float* um, const float* ui, int B, int I, int d,
                              float sim_weight, double reg_term, double gscale, double* loss, float* dout, float* dum, void* stream) {
-  DMM_CHECK_ARG(out && x0 && w && um && ui && loss && B > 0 && I > 0 && d > 0, "dmm_diff_loss: bad arguments");
+  DMM_CHECK_ARG(out && x0 && w && um && ui && (loss || dum) && B > 0 && I > 0 && d > 0, "dmm_diff_loss: bad arguments");
   hipLaunchKernelGGL(diff_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, x0, (long long)ld, w, um, ui, I, d, sim_weight, reg_term,
                      gscale, loss, dout, dum);
   DMM_LAUNCH_CHECK("dmm_diff_loss");

@@ -251,6 +251,147 @@ __global__ __launch_bounds__(256) void item_expand_kernel(const float* __restric
     }
 }
 
+// ---- expand, fused with what consumes it in the diffusion training step -----------------------------------------------------------------
+// Same tile and product as item_expand_kernel; the [B, I] result is not written in fp32 at all but as the two bf16 operands the next GEMMs
+// read: row-major Y16[B, Kc] and transposed YT[Kt, Bp] (through an LDS tile: 128-byte segments).  Two residual sources:
+//   MODE 0 (forward, Model.py:209):   v = R[b, c] + (P F^T)[b, c] for c < I,  v = R[b, c] for I <= c < Kc (the time-embedding / pad columns
+//                                     of [x_t | temb | 0]): replaces item_expand + cast + transpose-cast (6 passes over [B, I] -> 3)
+//   MODE 1 (backward, Model.py:418-428):  v = gscale w[b] 2/I (out[b, c] - x0[b, c]) + (dum F^T)[b, c] for c < I, 0 beyond -- the gradient of the
+//                                     diffusion loss w.r.t. the Denoise output, never materialised in fp32; also its column sums (the
+//                                     output layer's bias gradient, fp32 atomics into a zeroed vector): replaces diff_loss(dout) +
+//                                     item_expand + transpose-cast + colsum + cast (13 passes -> 4)
+// Rows b >= B of the tile (up to Bp, a multiple of 64) are written as zeros into YT.
+struct ExpandFusedP {
+  const float* P; long long ldp;    // [B, D]
+  const float* F; long long ldf;    // [I, D]
+  const float* R; long long ldr;    // MODE 0: residual rows; MODE 1: `out` rows
+  const float* X0; long long ldx0;  // MODE 1: x_0 rows
+  const double* w; double gscale;   // MODE 1: per-row loss weights
+  __bf16* Y16; long long ldy;       // [B, >= Kc]
+  __bf16* YT; long long ldt;        // [Kt, >= Bp]
+  float* csum;                      // MODE 1: [I]
+  int B, I, Kc, Kt;
+};
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFusedP A) {
+  constexpr int KS = D / 32;
+  constexpr int TLD = 72;  // bf16 elements per column of the transposed tile (64 rows + 8: 16-byte aligned, conflict-poor)
+  __shared__ __attribute__((aligned(16))) __bf16 tt[256 * TLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.y * 64, colw = blockIdx.x * 256, col0 = colw + wave * 64;
+  const int B = A.B, I = A.I, Kc = A.Kc;
+  // residual first: 16 float4 per lane in flight while the operands are fetched and multiplied
+  float4 rr[4][4];
+  float gc[4];
+  if (MODE == 1) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int row = row0 + rt * 16 + fr;
+      gc[rt] = row < B ? (float)(A.gscale * A.w[row] * 2.0 / (double)I) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
+      rr[ct][rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int lim = MODE == 0 ? Kc : I;
+      if (row < B && col < lim) {
+        const float* p = A.R + (long long)row * A.ldr + col;
+        if (col + 3 < lim) rr[ct][rt] = *reinterpret_cast<const float4*>(p);
+        else {
+          rr[ct][rt].x = p[0];
+          if (col + 1 < lim) rr[ct][rt].y = p[1];
+          if (col + 2 < lim) rr[ct][rt].z = p[2];
+        }
+      }
+    }
+  if (MODE == 1) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float4 xx[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
+        xx[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < B && col < I) {
+          const float* p = A.X0 + (long long)row * A.ldx0 + col;
+          if (col + 3 < I) xx[rt] = *reinterpret_cast<const float4*>(p);
+          else {
+            xx[rt].x = p[0];
+            if (col + 1 < I) xx[rt].y = p[1];
+            if (col + 2 < I) xx[rt].z = p[2];
+          }
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        float4& r = rr[ct][rt];
+        r = make_float4(gc[rt] * (r.x - xx[rt].x), gc[rt] * (r.y - xx[rt].y), gc[rt] * (r.z - xx[rt].z), gc[rt] * (r.w - xx[rt].w));
+      }
+    }
+  }
+  bf16x8 ff[4][KS], fp[4][KS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* f = A.F + (long long)min(col0 + t * 16 + fr, I - 1) * A.ldf + ks * 32 + kg * 8;
+      const float* p = A.P + (long long)min(row0 + t * 16 + fr, B - 1) * A.ldp + ks * 32 + kg * 8;
+      ff[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
+      fp[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+    }
+  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], acc, 0, 0, 0);
+      // acc[r] = (item column col0 + ct*16 + kg*4 + r, row row0 + rt*16 + fr)
+      const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
+      const float4 r4 = rr[ct][rt];
+      float v[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (col + j < I) v[j] += acc[j];
+        if (row >= B) v[j] = 0.f;
+        cs[j] += v[j];
+      }
+      const bf16x4v b4 = bf16x4v{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      if (row < B && col < Kc) {  // Kc % 4 == 0 and 8-byte aligned rows (checked on the host)
+        *reinterpret_cast<bf16x4v*>(A.Y16 + (long long)row * A.ldy + col) = b4;
+      }
+      const int cl = wave * 64 + ct * 16 + kg * 4, rl = rt * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tt[(cl + j) * TLD + rl] = b4[j];
+    }
+    if (MODE == 1) {  // column sums over the tile's 64 rows: reduce over fr (the 16 lanes of a kg group), then one atomic per column
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float c = cs[j];
+        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+        const int col = col0 + ct * 16 + kg * 4 + j;
+        if (fr == 0 && col < I) atomicAdd(A.csum + col, c);
+      }
+    }
+  }
+  __syncthreads();
+  // transposed copy: thread t owns tile column t = 64 consecutive batch rows = 128 bytes of YT's row colw + t
+  const int c = colw + threadIdx.x;
+  if (c < A.Kt) {
+    const uint4* src = reinterpret_cast<const uint4*>(tt + threadIdx.x * TLD);
+    uint4* dst = reinterpret_cast<uint4*>(A.YT + (long long)c * A.ldt + row0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = src[i];
+  }
+}
+
 }  // namespace dmm
 using namespace dmm;
 
@@ -323,5 +464,32 @@ extern "C" int dmm_item_expand(const float* P, int64_t ldp, const float* F, int6
   if (D == 64) hipLaunchKernelGGL(item_expand_kernel<64>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
   else hipLaunchKernelGGL(item_expand_kernel<128>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
   DMM_LAUNCH_CHECK("dmm_item_expand");
+  return 0;
+}
+
+extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, int D, void* stream) {
+  DMM_CHECK_ARG(a && (mode == 0 || mode == 1), "dmm_item_expand_fused: mode must be 0 (forward) or 1 (loss gradient)");
+  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_expand_fused: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(a->P && a->F && a->R && a->Y16 && a->YT && a->B > 0 && a->I > 0 && a->Kc >= a->I && a->Kc % 4 == 0 && a->Kt > 0 && a->Kt <= a->Kc,
+                "dmm_item_expand_fused: bad arguments");
+  DMM_CHECK_ARG(mode == 0 || (a->X0 && a->w && a->csum), "dmm_item_expand_fused: mode 1 needs x0, w and csum");
+  const int Bp = (a->B + 63) & ~63;
+  DMM_CHECK_ARG(a->ldp % 4 == 0 && a->ldf % 4 == 0 && a->ldr % 4 == 0 && (mode == 0 || a->ldx0 % 4 == 0) && a->ldy % 4 == 0 && a->ldy >= a->Kc && a->ldt % 8 == 0 &&
+                    a->ldt >= Bp && (mode == 1 || a->ldr >= a->Kc) &&
+                    (((uintptr_t)a->P | (uintptr_t)a->F | (uintptr_t)a->R | (uintptr_t)a->X0 | (uintptr_t)a->YT) & 15) == 0 && ((uintptr_t)a->Y16 & 7) == 0,
+                "dmm_item_expand_fused: operands must be 16-byte aligned (Y16: 8) with leading dimensions that are multiples of 4 (YT: of 8, >= round_up(B, 64))");
+  ExpandFusedP p;
+  p.P = a->P; p.ldp = a->ldp; p.F = a->F; p.ldf = a->ldf; p.R = a->R; p.ldr = a->ldr; p.X0 = a->X0; p.ldx0 = a->ldx0; p.w = a->w; p.gscale = a->gscale;
+  p.Y16 = (__bf16*)a->Y16; p.ldy = a->ldy; p.YT = (__bf16*)a->YT; p.ldt = a->ldt; p.csum = a->csum; p.B = a->B; p.I = a->I; p.Kc = a->Kc; p.Kt = a->Kt;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((a->Kc + 255) / 256, Bp / 64);
+  if (D == 64) {
+    if (mode == 0) hipLaunchKernelGGL((item_expand_fused_kernel<64, 0>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((item_expand_fused_kernel<64, 1>), grid, dim3(256), 0, s, p);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((item_expand_fused_kernel<128, 0>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((item_expand_fused_kernel<128, 1>), grid, dim3(256), 0, s, p);
+  }
+  DMM_LAUNCH_CHECK("dmm_item_expand_fused");
   return 0;
 }

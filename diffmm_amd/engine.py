@@ -580,6 +580,11 @@ class DiffusionEngine:
         """The dedicated item-space kernels (csrc/itemspace.hip) cover the bf16 single-product mode at d = 64 / 128."""
         return precision == 1 and self.D in (64, 128)
 
+    def _fused_expand(self) -> bool:
+        """The batched bf16 training step writes the expand results straight into the next GEMMs' bf16 operands (dmm_item_expand_fused);
+        hp fused_expand / DMM_FUSED_EXPAND=0 keeps the separate expand / cast / transpose / column-sum passes."""
+        return self._item_kernels(1) and bool(self.hp.get("fused_expand", os.environ.get("DMM_FUSED_EXPAND", "1") != "0"))
+
     def _project_items(self, X: Tensor, F: Tensor, out: Tensor, precision: int):
         """out = X[:, :I] @ F"""
         if precision == 1:
@@ -685,14 +690,17 @@ class DiffusionEngine:
         for m in range(M):
             a, P = self.act[m], self.P[m]
             ops.mul(a["proj"][:B], a["gate"][:B], a["pg"][:B])
-            if self._item_kernels(1):
+            if self._fused_expand():  # x_t += (proj * gate) F^T written only as layer 1's bf16 operand and its transposed copy (the backward's)
+                ops.item_expand_fused(a["pg"][:B], feats[m], a["xcat"][:B], W[m]["xa16"][:B], W[m]["xcatT16"], I, self.Kp, self.Kp)
+            elif self._item_kernels(1):
                 ops.item_expand(a["pg"][:B], feats[m], a["xcat"][:B], a["xcat"][:B], I)  # x_t += (proj * gate) F^T
             else:
                 ops.gemm(a["pg"][:B], feats[m], out=a["xcat"][:B], trans_b=True, residual=a["xcat"][:B], e1=1.0, e2=1.0, precision=1, N=I)
             ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
             ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
             self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
-            ops.cast_bf16(a["xcat"][:B], W[m]["xa16"][:B])
+            if not self._fused_expand():
+                ops.cast_bf16(a["xcat"][:B], W[m]["xa16"][:B])
         ops.gemm_bf16_nt_batched([dict(A=W[m]["xa16"][:B], B=self.w1_16[m], out=self.act[m]["h"][:B], out_bf16=W[m]["h16"][:B],
                                        bias=self.P[m].view("in_layers.0.bias"), act=L.ACT_TANH) for m in range(M)])
         if self.mids:
@@ -718,17 +726,25 @@ class DiffusionEngine:
             # entry of the 55 MB flat gradient buffer is overwritten by its GEMM / column sum
             ops.zero_(P.grad[: P.offsets["in_layers.0.weight"]])
             ops.zero_(P.g("gate_layer.weight"))
-            ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
-                          w["dum"][:B])
-            if self._item_kernels(1):
-                ops.item_expand(w["dum"][:B], feats[m], w["dout"][:B], w["dout"][:B], I)                                    # dout += dum F^T
-            else:
-                ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)
-            ops.transpose_cast_bf16(w["dout"][:B], w["doutT16"], rows=B, cols=I, rows_pad=Bp)      # dout^T [I, B]
             a_last = a["mid"][-1][:B] if self.mids else a["h"][:B]                                 # input of the last layer
+            if self._fused_expand():
+                # dout = d loss / d out (MSE part) + dum F^T is never written in fp32: one kernel forms it and emits dout (bf16), dout^T (bf16)
+                # and its column sums (the output bias gradient, into the zeroed vector)
+                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, None, None, w["dum"][:B])
+                ops.zero_(P.g(self.L2 + ".bias"))
+                ops.item_expand_fused(w["dum"][:B], feats[m], a["out"][:B], w["xb16"][:B], w["doutT16"], I, self.Kp, I, x0=x0p, w=a["w"], gscale=gscale,
+                                      csum=P.g(self.L2 + ".bias"))
+            else:
+                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
+                              w["dum"][:B])
+                if self._item_kernels(1):
+                    ops.item_expand(w["dum"][:B], feats[m], w["dout"][:B], w["dout"][:B], I)                                    # dout += dum F^T
+                else:
+                    ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)
+                ops.transpose_cast_bf16(w["dout"][:B], w["doutT16"], rows=B, cols=I, rows_pad=Bp)      # dout^T [I, B]
+                ops.colsum(w["dout"][:B], B, I, P.g(self.L2 + ".bias"))
+                ops.cast_bf16(w["dout"][:B], w["xb16"][:B])                                             # dout (pad columns are zero)
             ops.transpose_cast_bf16(a_last, w["hT16"], rows=B, cols=H, rows_pad=Bp)                # h^T    [H, B]
-            ops.colsum(w["dout"][:B], B, I, P.g(self.L2 + ".bias"))
-            ops.cast_bf16(w["dout"][:B], w["xb16"][:B])                                             # dout (pad columns are zero)
             ops.transpose_cast_bf16(P.view(self.L2 + ".weight"), w["w2T16"], rows=I, cols=H)     # W2^T   [H, I -> Kp]
         ops.gemm_bf16_nt_batched([dict(A=W[m]["doutT16"][:, :Bp], B=W[m]["hT16"][:, :Bp], out=self.P[m].g(self.L2 + ".weight"), N=H, K=Bp)
                                   for m in range(M)])                                               # dW2 = dout^T h
@@ -738,7 +754,8 @@ class DiffusionEngine:
             dh = self._mids_bwd(m, a["h"][:B], w["dh"][:B], 1) if self.mids else w["dh"][:B]
             ops.tanh_bwd(dh, a["h"][:B], w["dpre"][:B])
             ops.transpose_cast_bf16(w["dpre"][:B], w["dpreT16"], rows=B, cols=H, rows_pad=Bp)      # dpre^T [H, B]
-            ops.transpose_cast_bf16(a["xcat"][:B], w["xcatT16"], rows=B, cols=Kp, rows_pad=Bp)     # xcat^T [Kp, B]
+            if not self._fused_expand():  # (fused: written by the forward's expand kernel)
+                ops.transpose_cast_bf16(a["xcat"][:B], w["xcatT16"], rows=B, cols=Kp, rows_pad=Bp) # xcat^T [Kp, B]
             ops.colsum(w["dpre"][:B], B, H, P.g("in_layers.0.bias"))
             ops.cast_bf16(w["dpre"][:B], w["dpre16"][:B])
             ops.transpose_cast_bf16(P.view("in_layers.0.weight"), w["w1T16"], rows=H, cols=Kp)     # W1^T   [Kp, H]

@@ -541,11 +541,12 @@ def colsum(x: Tensor, rows: int, cols: int, out: Tensor, add: bool = False) -> N
 
 
 def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, gscale: float,
-              loss: Tensor, dout: Optional[Tensor], dum: Optional[Tensor]) -> None:
+              loss: Optional[Tensor], dout: Optional[Tensor], dum: Optional[Tensor]) -> None:
+    """loss None and dout None: only dum (the gradient through the similarity term) is computed; the [B, I] rows are not read."""
     B, d = um.shape
     if out.stride(0) != x0.stride(0) or (dout is not None and dout.stride(0) != out.stride(0)):
         raise ValueError("diff_loss: out, x0 and dout must share one leading dimension")
-    if w.dtype != torch.float64 or loss.dtype != torch.float64:
+    if w.dtype != torch.float64 or (loss is not None and loss.dtype != torch.float64):
         raise ValueError("diff_loss: w and loss are float64")
     L.call("dmm_diff_loss", L.ptr(out), L.ptr(x0), out.stride(0), L.ptr(w), L.ptr(um), L.ptr(ui), B, I, d, sim_weight, reg_term, gscale,
                                   L.ptr(loss), L.ptr(dout), L.ptr(dum), L.stream())
@@ -618,6 +619,29 @@ def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:
     if F.shape[0] < I or F.shape[1] != D or R.shape[0] < B or Y.shape[0] < B or R.shape[1] < I or Y.shape[1] < I:
         raise ValueError("item_expand: shape mismatch")
     L.call("dmm_item_expand", L.ptr(P), P.stride(0), L.ptr(F), F.stride(0), L.ptr(R), R.stride(0), L.ptr(Y), Y.stride(0), B, I, D, L.stream())
+
+
+def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, I: int, Kc: int, Kt: int, x0: Optional[Tensor] = None,
+                      w: Optional[Tensor] = None, gscale: float = 0.0, csum: Optional[Tensor] = None) -> None:
+    """item_expand whose result goes straight into the bf16 operands of the next GEMMs (Y16 [B, Kc] row-major, YT [Kt, round_up(B, 64)]
+    transposed).  x0 / w / csum given: the loss-gradient form v = gscale w[b] 2/I (R - x0) + P F^T with its column sums added to csum."""
+    B, D = P.shape[0], P.shape[1]
+    mode = 0 if x0 is None else 1
+    for t in (P, F, R) + ((x0,) if mode else ()):
+        if t.dtype != torch.float32 or t.stride(1) != 1:
+            raise ValueError("item_expand_fused: fp32 tensors with unit inner stride")
+    Bp = (B + 63) & ~63
+    if Y16.dtype != torch.bfloat16 or YT.dtype != torch.bfloat16 or Y16.stride(1) != 1 or YT.stride(1) != 1 or Y16.shape[0] < B or Y16.shape[1] < Kc or \
+            YT.shape[0] < Kt or YT.shape[1] < Bp or F.shape[0] < I or F.shape[1] != D or R.shape[0] < B or R.shape[1] < (I if mode else Kc):
+        raise ValueError("item_expand_fused: shape mismatch")
+    a = L.ExpandFusedArgs()
+    a.P, a.ldp, a.F, a.ldf, a.R, a.ldr = L.ptr(P), P.stride(0), L.ptr(F), F.stride(0), L.ptr(R), R.stride(0)
+    a.Y16, a.ldy, a.YT, a.ldt, a.B, a.I, a.Kc, a.Kt = L.ptr(Y16), Y16.stride(0), L.ptr(YT), YT.stride(0), B, I, Kc, Kt
+    if mode:
+        if w.dtype != torch.float64 or csum is None or csum.numel() < I:
+            raise ValueError("item_expand_fused: w is float64 [B], csum fp32 [I]")
+        a.X0, a.ldx0, a.w, a.gscale, a.csum = L.ptr(x0), x0.stride(0), L.ptr(w), float(gscale), L.ptr(_f32c(csum, "csum"))
+    L.call("dmm_item_expand_fused", C.byref(a), mode, D, L.stream())
 
 
 def noised_start(x0: Tensor, randn: Optional[Tensor], sqrt_ac: float, sqrt_1mac: float, xT: Tensor, I: int, seed: int = 0, offset: int = 0) -> None:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 203
+#define DMM_VERSION 204
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -310,10 +310,11 @@ int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out /*[co
 int dmm_colsum_add(const float* x, int64_t ldx, int rows, int cols, float* out /*[cols], accumulated into*/, void* stream);
 /* Diffusion loss, Model.py:407-425.  per row b: mse_b = mean_j (out - x0)^2; cos_b = cosine(um_b, ui_b);
  * loss_b = w_b * mse_b + sim_weight * (1 - cos_b) + reg_term  (float64 out, like the reference).
- * Also emits d loss / d out (the direct MSE part) and d loss / d um scaled by gscale (= 1 / (B * total)). */
+ * Also emits d loss / d out (the direct MSE part) and d loss / d um scaled by gscale (= 1 / (B * total)).
+ * loss == NULL and dout == NULL: only d loss / d um (the [B, I] rows are not read; dmm_item_expand_fused mode 1 forms d loss / d out). */
 int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w /*[B]*/, const float* um,
                   const float* ui, int B, int I, int d, float sim_weight, double reg_term, double gscale,
-                  double* loss /*[B]*/, float* dout /*[B,ld] or NULL*/, float* dum /*[B,d] or NULL*/, void* stream);
+                  double* loss /*[B] or NULL*/, float* dout /*[B,ld] or NULL*/, float* dum /*[B,d] or NULL*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Rebuild: per-row top-k with k = the user's degree (Main.py:224-230).  One workgroup per row; writes the k
@@ -337,6 +338,23 @@ int dmm_noised_start(const float* x0, int64_t ldx0, const float* randn, float sq
 int dmm_item_project(const float* X, int64_t ldx, const float* F, int64_t ldf, float* out, int64_t ldo, int B, int I, int D, void* stream);
 int dmm_item_expand(const float* P, int64_t ldp, const float* F, int64_t ldf, const float* R, int64_t ldr, float* Y, int64_t ldy, int B, int I, int D,
                     void* stream);
+/* dmm_item_expand fused with its consumers in the diffusion training step: the [B, I] result is written only as the bf16 operands of the next
+ * GEMMs -- row-major Y16[B, Kc] and transposed YT[Kt, round_up(B, 64)] (batch rows >= B zero) -- never in fp32.
+ *   mode 0 (Model.py:209):      v = R[b, c] + (P F^T)[b, c] for c < I;  v = R[b, c] for I <= c < Kc  (the [x_t | temb | 0] operand of layer 1)
+ *   mode 1 (Model.py:418-428):  v = gscale w[b] 2/I (R[b, c] - X0[b, c]) + (P F^T)[b, c] for c < I, 0 beyond: the gradient of the diffusion loss
+ *                               w.r.t. the Denoise output (R = that output, P = d loss / d (out F)), plus csum[c] += sum_b v (bias gradient) */
+typedef struct dmm_expand_fused_args {
+  const float* P; int64_t ldp;
+  const float* F; int64_t ldf;
+  const float* R; int64_t ldr;
+  const float* X0; int64_t ldx0; /* mode 1 */
+  const double* w; double gscale; /* mode 1 */
+  void* Y16; int64_t ldy;        /* bf16 [B, >= Kc] */
+  void* YT; int64_t ldt;         /* bf16 [Kt, >= round_up(B, 64)] */
+  float* csum;                   /* mode 1: [I], accumulated into */
+  int32_t B, I, Kc, Kt;
+} dmm_expand_fused_args;
+int dmm_item_expand_fused(const dmm_expand_fused_args* a /*host*/, int mode, int D, void* stream);
 /* The same product for up to 4 problems in one launch, 64 rows per workgroup (many short rows), with the layouts of the joint step's
  * modality-feature projections (Model.py:48-57,84-85,103):   out[r, c] += sum_k X[r, k] Fm(k, c) (+ bias[c], added once)
  *   f_transposed:   Fm(k, c) = F[c * ldf + k]  (F is an nn.Linear weight [D, K]);  else F[k * ldf + c]

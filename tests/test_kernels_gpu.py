@@ -721,6 +721,49 @@ def test_item_project_and_expand(dev, B, I, D):
     assert torch.equal(Rc[:, I:], R[:, I:])
 
 
+@pytest.mark.parametrize("D,B,I", [(64, 300, 1000), (128, 130, 517)])
+def test_item_expand_fused_equals_the_separate_passes(dev, D, B, I):
+    """dmm_item_expand_fused against the passes it replaces, bit for bit where the arithmetic is the same: forward (item_expand -> cast_bf16,
+    transpose_cast_bf16, incl. the time-embedding / pad columns and the zero batch-row padding of the transposed copy) and loss gradient
+    (diff_loss(dout) -> item_expand -> cast / transpose-cast; column sums up to summation order)."""
+    from diffmm_amd import ops
+    torch.manual_seed(B + I)
+    Kp = (I + 10 + 63) // 64 * 64
+    Bp = (B + 63) // 64 * 64
+    P, F = torch.randn(B, D, device=dev), torch.randn(I, D, device=dev)
+    R = torch.randn(B, Kp, device=dev)
+    R[:, I + 10:] = 0.0
+    Y = R.clone()
+    ops.item_expand(P, F, R, Y, I)
+    want16 = torch.zeros(B, Kp, device=dev, dtype=torch.bfloat16); ops.cast_bf16(Y, want16)
+    wantT = torch.full((Kp, Bp), 3.0, device=dev, dtype=torch.bfloat16); ops.transpose_cast_bf16(Y, wantT, rows=B, cols=Kp, rows_pad=Bp)
+    got16 = torch.full((B, Kp), 5.0, device=dev, dtype=torch.bfloat16); gotT = torch.full((Kp, Bp), 5.0, device=dev, dtype=torch.bfloat16)
+    ops.item_expand_fused(P, F, R, got16, gotT, I, Kp, Kp)
+    assert torch.equal(got16, want16), "forward: row-major bf16 operand"
+    assert torch.equal(gotT, wantT), "forward: transposed bf16 operand (batch rows >= B zero)"
+    # loss gradient
+    out, x0 = torch.randn(B, Kp, device=dev), (torch.rand(B, Kp, device=dev) < 0.05).float()
+    w = torch.rand(B, device=dev, dtype=torch.float64) + 0.5
+    um, ui = torch.randn(B, D, device=dev), torch.randn(B, D, device=dev)
+    gscale = 1.0 / (B * 3.7)
+    loss = torch.zeros(B, device=dev, dtype=torch.float64)
+    dout, dum = torch.zeros(B, Kp, device=dev), torch.zeros(B, D, device=dev)
+    ops.diff_loss(out, x0, w, um, ui, I, 0.1, 0.0, gscale, loss, dout, dum)
+    ops.item_expand(dum, F, dout, dout, I)
+    want16 = torch.zeros(B, Kp, device=dev, dtype=torch.bfloat16); ops.cast_bf16(dout, want16)
+    wantT = torch.zeros(I, Bp, device=dev, dtype=torch.bfloat16); ops.transpose_cast_bf16(dout, wantT, rows=B, cols=I, rows_pad=Bp)
+    wantc = torch.zeros(I, device=dev); ops.colsum(dout, B, I, wantc)
+    dum2 = torch.zeros(B, D, device=dev)
+    ops.diff_loss(out, x0, w, um, ui, I, 0.1, 0.0, gscale, None, None, dum2)
+    assert torch.equal(dum2, dum), "diff_loss: dum-only mode"
+    got16 = torch.full((B, Kp), 5.0, device=dev, dtype=torch.bfloat16); gotT = torch.full((I, Bp), 5.0, device=dev, dtype=torch.bfloat16)
+    gotc = torch.zeros(I, device=dev)
+    ops.item_expand_fused(dum2, F, out, got16, gotT, I, Kp, I, x0=x0, w=w, gscale=gscale, csum=gotc)
+    assert torch.equal(got16, want16), "loss gradient: row-major bf16 (columns >= I zero)"
+    assert torch.equal(gotT, wantT), "loss gradient: transposed bf16"
+    close(gotc, wantc, rtol=1e-4, atol=1e-6 * float(wantc.abs().max()) + 1e-9, what="column sums")
+
+
 @pytest.mark.parametrize("D", [64, 128])
 def test_item_project_batched_layouts(dev, D):
     """dmm_item_project_batched (the joint step's modality projections and their weight gradients) against fp64 products of the bf16-rounded
