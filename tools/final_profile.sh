@@ -2,7 +2,7 @@
 # Round-end artefacts (run on the GPU box: bash tools/final_profile.sh <tag>, e.g. r2): the full bench line (cpu_baseline, shard-scale SpMM
 # roofline, fp32-like rate), rocprofv3 stats of the bench, stats + separate PMC passes of the isolated roofline launches.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r2}; O=gpurun_out/final_$TAG; mkdir -p $O
+TAG=${1:-r2c}; O=gpurun_out/final_$TAG; mkdir -p $O
 timeout -k 10 700 python3 bench.py > $O/bench_full.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o ${TAG}_bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-roofline --no-fp32-like > $O/prof_bench.log 2>&1 || exit 1
 T=$(find $O/prof_bench -name "${TAG}_bench_kernel_trace.csv" | head -1)

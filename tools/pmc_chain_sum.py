@@ -10,11 +10,16 @@ ALG = {  # operands read once + outputs written once (+ residual read once), byt
     "layer2_bf16_state": 3 * (9308 * 1024 * 2 + 6710 * 1024 * 2 + 2 * 9308 * 6710 * 2),
     "layer2_fp32_state": 3 * (9308 * 1024 * 2 + 6710 * 1024 * 2 + 9308 * 6710 * (4 + 4 + 2)),
     "latent_step": 3 * (9308 * 1024 * (4 + 4 + 2 + 2) + 1024 * 1024 * 2),
+    # per LAUNCH of the persistent chain (two per call: 64 + 47 row-block groups; the counters are per launch, so is this figure: half a call):
+    # z_T and G read once, and per step every h element written once and read once (the exchange between the 4 workgroups of a row block)
+    "latent_chain": (3 * 9308 * 1024 * 4 + 39 * 3 * 9308 * 1024 * (2 + 2) + 3 * 1024 * 1024 * 2 + 3 * 9308 * 1024 * 2) // 2,
     "last_step_fp32_out": 3 * (9308 * 1024 * 2 + 6710 * 1024 * 2 + 9308 * 6710 * 4),
 }
 
 
 def kind(name):
+    if "latent_chain_8ph_kernel" in name:
+        return "latent_chain"
     if "gemm_bf16_nt_8ph_kernel<" not in name:
         return None
     return NAMES.get(name.split("gemm_bf16_nt_8ph_kernel<", 1)[1].split(">")[0].strip())
