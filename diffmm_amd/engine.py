@@ -101,8 +101,9 @@ class JointEngine:
         self.feat = [self._feat_block[m] for m in range(M)]
         # E_m^T [F_m, round_up(I, 32)] (constant): the weight gradient dW_m = dfeat_m^T E_m runs as E_m^T x dfeat_m on the item-space kernel
         self._featsT = None
-        self.nf = [z(items, D) for _ in range(M)]
-        self.fnorm = [z(items) for _ in range(M)]
+        self._nf_block, self._fnorm_block = z(M, items, D), z(M, items)  # blocks: the modalities' row normalisation is one launch
+        self.nf = [self._nf_block[m] for m in range(M)]
+        self.fnorm = [self._fnorm_block[m] for m in range(M)]
         self.Z = [z(N, D) for _ in range(M)]
         self.Bx, self.X1p, self.Mx, self.Fin, self.X2p, self.X3p, self.CL1 = (z(N, D) for _ in range(7))
         # gradient accumulators filled by scatter-adds: one block, one memset per step
@@ -190,8 +191,7 @@ class JointEngine:
         else:  # Linear_m(E_m) of every modality in ONE launch of the generic GEMM
             ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{n}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{n}_layer.bias"),
                                    precision=precision) for m, n in enumerate(names)])
-        for m in range(self.M):
-            ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
+        ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1))  # all modalities' rows
 
     def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3, _arena_zeroed: bool = False):
         hp, A, emb = self.hp, self.adj, self.P.view("emb")

@@ -126,8 +126,9 @@ class ShardedJointEngine:
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
         self._feat_block = z(M, I, D)
         self.feat = [self._feat_block[m] for m in range(M)]
-        self.nf = [z(I, D) for _ in range(M)]
-        self.fnorm = [z(I) for _ in range(M)]
+        self._nf_block, self._fnorm_block = z(M, I, D), z(M, I)  # blocks: the modalities' row normalisation is one launch
+        self.nf = [self._nf_block[m] for m in range(M)]
+        self.fnorm = [self._fnorm_block[m] for m in range(M)]
         self.Z = [z(n, D) for _ in range(M)]
         self.Bx, self.X1p, self.Mx, self.Fin, self.X2p, self.X3p, self.CL1 = (z(n, D) for _ in range(7))
         self.gblock = z(M + 3, n, D)
@@ -252,8 +253,7 @@ class ShardedJointEngine:
         else:
             ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
                                    precision=precision) for m, nm in enumerate(modality_names(self.M))])
-        for m in range(self.M):
-            ops.rownorm_fwd(self.feat[m], self.nf[m], self.fnorm[m])
+        ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1))  # all modalities' rows
 
     _feat_kernels = JointEngine._feat_kernels
 
