@@ -162,11 +162,16 @@ __device__ __forceinline__ void p8_ld_res_edge(const char* p, int nv, u32x2& r) 
 }
 
 // B2 (the latent reverse chain): the bf16 output is not a copy of C but the NEXT layer's activation tanh(C + bias2[n]).
-__device__ __forceinline__ void p8_st_keep(__bf16* p, const float (&v)[4]) {  // plain store: the line is meant to be re-read from L2
+// the persistent chain's h' stores.  KEEP = 1: plain stores (the lines stay in the XCD's L2 for the group's re-read; published by an agent
+// release fence = L2 write-back).  KEEP = 2: write-through (sc1) stores, published by waiting for them (no release fence; the lines
+// leave L2, the group re-reads them from the fabric side).  MI355X_MICROARCH.md "publish-large" prices both; measured here: see DESIGN 4.2.
+template <int KEEP>  // 1: plain, 2: write-through
+__device__ __forceinline__ void p8_st_keep(__bf16* p, const float (&v)[4]) {
   const bf16x4 b = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-  *reinterpret_cast<u32x2*>(p) = __builtin_bit_cast(u32x2, b);
+  if (KEEP == 2) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *reinterpret_cast<u32x2*>(p) = __builtin_bit_cast(u32x2, b);
 }
-template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2, bool KEEP = false>
+template <int PASS, int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2, int KEEP = 0>
 __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, float* tile, int q, int fr, const float4& b4, const float4& c4, const char*& pR, long long rs,
                                              float*& pC, __bf16*& pCb, const typename P8Res<RK>::type (&rcur)[8], typename P8Res<RK>::type (&rnext)[8],
                                              int mrow, int nv) {
@@ -198,11 +203,11 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
     if (B2) { w[0] = tanh_fast_bf16(v[0] + c4.x); w[1] = tanh_fast_bf16(v[1] + c4.y); w[2] = tanh_fast_bf16(v[2] + c4.z); w[3] = tanh_fast_bf16(v[3] + c4.w); }
     if (!EDGE) {
       if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-      if (HAS_CB) { if (KEEP) p8_st_keep(pCb + (long long)(it * 4) * E.ldcb, w); else p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w); }
+      if (HAS_CB) { if (KEEP) p8_st_keep<KEEP>(pCb + (long long)(it * 4) * E.ldcb, w); else p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w); }
     } else if (mrow + PASS * 32 + it * 4 < E.M && nv > 0) {
       if (nv == 4) {
         if (HAS_C) p8_st_stream(pC + (long long)(it * 4) * E.ldc, v);
-        if (HAS_CB) { if (KEEP) p8_st_keep(pCb + (long long)(it * 4) * E.ldcb, w); else p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w); }
+        if (HAS_CB) { if (KEEP) p8_st_keep<KEEP>(pCb + (long long)(it * 4) * E.ldcb, w); else p8_st_stream(pCb + (long long)(it * 4) * E.ldcb, w); }
       } else {
         if (HAS_C) p8_st_edge(pC + (long long)(it * 4) * E.ldc, v, nv);
         if (HAS_CB) p8_st_edge(pCb + (long long)(it * 4) * E.ldcb, w, nv);
@@ -216,7 +221,7 @@ __device__ __forceinline__ void p8_fast_pass(const P8Epi& E, const P8Acc& acc, f
   if (HAS_CB) pCb += 32 * E.ldcb;
 }
 
-template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2 = false, bool KEEP = false>
+template <int RK, bool HAS_C, bool HAS_CB, int ACT, bool EDGE, bool B2 = false, int KEEP = 0>
 __device__ __forceinline__ void p8_epilogue_fast(const P8Epi& E, const P8Acc& acc, char* smem, int m0, int n0, int wave, int lane) {
   constexpr bool HAS_R = RK != 0;
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, q = lane >> 4;
@@ -510,8 +515,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
 // 256 x 256 tile of z in the accumulator registers for the whole chain (as a = z / c1: the MFMAs of a step accumulate h G^T straight onto
 // a_init = (c2 / c1) z + g, and the next step's a_init is one FMA per register) -- z never touches memory again.  What a step still exchanges is h: the
 // H / 256 workgroups that share a row block (a "group") each write their 256 columns of h' (bf16) and read the whole row block back as the next A
-// operand, so a step ends in a group barrier: release fence, one atomic per workgroup on the group's counter, a BOUNDED spin (a partner that never
-// arrives -- it cannot, see below -- sets the error word instead of hanging the GPU), acquire fence.
+// operand, so a step ends in a group barrier: the stores are published (WT: write-through sc1 stores that every wave waits for; else plain stores +
+// one agent release fence), one atomic per workgroup on the group's counter, a BOUNDED spin (a partner that never arrives -- it cannot, see below --
+// sets the error word instead of hanging the GPU), acquire fence.
 // Placement: workgroup b belongs to group 8 (b / 8 / nt) + b % 8 -- the members of a group are nt CONSECUTIVE workgroups of one XCD's dispatch queue
 // (workgroups are dealt round-robin over the 8 XCDs), so they share that XCD's L2 (h' is re-read from it) and, dispatch being in order per XCD, the
 // earliest unfinished group of an XCD always has all its members resident: no wait can be circular.  The host launches at most CUs / nt groups at a time.
@@ -531,6 +537,7 @@ struct LatentBatch {
 };
 constexpr int LATENT_SPIN_MAX = 1 << 22;  // x (s_sleep(2) + an L2 round trip, ~0.3 us): about a second, then give up (the step kernel path takes a few ms in total)
 
+template <bool WT>
 __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch Lb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nt = Lb.H >> 8;
@@ -610,8 +617,8 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
     P8Epi E;
     E.C = nullptr; E.Cb = hbuf[src ^ 1]; E.R = nullptr; E.Rb = nullptr; E.bias = nullptr; E.bias2 = bias_t + (long long)(i - 1) * ldbt;
     E.ldc = 0; E.ldcb = ldh; E.ldr = 0; E.ldrb = 0; E.M = rows; E.N = Lb.H; E.act = DMM_ACT_NONE; E.alpha = coef[2 * i]; E.e1 = 1.f; E.e2 = 1.f;
-    if (interior) p8_epilogue_fast<0, false, true, DMM_ACT_NONE, false, true, true>(E, acc, smem, m0, n0, wave, lane);
-    else p8_epilogue_fast<0, false, true, DMM_ACT_NONE, true, true, true>(E, acc, smem, m0, n0, wave, lane);
+    if (interior) p8_epilogue_fast<0, false, true, DMM_ACT_NONE, false, true, (WT ? 2 : 1)>(E, acc, smem, m0, n0, wave, lane);
+    else p8_epilogue_fast<0, false, true, DMM_ACT_NONE, true, true, (WT ? 2 : 1)>(E, acc, smem, m0, n0, wave, lane);
     if (step + 1 == T - 1) break;  // h_0 is written; nothing follows in this kernel
     const float sc = coef[2 * i + 1];
 #pragma unroll
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: the flag must not overtake the write-back)
       __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int target = (step + 1) * nt;
@@ -652,10 +659,13 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
 
 int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
   static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     return true;
   }();
   (void)once;
+  // write-through h' stores and no release fence (default; rebuild 5.57 -> 5.20 ms at the bench shape) or plain stores + agent release (0)
+  static const int wt = [] { const char* e = getenv("DMM_LATENT_WT"); return e ? atoi(e) : 1; }();
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -670,7 +680,8 @@ int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
     b.n_groups = std::min(per, total - g0);
     hipError_t e = hipMemsetAsync(b.flags, 0, sizeof(int) * 512, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(latent_chain_8ph_kernel, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
+    if (wt) hipLaunchKernelGGL(latent_chain_8ph_kernel<true>, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
+    else hipLaunchKernelGGL(latent_chain_8ph_kernel<false>, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
   }
   return 0;
 }
