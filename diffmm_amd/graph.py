@@ -263,6 +263,7 @@ class DeviceGraphBuilder:
         L.check(L.lib().dmm_graph_build_scratch_bytes(users, items, self.E, D, C.byref(sb)), "dmm_graph_build_scratch_bytes")
         L.check(L.lib().dmm_graph_build_task_capacity(users, items, self.E, D, task_len, C.byref(tc), C.byref(fc)), "dmm_graph_build_task_capacity")
         self.scratch = torch.empty(sb.value, dtype=torch.uint8, device=self.dev)
+        self._scratches, self._streams = [self.scratch], []  # one scratch / stream per graph of a build_all (grown on demand)
         self.task_cap, self.fix_cap = int(tc.value), int(fc.value)
         self.nnz = 2 * self.E + self.N
 
@@ -278,14 +279,34 @@ class DeviceGraphBuilder:
         for i, item_idx in enumerate(item_lists):
             if item_idx.dtype != torch.int32 or not item_idx.is_contiguous() or item_idx.numel() < self.E:
                 raise ValueError("DeviceGraphBuilder.build: item_idx must be a contiguous int32 tensor with one entry per edge")
-            rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
-            col = torch.empty(nnz, dtype=torch.int32, device=dev)
-            val = torch.empty(nnz, dtype=torch.float32, device=dev)
-            tasks = torch.empty((self.task_cap, 4), dtype=torch.int32, device=dev)
-            fix = torch.empty((self.fix_cap, 4), dtype=torch.int32, device=dev)
-            L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,
-                   L.ptr(self.dinv), L.ptr(rowptr), L.ptr(col), L.ptr(val), L.ptr(tasks), L.ptr(fix), L.ptr(metas[i]), L.ptr(self.scratch), L.stream())
-            outs.append((rowptr, col, val, tasks, fix))
+            outs.append((torch.empty(N + 1, dtype=torch.int32, device=dev), torch.empty(nnz, dtype=torch.int32, device=dev),
+                         torch.empty(nnz, dtype=torch.float32, device=dev), torch.empty((self.task_cap, 4), dtype=torch.int32, device=dev),
+                         torch.empty((self.fix_cap, 4), dtype=torch.int32, device=dev)))
+        # the graphs are independent and their 7 launches each are latency-bound (scans, per-row sorts): one HIP stream and one scratch
+        # buffer per graph, forked from and joined to the caller's stream (all outputs were allocated on it above)
+        n = len(item_lists)
+        while len(self._scratches) < n:
+            self._scratches.append(torch.empty_like(self.scratch))
+        if dev.type == "cuda" and n > 1:
+            while len(self._streams) < n:
+                self._streams.append(torch.cuda.Stream(device=dev))
+            main = torch.cuda.current_stream(dev)
+            fork = torch.cuda.Event(); fork.record(main)
+            for i, item_idx in enumerate(item_lists):
+                st = self._streams[i]
+                st.wait_event(fork)
+                rowptr, col, val, tasks, fix = outs[i]
+                with torch.cuda.stream(st):
+                    L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,
+                           L.ptr(self.dinv), L.ptr(rowptr), L.ptr(col), L.ptr(val), L.ptr(tasks), L.ptr(fix), L.ptr(metas[i]), L.ptr(self._scratches[i]),
+                           L.stream())
+                    done = torch.cuda.Event(); done.record(st)
+                main.wait_event(done)
+        else:
+            for i, item_idx in enumerate(item_lists):
+                rowptr, col, val, tasks, fix = outs[i]
+                L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,
+                       L.ptr(self.dinv), L.ptr(rowptr), L.ptr(col), L.ptr(val), L.ptr(tasks), L.ptr(fix), L.ptr(metas[i]), L.ptr(self._scratches[i]), L.stream())
         adjs = []
         for (rowptr, col, val, tasks, fix), m in zip(outs, metas.tolist()):
             n_tasks, head, n_partial, n_fix, nnz_d = m[:5]
