@@ -470,6 +470,7 @@ class DiffusionEngine:
         self._chain_plans: Dict[tuple, list] = {}
         self._w1T_chain = None  # bf16 W1^T per modality, allocated by the first CSR chain start
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
+        self._x0_rows, self._ie16 = None, None  # the current training batch as CSR rows (if it came as such); bf16 i_embs for its gather
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
@@ -712,7 +713,18 @@ class DiffusionEngine:
             a = self.act[m]
             self._project_items(a["out"][:B], feats[m], a["um"][:B], 1)
             if m == 0:
-                self._project_items(x0p, i_embs, self.ui[:B], 1)
+                rows = self._x0_rows
+                if rows is not None and self.D % 4 == 0:
+                    # x_0 @ i_embs (Model.py:414) for 0/1 CSR rows is a sum of a handful of i_embs rows: a gather instead of a pass over [B, I]
+                    # (the same bf16-rounded operands and fp32 sums as dmm_item_project, in another order)
+                    if self._ie16 is None:
+                        self._ie16 = torch.zeros(self.I, self.D, dtype=torch.bfloat16, device=self.dev)
+                        self._zero_d = torch.zeros(self.D, dtype=torch.float32, device=self.dev)
+                        self._ui16 = torch.zeros(self.B_max, self.D, dtype=torch.bfloat16, device=self.dev)
+                    ops.cast_bf16(i_embs, self._ie16)
+                    ops.csr_gather_sum_latent(rows.ptr, rows.col, rows.users, self._ie16, self._zero_d, self.ui[:B], self._ui16[:B])
+                else:
+                    self._project_items(x0p, i_embs, self.ui[:B], 1)
             a["w"] = self.w_table[a["t"][:B].long()]
             ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
 
@@ -795,6 +807,7 @@ class DiffusionEngine:
         sums = torch.zeros(M, dtype=torch.float64, device=self.dev)
         if B:
             x0p = self._set_x0(x0)
+            self._x0_rows = x0 if isinstance(x0, CsrRows) else None
             ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32, generator=self.t_gen)).to(torch.int32)
                   for m in range(M)]
             if precision == 1:  # the modalities' large GEMMs go out as one batched launch each (enough 256 x 256 tiles to fill the chip)
