@@ -279,8 +279,9 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
     own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
   }
   const float inv_t = 1.0f / term.temp;
+  const float c2 = inv_t * 1.4426950408889634f;  // logits enter exp2 as s * c2
   const int i = i0 + fr;
-  float m = -INFINITY, ssum = 0.f, diag = 0.f;
+  float m = -INFINITY, ssum = 0.f, diag = 0.f;  // m: running maximum of s * c2 (base-2 domain)
   bf16x8 ca[D / 16], cl[D / 16], na[D / 16], nl[D / 16];
   const int n_t = (B + 31) >> 5, per = (n_t + 3) >> 2;
   const int jt0 = wave * per, jt1 = min(n_t, jt0 + per);
@@ -315,27 +316,35 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
       ca[ks] = na[ks];
       if (PREC == 3) cl[ks] = nl[ks];
     }
-    float v[16], tmax = -INFINITY;
+    // online log-sum-exp in the base-2 domain: m, mn are maxima of s * c (c = log2(e) / temp), p = exp2(fma(s, c, -mn)) -- one fmax, one
+    // fma, one v_exp and one add per logit.  The bounds test runs only on the last tile, the diagonal pick only on the tile that holds it
+    // (13 -> 7 issue slots per logit: the kernel is VALU-bound).
+    if (j0 == i0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      v[r] = j < B ? acc[r] * inv_t : -INFINITY;
-      if (j == i) diag = v[r];
-      tmax = fmaxf(tmax, v[r]);
+      for (int r = 0; r < 16; ++r)
+        if (j0 + (r & 3) + 8 * (r >> 2) + 4 * fh == i) diag = acc[r] * inv_t;
     }
+    if (j0 + 32 > B) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (j0 + (r & 3) + 8 * (r >> 2) + 4 * fh >= B) acc[r] = -INFINITY;
+    }
+    float tmax = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, acc[r]);
     if (tmax > -INFINITY) {
-      const float mn = fmaxf(m, tmax);
+      const float mn = fmaxf(m, tmax * c2);
       float add = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) add += __expf(v[r] - mn);
-      ssum = ssum * __expf(m - mn) + add;
+      for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mn));
+      ssum = ssum * __builtin_amdgcn_exp2f(m - mn) + add;
       m = mn;
     }
   }
   // the two lane halves hold disjoint column subsets of the same own row
   const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64), d2 = __shfl_xor(diag, 32, 64);
   const float M = fmaxf(m, m2);
-  const float L = (m > -INFINITY ? ssum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
+  const float L = (m > -INFINITY ? ssum * __builtin_amdgcn_exp2f(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __builtin_amdgcn_exp2f(m2 - M) : 0.f);
   if (fh == 0) {
     part[wave][fr][0] = M;
     part[wave][fr][1] = L;
@@ -352,8 +361,8 @@ __global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, Term
     float Ls = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      if (part[w][fr][0] > -INFINITY) Ls += part[w][fr][1] * __expf(part[w][fr][0] - Mx);
-    const float l = Mx + __logf(Ls);
+      if (part[w][fr][0] > -INFINITY) Ls += part[w][fr][1] * __builtin_amdgcn_exp2f(part[w][fr][0] - Mx);
+    const float l = (Mx + __log2f(Ls)) * 0.6931471805599453f;  // back to natural units
     lse[(size_t)t * B + i] = l;
     row_loss[(size_t)t * B + i] = (l - dg) * (term.weight / (float)B);
   }
