@@ -74,35 +74,52 @@ class TrainData:
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(config.base.seed) + 17)
         self.rows, self.cols = np.asarray(rows, dtype=np.int32), np.asarray(cols, dtype=np.int32)
-        self.negs = np.zeros(len(self.rows), dtype=np.int32)
+        self._negs_host: Optional[np.ndarray] = np.zeros(len(self.rows), dtype=np.int32)
         items = int(config.data.item_num)
         self._keys = torch.from_numpy(np.sort(self.rows.astype(np.int64) * items + self.cols)).to(self.device)
         self._rows_d = torch.from_numpy(self.rows).to(self.device)
         self._cols_d = torch.from_numpy(self.cols).to(self.device)
         self._negs_d = torch.zeros(len(self.rows), dtype=torch.int32, device=self.device)
+        self._rows64 = None  # user id * item_num as int64 keys (device), built by the first negSampling()
         order = np.argsort(self.rows, kind="stable")
         ptr = np.searchsorted(self.rows[order], np.arange(int(config.data.user_num) + 1))
         self.user_pos_items: List[np.ndarray] = [self.cols[order[ptr[u]:ptr[u + 1]]] for u in range(int(config.data.user_num))]
 
+    @property
+    def negs(self) -> np.ndarray:
+        """Host mirror of the current negatives (read back on first use after a negSampling(): the training path never needs it)."""
+        if self._negs_host is None:
+            self._negs_host = self._negs_d.cpu().numpy()
+        return self._negs_host
+
     def negSampling(self) -> None:
-        """One uniform negative per interaction, re-drawn while (user, item) is a train interaction."""
+        """One uniform negative per interaction, re-drawn while (user, item) is a train interaction (DataHandler.py:164-176).  Rejection
+        rounds run four at a time as masked re-draws on the device (a round re-draws every slot and keeps the draw only where the current
+        negative is a train positive: the same distribution as re-drawing the rejected ones) with ONE host check per four rounds --
+        a check per round was a device -> host round trip each (3-4 per epoch)."""
         items = int(self.config.data.item_num)
         n = len(self.rows)
-        rows64 = self._rows_d.long()
+        if self._rows64 is None:
+            self._rows64 = self._rows_d.long() * items
+        last = self._keys.numel() - 1
+
+        def is_positive(neg):
+            key = self._rows64 + neg
+            pos = torch.searchsorted(self._keys, key).clamp_(max=last)
+            return self._keys[pos] == key
+
         neg = torch.randint(0, items, (n,), device=self.device, generator=self.gen)
-        bad = torch.arange(n, device=self.device)
-        while bad.numel():
-            key = rows64[bad] * items + neg[bad]
-            pos = torch.searchsorted(self._keys, key).clamp_(max=self._keys.numel() - 1)
-            bad = bad[self._keys[pos] == key]
-            if bad.numel():
-                neg[bad] = torch.randint(0, items, (int(bad.numel()),), device=self.device, generator=self.gen)
+        while True:
+            for _ in range(4):
+                neg = torch.where(is_positive(neg), torch.randint(0, items, (n,), device=self.device, generator=self.gen), neg)
+            if not bool(is_positive(neg).any()):
+                break
         self._negs_d = neg.to(torch.int32)
-        self.negs = self._negs_d.cpu().numpy()
+        self._negs_host = None
 
     def set_negs(self, negs: np.ndarray) -> None:
-        self.negs = np.asarray(negs, dtype=np.int32)
-        self._negs_d = torch.from_numpy(self.negs).to(self.device)
+        self._negs_host = np.asarray(negs, dtype=np.int32)
+        self._negs_d = torch.from_numpy(self._negs_host).to(self.device)
 
     def __len__(self) -> int:
         return len(self.rows)
