@@ -471,6 +471,7 @@ class DiffusionEngine:
         self._w1T_chain = None  # bf16 W1^T per modality, allocated by the first CSR chain start
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
         self._x0_rows, self._ie16 = None, None  # the current training batch as CSR rows (if it came as such); bf16 i_embs for its gather
+        self._FT16 = None  # F^T operands of the folded products (_folded_prepare)
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
@@ -585,6 +586,24 @@ class DiffusionEngine:
         """The batched bf16 training step writes the expand results straight into the next GEMMs' bf16 operands (dmm_item_expand_fused);
         hp fused_expand / DMM_FUSED_EXPAND=0 keeps the separate expand / cast / transpose / column-sum passes."""
         return self._item_kernels(1) and bool(self.hp.get("fused_expand", os.environ.get("DMM_FUSED_EXPAND", "1") != "0"))
+
+    def _folded_products(self) -> bool:
+        """Backward of the gate path without d[x'|temb] = dpre W1: d(proj*gate) = (dpre W1x) F = dpre (W1x F) with an [H, d] product formed
+        once per step, d temb = dpre W1e.  (The forward's model_output @ F = h (W2^T F) + b2 F folds the same way; measured: the [d, H]
+        product from W2's layout costs what the pass over [B, I] costs -- not kept.)  hp folded_products / DMM_FOLDED_PRODUCTS=0: the GEMM."""
+        return self._item_kernels(1) and self.D % 8 == 0 and bool(self.hp.get("folded_products", os.environ.get("DMM_FOLDED_PRODUCTS", "1") != "0"))
+
+    def _folded_prepare(self):
+        """Buffers of the folded products, on first use."""
+        M, D, H = self.M, self.D, self.H
+        if self._FT16 is None:
+            zb = lambda *s_: torch.zeros(s_, dtype=torch.bfloat16, device=self.dev)
+            z = lambda *s_: torch.zeros(s_, dtype=torch.float32, device=self.dev)
+            self._FT16 = True
+            self._Gf, self._G16 = z(M, D, H), zb(M, D, H)  # (W1x F)^T: fp32 accumulator (K slices) and the bf16 NT operand
+            self._G1 = [self._G16[m] for m in range(M)]
+            self._W1eT = [zb(16, H) for _ in range(M)]  # rows te .. 15 stay zero
+            self._dtemb = [z(self.B_max, 16) for _ in range(M)]
 
     def _project_items(self, X: Tensor, F: Tensor, out: Tensor, precision: int):
         """out = X[:, :I] @ F"""
@@ -770,14 +789,33 @@ class DiffusionEngine:
                 ops.transpose_cast_bf16(a["xcat"][:B], w["xcatT16"], rows=B, cols=Kp, rows_pad=Bp) # xcat^T [Kp, B]
             ops.colsum(w["dpre"][:B], B, H, P.g("in_layers.0.bias"))
             ops.cast_bf16(w["dpre"][:B], w["dpre16"][:B])
-            ops.transpose_cast_bf16(P.view("in_layers.0.weight"), w["w1T16"], rows=H, cols=Kp)     # W1^T   [Kp, H]
+            if not self._folded_products():
+                ops.transpose_cast_bf16(P.view("in_layers.0.weight"), w["w1T16"], rows=H, cols=Kp) # W1^T   [Kp, H]
         ops.gemm_bf16_nt_batched([dict(A=W[m]["dpreT16"][:, :Bp], B=W[m]["xcatT16"][:, :Bp], out=self.P[m].g("in_layers.0.weight"), K=Bp)
                                   for m in range(M)])                                               # dW1 = dpre^T [x|temb]
-        ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=W[m]["w1T16"], out=W[m]["dxcat"][:B]) for m in range(M)])   # d[x'|temb] = dpre W1
+        if self._folded_products():
+            # d[x'|temb] = dpre W1 is only ever used projected: d(proj*gate) = (dpre W1x) F = dpre (W1x F) and d temb = dpre W1e -- an [H, d]
+            # product and two skinny GEMMs instead of the [B, Kp] GEMM, its fp32 result and a pass over it per modality
+            # G1 = (W1x F)^T [d, H] on the item-space kernel (rows = H, K = I the long axis, result stored transposed), one launch for all
+            # modalities (the same product as a K-sliced generic GEMM: 84 us; as the bf16 NT kernel: 130 us on 48 workgroups), then one cast
+            self._folded_prepare()
+            ops.zero_(self._Gf)
+            ops.item_project_batched([dict(X=self.P[m].view("in_layers.0.weight"), F=feats[m], out=self._Gf[m], K=I) for m in range(M)], D,
+                                     out_transposed=True)
+            ops.cast_bf16(self._Gf.view(-1, H), self._G16.view(-1, H))
+            ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=self._G1[m], out=W[m]["dpg"][:B]) for m in range(M)])
+            for m in range(M):
+                ops.transpose_cast_bf16(self.P[m].view("in_layers.0.weight")[:, I:I + self.te], self._W1eT[m], rows=H, cols=self.te)  # W1e^T [te, H]
+            ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=self._W1eT[m], out=self._dtemb[m][:B]) for m in range(M)])   # d temb (16 columns)
+        else:
+            ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=W[m]["w1T16"], out=W[m]["dxcat"][:B]) for m in range(M)])   # d[x'|temb] = dpre W1
         for m in range(M):
             a, P, w = self.act[m], self.P[m], W[m]
-            ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
-            self._project_items(w["dxcat"][:B], feats[m], w["dpg"][:B], 1)                          # d(proj*gate) = dx' F
+            if self._folded_products():
+                ops.temb_bwd(a["t"][:B], self._dtemb[m][:B], 0, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
+            else:
+                ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
+                self._project_items(w["dxcat"][:B], feats[m], w["dpg"][:B], 1)                      # d(proj*gate) = dx' F
             ops.gate_bwd(w["dpg"][:B], a["proj"][:B], a["gate"][:B], w["dproj"][:B], w["dgate"][:B])
             ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))
         # dWg = dgate_pre^T proj: a single d x d output tile with K = B -- split K over 32 workgroups (zeroed above), all modalities in one launch

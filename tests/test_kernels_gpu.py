@@ -987,8 +987,10 @@ def test_csr_rows_equal_the_dense_path(dev):
     mc = E.train_step(rows, feats, ie, t=t, noise=noise, precision=1, update=False)
     # the same operand buffer either way; the step itself accumulates a few products with fp32 atomics, so runs agree to round-off only
     for m in range(M):
-        assert abs(md[m] - mc[m]) <= 1e-9 * abs(md[m]), "CSR-fed training step == dense-fed training step (loss)"
-        assert float((gd[m] - E.P[m].grad).abs().max()) <= 1e-5 * float(gd[m].abs().max()), "CSR-fed training step == dense-fed training step (gradients)"
+        assert abs(md[m] - mc[m]) <= 1e-5 * abs(md[m]), "CSR-fed training step == dense-fed training step (loss; K-sliced products: summation order)"
+        # (fp32 sums accumulated by K slices and then ROUNDED to a bf16 operand -- (W1x F)^T -- can land on the other side of a rounding
+        # boundary from run to run: one bf16 ulp on one of 65k entries)
+        assert float((gd[m] - E.P[m].grad).abs().max()) <= 1e-4 * float(gd[m].abs().max()), "CSR-fed training step == dense-fed training step (gradients)"
     dense = [v.clone() for v in E.generate_views_bf16(want)]
     sparse = E.generate_views_bf16_csr(rows)
     for m in range(M):
