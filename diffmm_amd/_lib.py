@@ -124,6 +124,7 @@ _SIGS = {
     "dmm_noised_start": (C.c_int, [_P, _L, _P, _F, _F, _P, _L, _I, _I, _U64, _U64, _P]),
     "dmm_item_project": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_item_project_batched": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _I, _I, _P]),
+    "dmm_item_project_batched_x16": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _P]),
     "dmm_item_expand": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_item_expand_fused": (C.c_int, [C.POINTER(ExpandFusedArgs), _I, _I, _P]),
     "dmm_graph_build_scratch_bytes": (C.c_int, [_I, _I, _L, _I, _P]),

@@ -34,8 +34,10 @@ struct ProjP {
 struct ProjBatch { ProjP p[4]; };
 struct ProjOne { ProjP p[1]; };  // (the single-problem launch: a 72-byte kernel argument)
 
-template <int D, int MT, bool FT, bool OUT_T, typename BatchT>
+// XB (MT == 1 only): X is given in bf16 ([rows, ldx] bf16 elements) -- e.g. a transposed bf16 weight copy that exists anyway
+template <int D, int MT, bool FT, bool OUT_T, typename BatchT, bool XB = false>
 __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
+  static_assert(!XB || MT == 1, "bf16 X: 64-row workgroups only");
   constexpr int NT = D / 16;
   constexpr int LDT = IP_KS * 2 + 16;  // bytes per feature column in LDS (+16: the 16 columns of a fragment read hit distinct banks)
   __shared__ __attribute__((aligned(16))) char ft[D * LDT];
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
   const float* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) xrow[mt] = X + (long long)min(row0 + mt * 16 + fr, B - 1) * ldx + kg * 8;
+  const __bf16* xrow16 = reinterpret_cast<const __bf16*>(X) + (long long)min(row0 + fr, B - 1) * ldx + kg * 8;  // (XB)
 
   for (int k0 = kbeg; k0 < kend; k0 += IP_KS) {
     const int steps = min(IP_KS, (kend - k0 + 31) & ~31) / 32;
@@ -66,8 +69,12 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int kq = k0 + min(s, steps - 1) * 32;
-        xs[s][0] = *reinterpret_cast<const float4*>(xrow[0] + kq);
-        xs[s][1] = *reinterpret_cast<const float4*>(xrow[0] + kq + 4);
+        if (XB) {
+          xs[s][0] = *reinterpret_cast<const float4*>(xrow16 + kq);  // 8 bf16 = the MFMA fragment as it is
+        } else {
+          xs[s][0] = *reinterpret_cast<const float4*>(xrow[0] + kq);
+          xs[s][1] = *reinterpret_cast<const float4*>(xrow[0] + kq + 4);
+        }
       }
     }
     __syncthreads();  // the previous stage's fragment reads are done
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s < steps) {
-          const bf16x8 fa = is_cvt8(xs[s][0], xs[s][1]);
+          const bf16x8 fa = XB ? __builtin_bit_cast(bf16x8, xs[s][0]) : is_cvt8(xs[s][0], xs[s][1]);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const bf16x8 fb = *reinterpret_cast<const bf16x8*>(ft + (nt * 16 + fr) * LDT + (s * 32 + kg * 8) * 2);
@@ -419,7 +426,14 @@ extern "C" int dmm_item_project(const float* X, int64_t ldx, const float* F, int
   return 0;
 }
 
+static int project_batched(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, bool x_bf16, void* stream);
 extern "C" int dmm_item_project_batched(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, void* stream) {
+  return project_batched(p, n, D, f_transposed, out_transposed, false, stream);
+}
+extern "C" int dmm_item_project_batched_x16(const dmm_project_problem* p, int n, int D, void* stream) {
+  return project_batched(p, n, D, 0, 1, true, stream);
+}
+static int project_batched(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, bool x_bf16, void* stream) {
   DMM_CHECK_ARG(p && n >= 1 && n <= 4, "dmm_item_project_batched: 1..4 problems per launch");
   DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_project_batched: D=%d unsupported (64 or 128)", D);
   ProjBatch b;
@@ -429,7 +443,7 @@ extern "C" int dmm_item_project_batched(const dmm_project_problem* p, int n, int
   for (int i = 0; i < n; ++i) {
     const dmm_project_problem& q = p[i];
     DMM_CHECK_ARG(q.X && q.F && q.out && q.rows > 0 && q.K > 0, "dmm_item_project_batched: bad arguments (problem %d)", i);
-    DMM_CHECK_ARG(q.ldx % 4 == 0 && q.ldf % 4 == 0 && (((uintptr_t)q.X | (uintptr_t)q.F) & 15) == 0 && q.ldx >= ((q.K + 31) & ~31),
+    DMM_CHECK_ARG((x_bf16 ? q.ldx % 8 == 0 : q.ldx % 4 == 0) && q.ldf % 4 == 0 && (((uintptr_t)q.X | (uintptr_t)q.F) & 15) == 0 && q.ldx >= ((q.K + 31) & ~31),
                   "dmm_item_project_batched: X and F rows must be 16-byte aligned and X rows readable up to round_up(K, 32) (problem %d)", i);
     DMM_CHECK_ARG(f_transposed ? q.ldf >= q.K : q.ldf >= D, "dmm_item_project_batched: ldf too small (problem %d)", i);
     // K slices of whole 32-item steps: about 1024 workgroups per launch over all problems
@@ -446,7 +460,10 @@ extern "C" int dmm_item_project_batched(const dmm_project_problem* p, int n, int
     ks = std::max(ks, (q.K + kchunk - 1) / kchunk);
   }
   hipStream_t s = (hipStream_t)stream;
-  if (f_transposed && !out_transposed) project_launch<1, true, false>(b, n, D, rb, ks, s);
+  if (x_bf16) {
+    if (D == 64) hipLaunchKernelGGL((item_project_kernel<64, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((item_project_kernel<128, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+  } else if (f_transposed && !out_transposed) project_launch<1, true, false>(b, n, D, rb, ks, s);
   else if (!f_transposed && out_transposed) project_launch<1, false, true>(b, n, D, rb, ks, s);
   else if (!f_transposed && !out_transposed) project_launch<1, false, false>(b, n, D, rb, ks, s);
   else project_launch<1, true, true>(b, n, D, rb, ks, s);

@@ -588,9 +588,9 @@ class DiffusionEngine:
         return self._item_kernels(1) and bool(self.hp.get("fused_expand", os.environ.get("DMM_FUSED_EXPAND", "1") != "0"))
 
     def _folded_products(self) -> bool:
-        """Backward of the gate path without d[x'|temb] = dpre W1: d(proj*gate) = (dpre W1x) F = dpre (W1x F) with an [H, d] product formed
-        once per step, d temb = dpre W1e.  (The forward's model_output @ F = h (W2^T F) + b2 F folds the same way; measured: the [d, H]
-        product from W2's layout costs what the pass over [B, I] costs -- not kept.)  hp folded_products / DMM_FOLDED_PRODUCTS=0: the GEMM."""
+        """[B, I]-sized products through F folded into [d, H] products formed once per step.  Backward of the gate path without
+        d[x'|temb] = dpre W1: d(proj*gate) = (dpre W1x) F = dpre (W1x F), d temb = dpre W1e.  Forward: model_output @ F = h (F^T W2)^T + b2 F.
+        hp folded_products / DMM_FOLDED_PRODUCTS=0: the [B, Kp] GEMM and the passes over [B, I]."""
         return self._item_kernels(1) and self.D % 8 == 0 and bool(self.hp.get("folded_products", os.environ.get("DMM_FOLDED_PRODUCTS", "1") != "0"))
 
     def _folded_prepare(self):
@@ -602,6 +602,8 @@ class DiffusionEngine:
             self._FT16 = True
             self._Gf, self._G16 = z(M, D, H), zb(M, D, H)  # (W1x F)^T: fp32 accumulator (K slices) and the bf16 NT operand
             self._G1 = [self._G16[m] for m in range(M)]
+            self._G2f, self._G2_16 = z(M, D, H), zb(M, D, H)  # F^T W2 likewise
+            self._FT32, self._b2F = [z(D, (self.I + 3) & ~3) for _ in range(M)], [z(D) for _ in range(M)]
             self._W1eT = [zb(16, H) for _ in range(M)]  # rows te .. 15 stay zero
             self._dtemb = [z(self.B_max, 16) for _ in range(M)]
 
@@ -728,9 +730,22 @@ class DiffusionEngine:
                 ops.cast_bf16(self._mids_fwd(m, self.act[m]["h"][:B], 1), W[m]["h16"][:B])
         ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self.w2_16[m], out=self.act[m]["out"][:B], bias=self.P[m].view(self.L2 + ".bias"), N=I)
                                   for m in range(M)])
+        if self._folded_products():
+            # usr_model_embeds = model_output @ F (Model.py:413) with model_output = h W2^T + b2 is  h (F^T W2)^T + b2 F: the [d, H] product comes
+            # from the transposed bf16 copy of W2 the backward needs anyway (made here instead), on the item-space kernel
+            self._folded_prepare()
+            ops.zero_(self._G2f)
+            for m in range(M):
+                ops.transpose_cast_bf16(self.P[m].view(self.L2 + ".weight"), W[m]["w2T16"], rows=I, cols=self.H)  # W2^T [H, I -> Kp]
+                self._FT32[m][:, :I].copy_(feats[m].t())
+                ops.gemv_rows(self._FT32[m], self.P[m].view(self.L2 + ".bias"), self._b2F[m], cols=I)
+            ops.item_project_batched_x16([dict(X=W[m]["w2T16"], F=feats[m], out=self._G2f[m], K=I) for m in range(M)], self.D)
+            ops.cast_bf16(self._G2f.view(-1, self.H), self._G2_16.view(-1, self.H))
+            ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self._G2_16[m], out=self.act[m]["um"][:B], bias=self._b2F[m]) for m in range(M)])
         for m in range(M):
             a = self.act[m]
-            self._project_items(a["out"][:B], feats[m], a["um"][:B], 1)
+            if not self._folded_products():
+                self._project_items(a["out"][:B], feats[m], a["um"][:B], 1)
             if m == 0:
                 rows = self._x0_rows
                 if rows is not None and self.D % 4 == 0:
@@ -776,7 +791,8 @@ class DiffusionEngine:
                 ops.colsum(w["dout"][:B], B, I, P.g(self.L2 + ".bias"))
                 ops.cast_bf16(w["dout"][:B], w["xb16"][:B])                                             # dout (pad columns are zero)
             ops.transpose_cast_bf16(a_last, w["hT16"], rows=B, cols=H, rows_pad=Bp)                # h^T    [H, B]
-            ops.transpose_cast_bf16(P.view(self.L2 + ".weight"), w["w2T16"], rows=I, cols=H)     # W2^T   [H, I -> Kp]
+            if not self._folded_products():  # (folded: the forward made it)
+                ops.transpose_cast_bf16(P.view(self.L2 + ".weight"), w["w2T16"], rows=I, cols=H) # W2^T   [H, I -> Kp]
         ops.gemm_bf16_nt_batched([dict(A=W[m]["doutT16"][:, :Bp], B=W[m]["hT16"][:, :Bp], out=self.P[m].g(self.L2 + ".weight"), N=H, K=Bp)
                                   for m in range(M)])                                               # dW2 = dout^T h
         ops.gemm_bf16_nt_batched([dict(A=W[m]["xb16"][:B], B=W[m]["w2T16"], out=W[m]["dh"][:B], K=Kp) for m in range(M)])  # dh = dout W2

@@ -590,6 +590,19 @@ def item_project(X: Tensor, F: Tensor, out: Tensor, I: int) -> None:
     L.call("dmm_item_project", L.ptr(X), X.stride(0), L.ptr(F), F.stride(0), L.ptr(out), out.stride(0), B, I, D, L.stream())
 
 
+def item_project_batched_x16(problems: Sequence[dict], D: int) -> None:
+    """out[c, r] += sum_k X[r, k] F[k, c] with X in bf16 [rows, >= round_up(K, 32)] (the out_transposed form of item_project_batched)."""
+    arr = (L.ProjectProblem * len(problems))()
+    for a, p in zip(arr, problems):
+        X, F, out, K = p["X"], p["F"], p["out"], int(p["K"])
+        rows = int(p.get("rows", X.shape[0]))
+        if X.dtype != torch.bfloat16 or F.dtype != torch.float32 or out.dtype != torch.float32 or any(t.dim() != 2 or t.stride(1) != 1 for t in (X, F, out)) or \
+                F.shape[0] < K or F.shape[1] < D or out.shape[0] < D or out.shape[1] < rows or X.shape[0] < rows or X.shape[1] < ((K + 31) & ~31):
+            raise ValueError("item_project_batched_x16: bad operands")
+        a.X, a.ldx, a.F, a.ldf, a.out, a.ldo, a.rows, a.K = L.ptr(X), X.stride(0), L.ptr(F), F.stride(0), L.ptr(out), out.stride(0), rows, K
+    L.call("dmm_item_project_batched_x16", arr, len(problems), D, L.stream())
+
+
 def item_project_batched(problems: Sequence[dict], D: int, f_transposed: bool = False, out_transposed: bool = False) -> None:
     """Up to 4 problems  out[r, c] += sum_k X[r, k] Fm(k, c) (+ bias[c])  in one launch (dicts: X [rows, >= round_up(K, 32)], F, out, optional bias,
     K).  f_transposed: F is [D, K] (an nn.Linear weight); out_transposed: the result goes to out[c, r].  `out` holds the value to add to."""

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 204
+#define DMM_VERSION 205
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -368,6 +368,9 @@ typedef struct dmm_project_problem {
   int32_t rows, K;
 } dmm_project_problem;
 int dmm_item_project_batched(const dmm_project_problem* p /*host array*/, int n, int D, int f_transposed, int out_transposed, void* stream);
+/* the out_transposed form with X given in bf16 ([rows, ldx] bf16 elements, ldx % 8 == 0; the X pointer of the problem struct is read as such):
+ * a transposed bf16 weight copy that exists anyway as the long operand, e.g. (F^T W2)[d, H] from W2^T[H, I] in bf16 (Model.py:413 folded) */
+int dmm_item_project_batched_x16(const dmm_project_problem* p /*host array*/, int n, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Rebuild, second half: the modality graph of Main.py:232-253 (coo_matrix of the top-k edges -> DataHandler.makeTorchAdj,
