@@ -25,18 +25,20 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
                                                             const float* __restrict__ sqrt_1mac, const float* __restrict__ w_emb,
                                                             const float* __restrict__ b_emb, int te, float* __restrict__ xcat, long long ldx,
                                                             int I, int draw_noise, unsigned long long seed, unsigned long long offset,
-                                                            float* __restrict__ eps_out) {
+                                                            float* __restrict__ eps_out, const uint32_t* __restrict__ bits, long long ldb) {
   const int b = blockIdx.x;
   const int tb = t[b];
   float* __restrict__ row = xcat + (long long)b * ldx;
-  if (x0) {
+  if (x0 || bits) {  // bits: x_0 as one bit per (row, item) -- 0/1 interaction rows read at 1/32 of the bytes (dmm_csr_row_bits)
     const bool has_eps = noise != nullptr || draw_noise;
     const float a = has_eps ? sqrt_ac[tb] : 1.0f, c = has_eps ? sqrt_1mac[tb] : 0.0f;
-    const float* __restrict__ xr = x0 + (long long)b * ldx0;
+    const float* __restrict__ xr = x0 ? x0 + (long long)b * ldx0 : nullptr;
+    const uint32_t* __restrict__ br = bits ? bits + (long long)b * ldb : nullptr;
     if (noise || !draw_noise) {
       for (int j = threadIdx.x; j < I; j += 256) {
         const float e = noise ? noise[(long long)b * I + j] : 0.f;
-        row[j] = a * xr[j] + c * e;
+        const float xv = br ? (float)((br[j >> 5] >> (j & 31)) & 1u) : xr[j];
+        row[j] = a * xv + c * e;
         if (eps_out) eps_out[(long long)b * I + j] = e;
       }
     } else {
@@ -45,10 +47,12 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
         const uint4 r = philox4(seed, offset + (unsigned long long)b * ((I + 3) / 4) + q, 0xd1ffu);
         const float2 n0 = box_muller(r.x, r.y), n1 = box_muller(r.z, r.w);
         const float e[4] = {n0.x, n0.y, n1.x, n1.y};
+        const uint32_t word = br ? br[q >> 3] >> ((q & 7) * 4) : 0u;  // columns 4q .. 4q+3 sit in one word
         for (int u = 0; u < 4; ++u) {
           const int j = 4 * q + u;
           if (j < I) {
-            row[j] = a * xr[j] + c * e[u];
+            const float xv = br ? (float)((word >> u) & 1u) : xr[j];
+            row[j] = a * xv + c * e[u];
             if (eps_out) eps_out[(long long)b * I + j] = e[u];
           }
         }
@@ -235,18 +239,19 @@ __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict_
                                                          const double* __restrict__ w, const float* __restrict__ um,
                                                          const float* __restrict__ ui, int I, int d, float sim_weight, double reg_term,
                                                          double gscale, double* __restrict__ loss, float* __restrict__ dout,
-                                                         float* __restrict__ dum) {
+                                                         float* __restrict__ dum, const uint32_t* __restrict__ bits, long long ldb) {
   __shared__ double smd[4];
   __shared__ float smf[4];
   const int b = blockIdx.x;
   const float* __restrict__ o = out + (long long)b * ld;
-  const float* __restrict__ x = x0 + (long long)b * ld;
+  const float* __restrict__ x = x0 ? x0 + (long long)b * ld : nullptr;
+  const uint32_t* __restrict__ br = bits ? bits + (long long)b * ldb : nullptr;  // x_0 as a bit mask (dmm_csr_row_bits)
   const double wb = w[b];
   const float gcoef = (float)(gscale * wb * 2.0 / (double)I);
   double a = 0.0;
   if (loss || dout) {  // (loss == NULL and dout == NULL: only d loss / d um is wanted -- the rows are not read at all)
     for (int j = threadIdx.x; j < I; j += 256) {
-      const float df = o[j] - x[j];
+      const float df = o[j] - (br ? (float)((br[j >> 5] >> (j & 31)) & 1u) : x[j]);
       a += (double)(df * df);
       if (dout) dout[(long long)b * ld + j] = gcoef * df;
     }
@@ -748,8 +753,47 @@ extern "C" int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* nois
   DMM_CHECK_ARG(te >= 2 && te <= MAX_TE && ldx >= I + te, "dmm_qsample_temb: te=%d must be 2..%d and ldx >= I+te", te, MAX_TE);
   DMM_CHECK_ARG(!(noise || draw_noise) || (sqrt_ac && sqrt_1mac), "dmm_qsample_temb: schedule tables missing");
   hipLaunchKernelGGL(qsample_temb_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x0, (long long)ldx0, noise, t, sqrt_ac, sqrt_1mac, w_emb,
-                     b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out);
+                     b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out,
+                     (const uint32_t*)nullptr, 0ll);
   DMM_LAUNCH_CHECK("dmm_qsample_temb");
+  return 0;
+}
+
+extern "C" int dmm_qsample_temb_bits(const uint32_t* x0bits, int64_t ldb, const float* noise, const int32_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                                     const float* w_emb, const float* b_emb, int te, float* xcat, int64_t ldx, int B, int I, int draw_noise, uint64_t seed,
+                                     uint64_t offset, float* eps_out, void* stream) {
+  DMM_CHECK_ARG(x0bits && t && w_emb && b_emb && xcat && B > 0 && I > 0 && ldb * 32 >= I, "dmm_qsample_temb_bits: bad arguments");
+  DMM_CHECK_ARG(te >= 2 && te <= MAX_TE && ldx >= I + te, "dmm_qsample_temb_bits: te=%d must be 2..%d and ldx >= I+te", te, MAX_TE);
+  DMM_CHECK_ARG(!(noise || draw_noise) || (sqrt_ac && sqrt_1mac), "dmm_qsample_temb_bits: schedule tables missing");
+  hipLaunchKernelGGL(qsample_temb_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ll, noise, t, sqrt_ac, sqrt_1mac, w_emb,
+                     b_emb, te, xcat, (long long)ldx, I, draw_noise, (unsigned long long)seed, (unsigned long long)offset, eps_out, x0bits, (long long)ldb);
+  DMM_LAUNCH_CHECK("dmm_qsample_temb_bits");
+  return 0;
+}
+
+// x_0 rows as bit masks: bits[b, w] bit k = 1 iff item 32 w + k is an interaction of user rows[b] (one workgroup per row: clear, then set)
+__global__ __launch_bounds__(256) void csr_row_bits_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                           const long long* __restrict__ rows, uint32_t* __restrict__ bits, long long ldb, int I) {
+  extern __shared__ uint32_t wb[];
+  const int b = blockIdx.x, W = (I + 31) >> 5;
+  for (int w = threadIdx.x; w < W; w += 256) wb[w] = 0u;
+  __syncthreads();
+  const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int c = col[e];
+    if ((unsigned)c < (unsigned)I) atomicOr(&wb[c >> 5], 1u << (c & 31));
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < ldb; w += 256) bits[(long long)b * ldb + w] = w < W ? wb[w] : 0u;
+}
+
+extern "C" int dmm_csr_row_bits(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, uint32_t* bits, int64_t ldb, void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && bits && B > 0 && I > 0 && ldb * 32 >= I, "dmm_csr_row_bits: bad arguments (ldb words >= ceil(I / 32))");
+  const size_t lds = (size_t)((I + 31) >> 5) * 4;
+  DMM_CHECK_ARG(lds <= 60 * 1024, "dmm_csr_row_bits: I=%d too large for the LDS row mask (<= 491520)", I);
+  hipLaunchKernelGGL(csr_row_bits_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, bits,
+                     (long long)ldb, I);
+  DMM_LAUNCH_CHECK("dmm_csr_row_bits");
   return 0;
 }
 
@@ -821,8 +865,17 @@ extern "C" int dmm_diff_loss(const float* out, const float* x0, int64_t ld, cons
                              float sim_weight, double reg_term, double gscale, double* loss, float* dout, float* dum, void* stream) {
   DMM_CHECK_ARG(out && x0 && w && um && ui && (loss || dum) && B > 0 && I > 0 && d > 0, "dmm_diff_loss: bad arguments");
   hipLaunchKernelGGL(diff_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, x0, (long long)ld, w, um, ui, I, d, sim_weight, reg_term,
-                     gscale, loss, dout, dum);
+                     gscale, loss, dout, dum, (const uint32_t*)nullptr, 0ll);
   DMM_LAUNCH_CHECK("dmm_diff_loss");
+  return 0;
+}
+
+extern "C" int dmm_diff_loss_bits(const float* out, int64_t ld, const uint32_t* x0bits, int64_t ldb, const double* w, const float* um, const float* ui, int B,
+                                  int I, int d, float sim_weight, double reg_term, double* loss, void* stream) {
+  DMM_CHECK_ARG(out && x0bits && w && um && ui && loss && B > 0 && I > 0 && d > 0 && ldb * 32 >= I, "dmm_diff_loss_bits: bad arguments");
+  hipLaunchKernelGGL(diff_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, (const float*)nullptr, (long long)ld, w, um, ui, I, d, sim_weight,
+                     reg_term, 0.0, loss, (float*)nullptr, (float*)nullptr, x0bits, (long long)ldb);
+  DMM_LAUNCH_CHECK("dmm_diff_loss_bits");
   return 0;
 }
 

@@ -272,7 +272,8 @@ struct ExpandFusedP {
   const float* P; long long ldp;    // [B, D]
   const float* F; long long ldf;    // [I, D]
   const float* R; long long ldr;    // MODE 0: residual rows; MODE 1: `out` rows
-  const float* X0; long long ldx0;  // MODE 1: x_0 rows
+  const float* X0; long long ldx0;  // MODE 1: x_0 rows (dense) ...
+  const uint32_t* X0b; long long ldb;  // ... or as bit masks (used when X0 is NULL)
   const double* w; double gscale;   // MODE 1: per-row loss weights
   __bf16* Y16; long long ldy;       // [B, >= Kc]
   __bf16* YT; long long ldt;        // [Kt, >= Bp]
@@ -324,7 +325,10 @@ __global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFuse
       for (int rt = 0; rt < 4; ++rt) {
         const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
         xx[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < B && col < I) {
+        if (row < B && col < I && !A.X0) {  // bit mask: the lane's 4 columns (col % 4 == 0) sit in one word; bits past I are zero
+          const uint32_t wd = A.X0b[(long long)row * A.ldb + (col >> 5)] >> (col & 31);
+          xx[rt] = make_float4((float)(wd & 1u), (float)((wd >> 1) & 1u), (float)((wd >> 2) & 1u), (float)((wd >> 3) & 1u));
+        } else if (row < B && col < I) {
           const float* p = A.X0 + (long long)row * A.ldx0 + col;
           if (col + 3 < I) xx[rt] = *reinterpret_cast<const float4*>(p);
           else {
@@ -489,14 +493,14 @@ extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, i
   DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_expand_fused: D=%d unsupported (64 or 128)", D);
   DMM_CHECK_ARG(a->P && a->F && a->R && a->Y16 && a->YT && a->B > 0 && a->I > 0 && a->Kc >= a->I && a->Kc % 4 == 0 && a->Kt > 0 && a->Kt <= a->Kc,
                 "dmm_item_expand_fused: bad arguments");
-  DMM_CHECK_ARG(mode == 0 || (a->X0 && a->w && a->csum), "dmm_item_expand_fused: mode 1 needs x0, w and csum");
+  DMM_CHECK_ARG(mode == 0 || ((a->X0 || (a->X0bits && a->ldbits * 32 >= a->I)) && a->w && a->csum), "dmm_item_expand_fused: mode 1 needs x0 (rows or bit masks), w and csum");
   const int Bp = (a->B + 63) & ~63;
-  DMM_CHECK_ARG(a->ldp % 4 == 0 && a->ldf % 4 == 0 && a->ldr % 4 == 0 && (mode == 0 || a->ldx0 % 4 == 0) && a->ldy % 4 == 0 && a->ldy >= a->Kc && a->ldt % 8 == 0 &&
+  DMM_CHECK_ARG(a->ldp % 4 == 0 && a->ldf % 4 == 0 && a->ldr % 4 == 0 && (mode == 0 || !a->X0 || a->ldx0 % 4 == 0) && a->ldy % 4 == 0 && a->ldy >= a->Kc && a->ldt % 8 == 0 &&
                     a->ldt >= Bp && (mode == 1 || a->ldr >= a->Kc) &&
                     (((uintptr_t)a->P | (uintptr_t)a->F | (uintptr_t)a->R | (uintptr_t)a->X0 | (uintptr_t)a->YT) & 15) == 0 && ((uintptr_t)a->Y16 & 7) == 0,
                 "dmm_item_expand_fused: operands must be 16-byte aligned (Y16: 8) with leading dimensions that are multiples of 4 (YT: of 8, >= round_up(B, 64))");
   ExpandFusedP p;
-  p.P = a->P; p.ldp = a->ldp; p.F = a->F; p.ldf = a->ldf; p.R = a->R; p.ldr = a->ldr; p.X0 = a->X0; p.ldx0 = a->ldx0; p.w = a->w; p.gscale = a->gscale;
+  p.P = a->P; p.ldp = a->ldp; p.F = a->F; p.ldf = a->ldf; p.R = a->R; p.ldr = a->ldr; p.X0 = a->X0; p.ldx0 = a->ldx0; p.X0b = a->X0bits; p.ldb = a->ldbits; p.w = a->w; p.gscale = a->gscale;
   p.Y16 = (__bf16*)a->Y16; p.ldy = a->ldy; p.YT = (__bf16*)a->YT; p.ldt = a->ldt; p.csum = a->csum; p.B = a->B; p.I = a->I; p.Kc = a->Kc; p.Kt = a->Kt;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((a->Kc + 255) / 256, Bp / 64);

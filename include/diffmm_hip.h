@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 205
+#define DMM_VERSION 206
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -281,6 +281,15 @@ int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const in
  *   dmm_csr_add_rows         y[b, j] += c (and y16[b, j] = bf16 of it) for j in items(rows[b]): the posterior-mean residual c2 * x_0 of that step
  *                            (Model.py:375) without a dense x_0; y == NULL: the row is kept in bf16 only (y16 read and written). */
 int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream);
+/* x_0 rows as BIT MASKS: bits[b, w] bit k = 1 iff item 32 w + k is an interaction of user rows[b] (ldb words per row, ldb * 32 >= I; the words'
+ * unused bits are zero).  The training step's three readers of the dense 0/1 rows take the masks instead -- 1/32 of the bytes:
+ * dmm_qsample_temb_bits, dmm_diff_loss_bits (forward loss), dmm_item_expand_fused mode 1 (X0bits). */
+int dmm_csr_row_bits(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, uint32_t* bits, int64_t ldb, void* stream);
+int dmm_qsample_temb_bits(const uint32_t* x0bits, int64_t ldb, const float* noise, const int32_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                          const float* w_emb, const float* b_emb, int te, float* xcat, int64_t ldx, int B, int I, int draw_noise, uint64_t seed,
+                          uint64_t offset, float* eps_out, void* stream);
+int dmm_diff_loss_bits(const float* out, int64_t ld, const uint32_t* x0bits, int64_t ldb, const double* w, const float* um, const float* ui, int B, int I,
+                       int d, float sim_weight, double reg_term, double* loss /*[B]*/, void* stream);
 int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias, int H,
                             int act, void* out16, int64_t ldo, void* stream);
 int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float c, float* y, int64_t ldy, void* y16, int64_t ldy16,
@@ -353,6 +362,7 @@ typedef struct dmm_expand_fused_args {
   void* YT; int64_t ldt;         /* bf16 [Kt, >= round_up(B, 64)] */
   float* csum;                   /* mode 1: [I], accumulated into */
   int32_t B, I, Kc, Kt;
+  const uint32_t* X0bits; int64_t ldbits; /* mode 1, X0 == NULL: x_0 as bit masks (dmm_csr_row_bits), ldbits words per row */
 } dmm_expand_fused_args;
 int dmm_item_expand_fused(const dmm_expand_fused_args* a /*host*/, int mode, int D, void* stream);
 /* The same product for up to 4 problems in one launch, 64 rows per workgroup (many short rows), with the layouts of the joint step's
