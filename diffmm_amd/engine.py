@@ -472,6 +472,7 @@ class DiffusionEngine:
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
         self._x0_rows, self._ie16 = None, None  # the current training batch as CSR rows (if it came as such); bf16 i_embs for its gather
         self._FT16 = None  # F^T operands of the folded products (_folded_prepare)
+        self._x0_bits, self._bits_buf = None, None  # the current batch's x_0 rows as bit masks (batched bf16 step fed with CSR rows)
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
@@ -702,9 +703,14 @@ class DiffusionEngine:
         for m in range(M):
             a, P = self.act[m], self.P[m]
             a["t"][:B].copy_(ts[m])
-            ops.qsample_temb(x0p, noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, P.view("emb_layer.weight"),
-                             P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None, seed=self.hp.get("seed", 1818),
-                             offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
+            if self._x0_bits is not None:  # x_0 as bit masks: 1/32 of the bytes of the dense 0/1 rows
+                ops.qsample_temb_bits(self._x0_bits[:B], noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac,
+                                      P.view("emb_layer.weight"), P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None,
+                                      seed=self.hp.get("seed", 1818), offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
+            else:
+                ops.qsample_temb(x0p, noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, P.view("emb_layer.weight"),
+                                 P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None, seed=self.hp.get("seed", 1818),
+                                 offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
             self._project_items(a["xcat"][:B], feats[m], a["proj"][:B], 1)
         # the modalities' gate layers (d x d, one tile each) in one launch
         ops.gemm_batched([dict(A=self.act[m]["proj"][:B], B=self.P[m].view("gate_layer.weight"), out=self.act[m]["gate"][:B], trans_b=True,
@@ -760,7 +766,10 @@ class DiffusionEngine:
                 else:
                     self._project_items(x0p, i_embs, self.ui[:B], 1)
             a["w"] = self.w_table[a["t"][:B].long()]
-            ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
+            if self._x0_bits is not None:
+                ops.diff_loss_bits(a["out"][:B], self._x0_bits[:B], a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, a["loss"][:B])
+            else:
+                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
 
     def _backward_batched(self, x0p: Tensor, feats, reg_term: float, gscale: float):
         B, I, H, D, Kp, M = x0p.shape[0], self.I, self.H, self.D, self.Kp, self.M
@@ -778,8 +787,8 @@ class DiffusionEngine:
                 # and its column sums (the output bias gradient, into the zeroed vector)
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, None, None, w["dum"][:B])
                 ops.zero_(P.g(self.L2 + ".bias"))
-                ops.item_expand_fused(w["dum"][:B], feats[m], a["out"][:B], w["xb16"][:B], w["doutT16"], I, self.Kp, I, x0=x0p, w=a["w"], gscale=gscale,
-                                      csum=P.g(self.L2 + ".bias"))
+                ops.item_expand_fused(w["dum"][:B], feats[m], a["out"][:B], w["xb16"][:B], w["doutT16"], I, self.Kp, I, w=a["w"], gscale=gscale,
+                                      csum=P.g(self.L2 + ".bias"), **(dict(x0bits=self._x0_bits[:B]) if self._x0_bits is not None else dict(x0=x0p)))
             else:
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
                               w["dum"][:B])
@@ -860,8 +869,19 @@ class DiffusionEngine:
             reg_term = self.reg_term(i_embs)
         sums = torch.zeros(M, dtype=torch.float64, device=self.dev)
         if B:
-            x0p = self._set_x0(x0)
             self._x0_rows = x0 if isinstance(x0, CsrRows) else None
+            self._x0_bits = None
+            if precision == 1 and self._x0_rows is not None and self._fused_expand() and self.I <= 480000 and \
+                    self.hp.get("x0_bits", os.environ.get("DMM_X0_BITS", "1") != "0"):
+                # the batched bf16 step reads x_0 in three places (q_sample, loss, loss gradient) and sums its i_embs rows: bit masks + the
+                # CSR gather serve all of them -- no dense [B, I] x_0 operand is built for this step at all
+                if self._bits_buf is None:
+                    self._bits_buf = torch.zeros(self.B_max, (self.I + 31) // 32, dtype=torch.int32, device=self.dev)
+                self._x0_bits = self._bits_buf
+                ops.csr_row_bits(x0.ptr, x0.col, x0.users, self.I, self._x0_bits[:B])
+                x0p = self.x0p[:B]  # (not filled: nothing on this path reads it)
+            else:
+                x0p = self._set_x0(x0)
             ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32, generator=self.t_gen)).to(torch.int32)
                   for m in range(M)]
             if precision == 1:  # the modalities' large GEMMs go out as one batched launch each (enough 256 x 256 tiles to fill the chip)

@@ -451,6 +451,33 @@ def qsample_temb(x0: Optional[Tensor], noise: Optional[Tensor], t: Tensor, sqrt_
                                      offset, L.ptr(eps_out), L.stream())
 
 
+def qsample_temb_bits(x0bits: Tensor, noise: Optional[Tensor], t: Tensor, sqrt_ac: Tensor, sqrt_1mac: Tensor, w_emb: Tensor, b_emb: Tensor, xcat: Tensor,
+                      I: int, draw_noise: bool = False, seed: int = 0, offset: int = 0, eps_out: Optional[Tensor] = None) -> None:
+    """qsample_temb with x_0 given as bit masks (csr_row_bits): int32 [B, >= ceil(I / 32)]."""
+    B, te = t.shape[0], w_emb.shape[0]
+    if x0bits.dtype != torch.int32 or x0bits.stride(1) != 1 or x0bits.shape[0] < B or x0bits.shape[1] * 32 < I:
+        raise ValueError("qsample_temb_bits: x0bits must be int32 [B, >= ceil(I / 32)]")
+    L.call("dmm_qsample_temb_bits", L.ptr(x0bits), x0bits.stride(0), L.ptr(noise), L.ptr(_i32c(t, "t")), L.ptr(sqrt_ac), L.ptr(sqrt_1mac), L.ptr(w_emb),
+           L.ptr(b_emb), te, L.ptr(xcat), xcat.stride(0), B, I, int(draw_noise), seed, offset, L.ptr(eps_out), L.stream())
+
+
+def csr_row_bits(ptr: Tensor, col: Tensor, rows: Tensor, I: int, bits: Tensor) -> None:
+    """bits[b, w] bit k = 1 iff item 32 w + k is an interaction of user rows[b]; bits int32 [B, ld >= ceil(I / 32)], whole rows written."""
+    p, c, r, B = _csr_args(ptr, col, rows)
+    if bits.dtype != torch.int32 or bits.stride(1) != 1 or bits.shape[0] < B or bits.shape[1] * 32 < I:
+        raise ValueError("csr_row_bits: bits must be int32 [B, >= ceil(I / 32)]")
+    L.call("dmm_csr_row_bits", p, c, r, B, I, L.ptr(bits), bits.stride(0), L.stream())
+
+
+def diff_loss_bits(out: Tensor, x0bits: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, loss: Tensor) -> None:
+    """diff_loss forward (loss only) with x_0 given as bit masks."""
+    B, d = um.shape
+    if w.dtype != torch.float64 or loss.dtype != torch.float64 or x0bits.dtype != torch.int32 or x0bits.shape[1] * 32 < I:
+        raise ValueError("diff_loss_bits: w / loss float64, x0bits int32 [B, >= ceil(I / 32)]")
+    L.call("dmm_diff_loss_bits", L.ptr(out), out.stride(0), L.ptr(x0bits), x0bits.stride(0), L.ptr(w), L.ptr(um), L.ptr(ui), B, I, d, sim_weight, reg_term,
+           L.ptr(loss), L.stream())
+
+
 def _csr_args(ptr: Tensor, col: Tensor, rows: Tensor):
     if ptr.dtype != torch.int64 or col.dtype != torch.int32 or rows.dtype != torch.int64 or not (ptr.is_contiguous() and col.is_contiguous() and rows.is_contiguous()):
         raise ValueError("CSR rows: ptr int64, col int32, rows int64, all contiguous")
@@ -635,12 +662,12 @@ def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:
 
 
 def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, I: int, Kc: int, Kt: int, x0: Optional[Tensor] = None,
-                      w: Optional[Tensor] = None, gscale: float = 0.0, csum: Optional[Tensor] = None) -> None:
+                      w: Optional[Tensor] = None, gscale: float = 0.0, csum: Optional[Tensor] = None, x0bits: Optional[Tensor] = None) -> None:
     """item_expand whose result goes straight into the bf16 operands of the next GEMMs (Y16 [B, Kc] row-major, YT [Kt, round_up(B, 64)]
     transposed).  x0 / w / csum given: the loss-gradient form v = gscale w[b] 2/I (R - x0) + P F^T with its column sums added to csum."""
     B, D = P.shape[0], P.shape[1]
-    mode = 0 if x0 is None else 1
-    for t in (P, F, R) + ((x0,) if mode else ()):
+    mode = 0 if (x0 is None and x0bits is None) else 1
+    for t in (P, F, R) + ((x0,) if x0 is not None else ()):
         if t.dtype != torch.float32 or t.stride(1) != 1:
             raise ValueError("item_expand_fused: fp32 tensors with unit inner stride")
     Bp = (B + 63) & ~63
@@ -653,7 +680,13 @@ def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, 
     if mode:
         if w.dtype != torch.float64 or csum is None or csum.numel() < I:
             raise ValueError("item_expand_fused: w is float64 [B], csum fp32 [I]")
-        a.X0, a.ldx0, a.w, a.gscale, a.csum = L.ptr(x0), x0.stride(0), L.ptr(w), float(gscale), L.ptr(_f32c(csum, "csum"))
+        a.w, a.gscale, a.csum = L.ptr(w), float(gscale), L.ptr(_f32c(csum, "csum"))
+        if x0 is not None:
+            a.X0, a.ldx0 = L.ptr(x0), x0.stride(0)
+        else:  # x_0 as bit masks (csr_row_bits)
+            if x0bits.dtype != torch.int32 or x0bits.stride(1) != 1 or x0bits.shape[0] < B or x0bits.shape[1] * 32 < I:
+                raise ValueError("item_expand_fused: x0bits must be int32 [B, >= ceil(I / 32)]")
+            a.X0bits, a.ldbits = L.ptr(x0bits), x0bits.stride(0)
     L.call("dmm_item_expand_fused", C.byref(a), mode, D, L.stream())
 
 

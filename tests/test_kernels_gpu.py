@@ -764,6 +764,53 @@ def test_item_expand_fused_equals_the_separate_passes(dev, D, B, I):
     close(gotc, wantc, rtol=1e-4, atol=1e-6 * float(wantc.abs().max()) + 1e-9, what="column sums")
 
 
+def test_x0_bit_masks_equal_the_dense_rows(dev):
+    """dmm_csr_row_bits and the three readers of x_0 that take bit masks instead of dense 0/1 rows: q_sample (explicit noise and the
+    in-kernel Philox draw), the forward diffusion loss and the fused loss gradient -- bit for bit what the dense rows give."""
+    from diffmm_amd import ops, synth
+    from diffmm_amd.DataHandler import DiffusionData
+    torch.manual_seed(9)
+    g = synth.named("mid")
+    U, I, D, B, te = g.users, g.items, 64, 200, 10
+    dd = DiffusionData(g.trn_rows, g.trn_cols, U, I, dev)
+    users = torch.randperm(U, device=dev)[:B]
+    rows = dd.csr_rows(users)
+    x0 = dd.rows(users)
+    W = (I + 31) // 32
+    bits = torch.full((B, W + 3), -1, dtype=torch.int32, device=dev)
+    ops.csr_row_bits(rows.ptr, rows.col, rows.users, I, bits)
+    cols = torch.arange(I, device=dev)
+    unpacked = ((bits[:, cols >> 5] >> (cols & 31)) & 1).float()
+    assert torch.equal(unpacked, x0) and int(bits[:, W:].abs().sum()) == 0, "bit masks (whole leading dimension written, spare bits zero)"
+    Kp = (I + te + 63) // 64 * 64
+    t = torch.randint(0, 6, (B,), device=dev, dtype=torch.int32)
+    sa, sb = torch.rand(6, device=dev), torch.rand(6, device=dev)
+    we, be = torch.randn(te, te, device=dev), torch.randn(te, device=dev)
+    x0p = torch.zeros(B, Kp, device=dev); x0p[:, :I] = x0
+    noise = torch.randn(B, I, device=dev)
+    for kw in (dict(noise=noise), dict(noise=None, draw_noise=True, seed=5, offset=77)):
+        a, b = torch.zeros(B, Kp, device=dev), torch.zeros(B, Kp, device=dev)
+        ops.qsample_temb(x0p, kw.get("noise"), t, sa, sb, we, be, a, I, draw_noise=kw.get("draw_noise", False), seed=kw.get("seed", 0), offset=kw.get("offset", 0))
+        ops.qsample_temb_bits(bits, kw.get("noise"), t, sa, sb, we, be, b, I, draw_noise=kw.get("draw_noise", False), seed=kw.get("seed", 0), offset=kw.get("offset", 0))
+        assert torch.equal(a, b), "q_sample from bit masks"
+    out = torch.randn(B, Kp, device=dev)
+    w = torch.rand(B, device=dev, dtype=torch.float64) + 0.5
+    um, ui = torch.randn(B, D, device=dev), torch.randn(B, D, device=dev)
+    l1, l2 = torch.zeros(B, device=dev, dtype=torch.float64), torch.zeros(B, device=dev, dtype=torch.float64)
+    ops.diff_loss(out, x0p, w, um, ui, I, 0.1, 0.01, 0.0, l1, None, None)
+    ops.diff_loss_bits(out, bits, w, um, ui, I, 0.1, 0.01, l2)
+    assert torch.equal(l1, l2), "diffusion loss from bit masks"
+    F, dum = torch.randn(I, D, device=dev), torch.randn(B, D, device=dev)
+    Bp = (B + 63) // 64 * 64
+    res = []
+    for kw in (dict(x0=x0p), dict(x0bits=bits)):
+        y16, yT, cs = torch.zeros(B, Kp, device=dev, dtype=torch.bfloat16), torch.zeros(I, Bp, device=dev, dtype=torch.bfloat16), torch.zeros(I, device=dev)
+        ops.item_expand_fused(dum, F, out, y16, yT, I, Kp, I, w=w, gscale=1e-3, csum=cs, **kw)
+        res.append((y16, yT, cs))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "fused loss gradient from bit masks"
+    close(res[1][2], res[0][2], rtol=1e-4, atol=1e-6 * float(res[0][2].abs().max()) + 1e-12, what="column sums")
+
+
 @pytest.mark.parametrize("D", [64, 128])
 def test_item_project_batched_layouts(dev, D):
     """dmm_item_project_batched (the joint step's modality projections and their weight gradients) against fp64 products of the bf16-rounded
