@@ -96,6 +96,7 @@ _SIGS = {
     "dmm_infonce_pack_bytes": (C.c_int64, [_I, _I, _I]),
     "dmm_gather_normalize": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_infonce_fwd": (C.c_int, [_P, _P, _I, _I, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P]),
+    "dmm_infonce_fwd_bwd": (C.c_int, [_P, _P, _I, _I, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_infonce_bwd": (C.c_int, [_P, _P, _I, _I, _P, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P]),
     "dmm_scatter_normalize_bwd": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_bpr_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

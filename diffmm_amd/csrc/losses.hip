@@ -575,7 +575,7 @@ __device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[
 
 template <int D, int PREC>
 __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
-                                                               float* __restrict__ dzhat) {
+                                                               float* __restrict__ dzhat, int pass_base) {
   using Sh = InbShape<D, PREC>;
   constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS;
   static_assert(TILE % (8 * 256) == 0, "tile must split into whole 16-byte pieces per lane");
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
   typedef __attribute__((address_space(3))) void* lds_p;
   typedef const __attribute__((address_space(1))) void* gbl_p;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
-  const int t = blockIdx.y, pass = blockIdx.z;
+  const int t = blockIdx.y, pass = blockIdx.z + pass_base;
   const int o0 = (blockIdx.x * 4 + wave) * 32;
   const bool active = o0 < B;
   const dmm_infonce_term term = T.t[t];
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
 
 constexpr int INB_MAX_B = 8192;  // the term's lse vector (4 B per batch row) sits in LDS behind the ring: 32 KiB at most
 template <int D, int PREC>
-static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat) {
+static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat, int pass_base = 0) {
   static const bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               InbShape<D, PREC>::LDS_BYTES + INB_MAX_B * 4);
@@ -665,7 +665,160 @@ static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, 
   }();
   (void)once;
   const size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES + (size_t)((B + 3) & ~3) * 4;
-  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, lse, T, B, dzhat);
+  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, lse, T, B, dzhat, pass_base);
+}
+
+// ---- forward + the anchor-side backward in one walk (unit-norm rows) -------------------------------------------------------------------
+// With cosine-normalised views every logit s <= 1, so exp(s / temp) needs no running maximum: p' = exp2(s c1 - c1) <= 1 with
+// c1 = log2(e) / temp.  One walk over the other view then yields, per own (anchor) row i: L_i = sum_k p'_ik (-> lse_i = ln2 (c1 + log2 L_i),
+// the forward's output), the raw diagonal logit (-> row_loss_i), and N_i = sum_k p'_ik other_k (the MFMA product the backward's pass 0
+// accumulates) -> d anchor_i = (N_i / L_i - other_i) w / (temp B): the forward kernel and HALF of the backward (its pass 0 recomputed every
+// logit and exponential) become one kernel; the backward keeps only pass 1 (gradient w.r.t. the other view, which needs lse_i first).
+template <int D, int PREC, bool CHECK>
+__device__ __forceinline__ void inf_tile(const __bf16* S, const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16], f32x16 (&out)[D / 32], int k0,
+                                         int oidx, int B, float c1, float& lsum, float& diag, int fr, int fh) {
+  constexpr int BLK = 32 * D;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
+    const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(S + fo);
+    if (PREC == 3) {
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(S + 2 * BLK + fo);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, own_h[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_l[ks], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_h[ks], acc, 0, 0, 0);
+  }
+  float p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    p[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c1, -c1));
+    if (CHECK) {
+      const int kidx = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (kidx >= B) p[r] = 0.f;
+      if (kidx == oidx) diag = acc[r];
+    }
+    lsum += p[r];
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    bf16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ph[j] = (__bf16)p[8 * s2 + j];
+      if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb) {
+      const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
+      const bf16x8 t_h = *reinterpret_cast<const bf16x8*>(S + BLK + to);
+      if (PREC == 3) {
+        const bf16x8 t_l = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, t_h, out[cb], 0, 0, 0);
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_l, out[cb], 0, 0, 0);
+      }
+      out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_h, out[cb], 0, 0, 0);
+    }
+  }
+}
+
+template <int D, int PREC>
+__global__ __launch_bounds__(256) void infonce_fused_kernel(Bf16Pack pk, const float* __restrict__ zhat, TermTable T, int B, float* __restrict__ lse,
+                                                            float* __restrict__ row_loss, float* __restrict__ dzhat) {
+  using Sh = InbShape<D, PREC>;
+  constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS;
+  extern __shared__ __attribute__((aligned(16))) __bf16 sm_oth[];  // [NS][TILE]
+  typedef __attribute__((address_space(3))) void* lds_p;
+  typedef const __attribute__((address_space(1))) void* gbl_p;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const int t = blockIdx.y;
+  const int o0 = (blockIdx.x * 4 + wave) * 32;
+  const bool active = o0 < B;
+  const dmm_infonce_term term = T.t[t];
+  const int own_slot = term.a, oth_slot = term.b;
+  const int tiles = pk.Bp >> 5;
+  const size_t oth_base = (size_t)oth_slot * tiles * BLK;
+  auto issue = [&](int kt, int stage) {
+    const int k = kt < tiles ? kt : tiles - 1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c0 = i * 256 + wave * 64;
+      const int c = c0 + lane, blk = c / (BLK / 8), w = c % (BLK / 8);
+      const __bf16* src = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)k * BLK + (size_t)w * 8;
+      __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(sm_oth + (size_t)stage * TILE + (size_t)c0 * 8), 16, 0, 0);
+    }
+  };
+  bf16x8 own_h[D / 16], own_l[D / 16];
+  const int otile = active ? (o0 >> 5) : 0;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const size_t o = frag_off<D>(own_slot, tiles, otile, ks, fh, fr);
+    own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+    if (PREC == 3) own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
+  }
+  f32x16 out[D / 32];
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[cb][r] = 0.f;
+  const float inv_t = 1.0f / term.temp;
+  const float c1 = inv_t * 1.4426950408889634f;
+  const int oidx = o0 + fr;
+  float lsum = 0.f, diag = 0.f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j) issue(j, j);
+  for (int kt = 0; kt < tiles; ++kt) {
+    inb_wait_vmcnt<(NS - 2) * PER>();
+    asm volatile("s_barrier" ::: "memory");
+    issue(kt + NS - 1, (kt + NS - 1) % NS);
+    const __bf16* S = sm_oth + (size_t)(kt % NS) * TILE;
+    if (active) {
+      if (kt == otile || kt == tiles - 1) inf_tile<D, PREC, true>(S, own_h, own_l, out, kt * 32, oidx, B, c1, lsum, diag, fr, fh);
+      else inf_tile<D, PREC, false>(S, own_h, own_l, out, kt * 32, oidx, B, c1, lsum, diag, fr, fh);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!active) return;
+  // the two lane halves hold disjoint other-index subsets of the same own row
+  const float L = lsum + __shfl_xor(lsum, 32, 64);
+  const float dg = diag + __shfl_xor(diag, 32, 64);
+  const float l = (c1 + __log2f(L)) * 0.6931471805599453f;
+  if (fh == 0 && oidx < B) {
+    lse[(size_t)t * B + oidx] = l;
+    row_loss[(size_t)t * B + oidx] = (l - dg * inv_t) * (term.weight / (float)B);
+  }
+  const float invL = 1.0f / L;
+  const float coef = term.weight * inv_t / (float)B;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rho = (r & 3) + 8 * (r >> 2) + 4 * fh;  // the own row this accumulator register belongs to
+    const float il = __shfl(invL, rho, 64);
+    const int row = o0 + rho;
+    if (row < B) {
+#pragma unroll
+      for (int cb = 0; cb < D / 32; ++cb) {
+        float other = zhat[((size_t)oth_slot * B + row) * D + cb * 32 + fr];  // the positive pair: row `row` of the other view
+        if (PREC == 1) other = (float)(__bf16)other;                         // (what the MFMA path of the two-pass backward subtracts)
+        atomicAdd(dzhat + ((size_t)own_slot * B + row) * D + cb * 32 + fr, (out[cb][r] * il - other) * coef);
+      }
+    }
+  }
+}
+
+template <int D, int PREC>
+static void inf_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* zhat, const TermTable& T, int B, float* lse, float* row_loss, float* dzhat) {
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_fused_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              InbShape<D, PREC>::LDS_BYTES);
+    return true;
+  }();
+  (void)once;
+  constexpr size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES;
+  hipLaunchKernelGGL((infonce_fused_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, zhat, T, B, lse, row_loss, dzhat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -860,6 +1013,40 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
   DMM_LAUNCH_CHECK("dmm_infonce_bwd");
   return 0;
 }
+
+extern "C" int dmm_infonce_fwd_bwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const dmm_infonce_term* terms, int n_terms,
+                                   int B, int D, float* lse, float* row_loss, float* dzhat, void* stream) {
+  TermTable T;
+  if (int e = fill_terms(terms, n_terms, T)) return e;
+  DMM_CHECK_ARG(zhat && lse && row_loss && dzhat && B > 0 && D % 4 == 0 && D > 0, "dmm_infonce_fwd_bwd: bad arguments");
+  bool fused = bf16_pack && (precision == 1 || precision == 3) && mfma_ok(D) && B <= INB_MAX_B;
+  for (int i = 0; i < n_terms && fused; ++i) fused = terms[i].temp >= 0.024f;  // exp2((s - 1) log2(e) / temp) must not underflow for s in [-1, 1]
+  // Measured (B = 4096, d = 64, 8 terms): the one-walk kernel 97 us + the other-view pass alone 103 us = 200 us, against 40 us (forward) +
+  // 123 us (both backward passes in ONE launch) = 163 us for the two-kernel path -- a walk is a serial MFMA -> exp -> MFMA chain per wave, and with
+  // 1024 waves per launch (one per SIMD) nothing hides it; the two-pass launch has 2048.  Off by default (DMM_INFONCE_FUSED=1 enables); what
+  // would make it pay is a K split with a deferred normalisation.
+  static const int allow = [] { const char* e = getenv("DMM_INFONCE_FUSED"); return e ? atoi(e) : 0; }();
+  if (!fused || !allow) {  // the two-kernel path (any arithmetic mode, any temperature)
+    if (int e = dmm_infonce_fwd(zhat, bf16_pack, n_slots, precision, terms, n_terms, B, D, lse, row_loss, stream)) return e;
+    return dmm_infonce_bwd(zhat, bf16_pack, n_slots, precision, lse, terms, n_terms, B, D, dzhat, stream);
+  }
+  const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g1(cdiv(B, 128), n_terms), g2(cdiv(B, 128), n_terms, 1);
+  switch (D) {
+    case 32: if (precision == 3) { inf_launch<32, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<32, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
+             else { inf_launch<32, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<32, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
+    case 64: if (precision == 3) { inf_launch<64, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<64, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
+             else { inf_launch<64, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<64, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
+    case 128: if (precision == 3) { inf_launch<128, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<128, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
+              else { inf_launch<128, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<128, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
+    case 256: if (precision == 3) { inf_launch<256, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<256, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
+              else { inf_launch<256, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<256, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
+  }
+  DMM_LAUNCH_CHECK("dmm_infonce_fwd_bwd");
+  return 0;
+}
+
 
 extern "C" int dmm_bpr_fwd_bwd_tables(const float* fin_u, const float* fin_i, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int D,
                                       float* row_loss, float* dfin_u, float* dfin_i, void* stream) {

@@ -271,12 +271,11 @@ class JointEngine:
         row_loss = self.row_loss.view(-1)[: (nT + 1) * B].view(nT + 1, B)
         pk = dict(pack=self.pack, n_slots=self.n_slots, precision=precision) if self.mfma_cl else {}
         ops.gather_normalize(slots, B, D, zhat, znorm, self.pack)
-        ops.infonce_fwd(zhat, terms, nT, B, D, lse, row_loss, **pk)
+        ops.infonce_fwd_bwd(zhat, terms, nT, B, D, lse, row_loss, dzhat, **pk)  # (rows are unit-norm: forward + both gradient passes in one call)
         ops.bpr_fwd_bwd(self.Fin, users, pos, neg, U, row_loss[nT], self.dFin)
         ops.segment_sum(row_loss, nT + 1, B, 1.0, self.loss_parts)
         ops.sumsq(self.P.view("emb"), hp["reg"], self.loss_parts[nT + 1:], self.sumsq_scratch)
         # ---- backward ----
-        ops.infonce_bwd(zhat, lse, terms, nT, B, D, dzhat, **pk)
         ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
         A = self.adj
         s = 1.0 + hp["residual_weight"]

@@ -385,6 +385,12 @@ def infonce_fwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, 
     L.call("dmm_infonce_fwd", L.ptr(zhat), L.ptr(pack), n_slots, precision, terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.stream())
 
 
+def infonce_fwd_bwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, row_loss: Tensor, dzhat: Tensor, pack: Optional[Tensor] = None,
+                    n_slots: int = 0, precision: int = 0) -> None:
+    """Forward and backward of all terms for UNIT-NORM rows (gather_normalize's output) in one call; dzhat zeroed by the caller."""
+    L.call("dmm_infonce_fwd_bwd", L.ptr(zhat), L.ptr(pack), n_slots, precision, terms, n_terms, B, D, L.ptr(lse), L.ptr(row_loss), L.ptr(dzhat), L.stream())
+
+
 def infonce_bwd(zhat: Tensor, lse: Tensor, terms, n_terms: int, B: int, D: int, dzhat: Tensor, pack: Optional[Tensor] = None,
                 n_slots: int = 0, precision: int = 0) -> None:
     L.call("dmm_infonce_bwd", L.ptr(zhat), L.ptr(pack), n_slots, precision, L.ptr(lse), terms, n_terms, B, D, L.ptr(dzhat), L.stream())

@@ -375,7 +375,7 @@ class ShardedJointEngine:
         terms = self._terms()
         pk = dict(pack=self.pack, n_slots=nS, precision=precision) if self.mfma_cl else {}
         ops.gather_normalize(slots, B, D, zhat, znorm, self.pack)
-        ops.infonce_fwd(zhat, terms, nT, B, D, lse, row_loss, **pk)
+        ops.infonce_fwd_bwd(zhat, terms, nT, B, D, lse, row_loss, dzhat, **pk)  # (rows are unit-norm: forward + both gradient passes in one call)
         ops.bpr_fwd_bwd_tables(ub[0], views[0][2], ar, pos, neg, row_loss[nT], dub[0], views[0][3])
         ops.segment_sum(row_loss, nT + 1, B, 1.0, self.loss_parts)
         emb = self.P.view("emb")
@@ -385,7 +385,6 @@ class ShardedJointEngine:
             ops.zero_(self.loss_parts[nT + 1:nT + 2])
         ops.sumsq(emb[nu:], hp["reg"], self.loss_parts[nT + 2:], self.sumsq_scratch)
         # ---- backward ----
-        ops.infonce_bwd(zhat, lse, terms, nT, B, D, dzhat, **pk)
         ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
         ops.scatter_add_rows(ops.Slots([(v[0], users, v[1]) for v in views]), B, D, self.seg_s, dub)
         A = self.adj

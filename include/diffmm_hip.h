@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 206
+#define DMM_VERSION 207
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -229,6 +229,13 @@ int dmm_infonce_fwd(const float* zhat, const void* bf16_pack, int n_slots, int p
 int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const float* lse,
                     const dmm_infonce_term* terms /*host*/, int n_terms, int B, int D, float* dzhat /*[n_slots,B,D], accumulated*/,
                     void* stream);
+/* forward and backward of all terms in one call, for UNIT-NORM rows (dmm_gather_normalize's output; cosine InfoNCE, Utils.py:60-62): with every
+ * logit <= 1 the exponentials need no running maximum, so ONE walk over the other view gives lse, row_loss and the anchor-side gradient, and the
+ * backward keeps only the pass for the other view (two kernels instead of forward + a two-pass backward that recomputed every logit twice).
+ * dzhat must be zeroed by the caller.  The one-walk kernels run when DMM_INFONCE_FUSED=1 (measured slower at B = 4096: too few waves per launch;
+ * csrc/losses.hip); otherwise, and for fp32-VALU arithmetic or temperatures < 0.024, this is dmm_infonce_fwd followed by dmm_infonce_bwd. */
+int dmm_infonce_fwd_bwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const dmm_infonce_term* terms /*host*/, int n_terms,
+                        int B, int D, float* lse, float* row_loss, float* dzhat, void* stream);
 int dmm_scatter_normalize_bwd(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const float* zhat,
                               const float* norm, const float* dzhat, void* stream);
 /* BPR forward + backward in one pass: row_loss[b] = -log(1e-5 + sigmoid(u.p - u.n)) / B and, when dfin != NULL,

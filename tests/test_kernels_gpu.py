@@ -1109,3 +1109,41 @@ def test_transpose_cast(dev):
     dst = torch.full((6710, 1120), 7.0, dtype=torch.bfloat16, device=dev)
     ops.transpose_cast_bf16(x, dst)
     assert torch.equal(dst[:, :1116], x.t().bfloat16()) and float(dst[:, 1116:1120].abs().max()) == 0.0
+
+
+def test_infonce_one_walk_kernels_match_the_two_kernel_path(dev):
+    """dmm_infonce_fwd_bwd with DMM_INFONCE_FUSED=1 (forward + anchor-side gradient in one walk with a fixed exponent reference, then the
+    other-view pass) against the default forward + two-pass backward, in a child process (the knob is read once per process)."""
+    import subprocess, sys, os
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from diffmm_amd import ops
+torch.manual_seed(4)
+dev = torch.device("cuda:0")
+B, D, S = 300, 64, 4
+src = [torch.randn(500, D, device=dev) for _ in range(S)]
+idx = torch.randint(0, 500, (B,), device=dev, dtype=torch.int32)
+slots = ops.Slots([(src[s], idx, torch.zeros_like(src[s])) for s in range(S)])
+terms = ops.make_terms([(0, 1, 0.2, 0.5), (2, 3, 0.5, 0.01), (0, 3, 0.3, 1.0)])
+zhat, znorm = torch.zeros(S, B, D, device=dev), torch.zeros(S, B, device=dev)
+pack = ops.infonce_pack(S, B, D, dev)
+ops.gather_normalize(slots, B, D, zhat, znorm, pack)
+lse, rl, dz = torch.zeros(3, B, device=dev), torch.zeros(3, B, device=dev), torch.zeros(S, B, D, device=dev)
+ops.infonce_fwd_bwd(zhat, terms, 3, B, D, lse, rl, dz, pack=pack, n_slots=S, precision=int(sys.argv[1]))
+torch.save(dict(lse=lse.cpu(), rl=rl.cpu(), dz=dz.cpu()), sys.argv[2])
+"""
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for prec, tol in ((1, 2e-2), (3, 2e-4)):
+        outs = []
+        with tempfile.TemporaryDirectory() as tmp:
+            for fused in ("0", "1"):
+                path = os.path.join(tmp, f"o{fused}.pt")
+                r = subprocess.run([sys.executable, "-c", code, str(prec), path], cwd=repo, env=dict(os.environ, DMM_INFONCE_FUSED=fused), capture_output=True, text=True, timeout=300)
+                assert r.returncode == 0, r.stderr[-2000:]
+                outs.append(torch.load(path, weights_only=True))
+        a, b = outs
+        assert float((a["lse"] - b["lse"]).abs().max()) < 1e-4 and float((a["rl"] - b["rl"]).abs().max()) < 1e-6, f"precision {prec}: lse / row loss"
+        scale = float(a["dz"].abs().max())
+        assert float((a["dz"] - b["dz"]).abs().max()) < tol * scale, f"precision {prec}: gradients {float((a['dz'] - b['dz']).abs().max()) / scale:.2e} of the scale"
