@@ -575,7 +575,7 @@ __device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[
 
 template <int D, int PREC>
 __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
-                                                               float* __restrict__ dzhat, int pass_base) {
+                                                               float* __restrict__ dzhat, int pass_base, int ksplit) {
   using Sh = InbShape<D, PREC>;
   constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS;
   static_assert(TILE % (8 * 256) == 0, "tile must split into whole 16-byte pieces per lane");
@@ -583,12 +583,15 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
   typedef __attribute__((address_space(3))) void* lds_p;
   typedef const __attribute__((address_space(1))) void* gbl_p;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
-  const int t = blockIdx.y, pass = blockIdx.z + pass_base;
+  // blockIdx.z = pass * ksplit + split: a split walks its share of the other view's tiles (the probabilities are normalised by lse, so the
+  // splits' partial products simply add: one more atomicAdd per output element and split, twice the waves in flight per SIMD)
+  const int t = blockIdx.y, pass = (int)blockIdx.z / ksplit + pass_base, split = (int)blockIdx.z % ksplit;
   const int o0 = (blockIdx.x * 4 + wave) * 32;
   const bool active = o0 < B;
   const dmm_infonce_term term = T.t[t];
   const int own_slot = pass == 0 ? term.a : term.b, oth_slot = pass == 0 ? term.b : term.a;
   const int tiles = pk.Bp >> 5;
+  const int kt_beg = (int)((long long)tiles * split / ksplit), kt_end = (int)((long long)tiles * (split + 1) / ksplit);
   const size_t oth_base = (size_t)oth_slot * tiles * BLK;
 
   // piece i of a tile: 16 bytes per lane, pieces of one wave-instruction contiguous (what LDS-DMA writes: base + 16 * lane)
@@ -631,12 +634,13 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
 #pragma unroll
-  for (int j = 0; j < NS - 1; ++j) issue(j, j);
-  for (int kt = 0; kt < tiles; ++kt) {
+  for (int j = 0; j < NS - 1; ++j) issue(kt_beg + j, j);
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int rel = kt - kt_beg;
     inb_wait_vmcnt<(NS - 2) * PER>();  // this wave's pieces of tile kt have landed (the NS - 2 younger tiles stay in flight)
     asm volatile("s_barrier" ::: "memory");  // ... every wave's pieces; and every wave is done reading tile kt - 1
-    issue(kt + NS - 1, (kt + NS - 1) % NS);  // into the stage tile kt - 1 occupied
-    const __bf16* S = sm_oth + (size_t)(kt % NS) * TILE;
+    issue(kt + NS - 1, (rel + NS - 1) % NS);  // into the stage tile kt - 1 occupied
+    const __bf16* S = sm_oth + (size_t)(rel % NS) * TILE;
     if (active) {
       // bounds / diagonal handling only where it can matter: the tile that holds the wave's own rows and the (padded) last tile
       if (kt == otile || kt == tiles - 1) inb_tile<D, PREC, true>(S, own_h, own_l, out, kt * 32, oidx, B, c1, pass == 0, l2_own, ls_lds, fr, fh);
@@ -658,6 +662,9 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
 constexpr int INB_MAX_B = 8192;  // the term's lse vector (4 B per batch row) sits in LDS behind the ring: 32 KiB at most
 template <int D, int PREC>
 static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat, int pass_base = 0) {
+  // walk splits per (term, pass): 1 / 2 / 4 / 8 measured 123.5 / 117.6 / 113.8 / ~125 us at B = 4096, 8 terms (more waves per SIMD against more atomics)
+  static const int ksplit = [] { const char* e = getenv("DMM_INFONCE_LDS_KSPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  grid.z *= ksplit;
   static const bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               InbShape<D, PREC>::LDS_BYTES + INB_MAX_B * 4);
@@ -665,7 +672,7 @@ static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, 
   }();
   (void)once;
   const size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES + (size_t)((B + 3) & ~3) * 4;
-  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, lse, T, B, dzhat, pass_base);
+  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, lse, T, B, dzhat, pass_base, ksplit);
 }
 
 // ---- forward + the anchor-side backward in one walk (unit-norm rows) -------------------------------------------------------------------
