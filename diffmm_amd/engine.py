@@ -1266,6 +1266,27 @@ class DiffusionEngine:
         self._xT_calls += 1
         return self._xT[:B, :I]
 
+    def _topk_all(self, views, row_ids: Tensor, deg_ptr: Tensor, out):
+        """Per-user top-k of every modality's view: independent row-streaming kernels, one HIP stream each (forked from / joined to the
+        caller's stream) so that their tails overlap."""
+        M = self.M
+        if M == 1 or self.dev.type != "cuda":
+            for m in range(M):
+                ops.topk_rows(views[m], row_ids, deg_ptr, out[m], self.I)
+            return
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
+            self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
+        main = torch.cuda.current_stream()
+        self._side_events[M].record(main)
+        for m in range(M):
+            st = self._side_streams[m]
+            st.wait_event(self._side_events[M])
+            with torch.cuda.stream(st):
+                ops.topk_rows(views[m], row_ids, deg_ptr, out[m], self.I)
+                self._side_events[m].record(st)
+            main.wait_event(self._side_events[m])
+
     def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1,
                       sampling_step: int = 0, csr: Optional[tuple] = None) -> List[Tensor]:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
@@ -1287,8 +1308,7 @@ class DiffusionEngine:
             if csr is not None and precision == 1 and sampling_step == 0:  # x_0 stays CSR: no dense [rows, I] operand is built
                 rows = CsrRows(csr[0], csr[1], ub + int(csr[2]))
                 views = self.generate_views_latent(rows=rows) if latent else self.generate_views_bf16_csr(rows)
-                for m in range(self.M):
-                    ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
+                self._topk_all(views, ub.to(torch.int32), deg_ptr, out)
                 continue
             x0 = dense_rows(ub)
             if latent:  # dense start: x_0 itself, or each modality's own noised x_T (drawn one at a time into a shared buffer)
