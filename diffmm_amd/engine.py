@@ -30,6 +30,31 @@ def _align4(n: int) -> int:
     return (n + 3) & ~3
 
 
+class _Lazy:
+    """A buffer (or list of buffers) allocated on first access."""
+
+    def __init__(self, factory):
+        self.factory, self.value = factory, None
+
+    def get(self):
+        if self.value is None:
+            self.value = self.factory()
+        return self.value
+
+
+class _LazyDict(dict):
+    """dict whose `lazy` entries are created on first lookup."""
+
+    def __init__(self, eager, lazy):
+        super().__init__(eager)
+        self._lazy = lazy
+
+    def __missing__(self, k):
+        v = self._lazy[k]()
+        self[k] = v
+        return v
+
+
 class CsrRows:
     """Rows of the 0/1 interaction matrix named by user id, kept as CSR (ptr int64 over ALL users, col int32): what the engines take
     instead of a dense [B, I] x_0 (the reference's dense U x I matrix, DataHandler.py:128, cannot exist at I = 1e6)."""
@@ -447,17 +472,21 @@ class DiffusionEngine:
             a_["mid"] = [z(R_mid, dout) for _, _, dout in self.mids]
         self.dmid_pre = [z(B_max, dout) for _, _, dout in self.mids]
         self.dmid_in = [z(B_max, din) for _, din, _ in self.mids]
-        self.x0p = z(B_max, Kp)  # x0 with the padded leading dimension
+        zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
+        # [rows, Kp]-sized buffers only some modes use are allocated on first access (properties below): the dense x_0 operand (not built
+        # when the step runs on bit masks), the fp32 loss gradient and d[x'|temb] (fused expand / folded products write neither), the second
+        # ping-pong set of the STEPWISE chain (the latent chain has no item-sized state).  At 1M x 100k they are 50 of 149 GiB.
+        self._lazy = dict(x0p=_Lazy(lambda: z(B_max, Kp)), dout=_Lazy(lambda: z(B_max, Kp)), dxcat=_Lazy(lambda: z(B_max, Kp)),
+                          cxb=_Lazy(lambda: [z(self.chain_rows, Kp) for _ in range(M)]), w1T16=_Lazy(lambda: zb(Kp, H)))
         self.ui = z(B_max, D)
-        self.dout, self.dxcat = z(B_max, Kp), z(B_max, Kp)
         self.dum, self.dpg, self.dgate, self.dproj = z(B_max, D), z(B_max, D), z(B_max, D), z(B_max, D)
         self.dh, self.dpre = z(self.chain_rows, H), z(B_max, H)
         R = self.chain_rows
         zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
         # ping-pong buffers of the reverse chain, one set per modality (the modalities' chains advance together, batched launches)
-        self.cxa, self.cxb = [z(R, Kp) for _ in range(M)], [z(R, Kp) for _ in range(M)]
+        self.cxa = [z(R, Kp) for _ in range(M)]
         self.cxa16, self.cxb16, self.ch16 = [zb(R, Kp) for _ in range(M)], [zb(R, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
-        self.xa, self.xb, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxb[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
+        self.xa, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
         self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
         if any(w % 8 for w in hidden):
             raise ValueError("DiffusionEngine: hidden widths must be multiples of 8 (bf16 operand rows are 16-byte pieces)")
@@ -476,13 +505,20 @@ class DiffusionEngine:
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
         # bf16 / transposed operands of the training step's large GEMMs (precision == 1): every product runs in NT form
         self.dpre16, self.doutT16, self.hT16, self.dpreT16 = zb(B_max, H), zb(items, Bp8), zb(H, Bp8), zb(H, Bp8)
-        self.xcatT16, self.w1T16, self.w2T16 = zb(Kp, Bp8), zb(Kp, H), zb(H, Kp)
+        self.xcatT16, self.w2T16 = zb(Kp, Bp8), zb(H, Kp)
         self._ws = None  # per-modality workspaces of the batched training step (allocated on first use)
         self.rng_step = 0
         # user-sharded training (diffmm_amd/sharded.py): every replica holds the rows of a minibatch whose users it owns; the Denoise
         # weights are replicated and their gradients SUMMED over the replicas (the loss scale already carries 1 / global batch)
         self.shard_world, self.shard_rank, self.shard_group = 1, 0, None
         self.t_gen: Optional[torch.Generator] = None  # timestep draws (per-replica generator when sharded; torch's global one otherwise)
+
+    x0p = property(lambda self: self._lazy["x0p"].get())      # x_0 with the padded leading dimension
+    dout = property(lambda self: self._lazy["dout"].get())
+    dxcat = property(lambda self: self._lazy["dxcat"].get())
+    cxb = property(lambda self: self._lazy["cxb"].get())
+    xb = property(lambda self: self._lazy["cxb"].get()[0])
+    w1T16 = property(lambda self: self._lazy["w1T16"].get())
 
     def load_reference_state(self, m: int, sd: Dict[str, Tensor]):
         t = {k: torch.as_tensor(v).float() for k, v in sd.items()}
@@ -686,13 +722,15 @@ class DiffusionEngine:
             self._ws = []
             for m in range(self.M):
                 if m == 0:  # modality 0 keeps the buffers the single-modality path uses
-                    w = dict(xa16=self.cxa16[0], h16=self.ch16[0], xb16=self.cxb16[0], dout=self.dout, dum=self.dum, doutT16=self.doutT16, hT16=self.hT16,
-                             w2T16=self.w2T16, dh=self.dh, dpre=self.dpre, dpreT16=self.dpreT16, xcatT16=self.xcatT16, dpre16=self.dpre16,
-                             w1T16=self.w1T16, dxcat=self.dxcat, dpg=self.dpg, dgate=self.dgate, dproj=self.dproj)
-                else:
-                    w = dict(xa16=self.cxa16[m], h16=self.ch16[m], xb16=self.cxb16[m], dout=z(Bm, Kp), dum=z(Bm, D), doutT16=zb(I, Bp), hT16=zb(H, Bp),
-                             w2T16=zb(H, Kp), dh=z(Bm, H), dpre=z(Bm, H), dpreT16=zb(H, Bp), xcatT16=zb(Kp, Bp), dpre16=zb(Bm, H), w1T16=zb(Kp, H),
-                             dxcat=z(Bm, Kp), dpg=z(Bm, D), dgate=z(Bm, D), dproj=z(Bm, D))
+                    w = _LazyDict(dict(xa16=self.cxa16[0], h16=self.ch16[0], xb16=self.cxb16[0], dum=self.dum, doutT16=self.doutT16, hT16=self.hT16,
+                                       w2T16=self.w2T16, dh=self.dh, dpre=self.dpre, dpreT16=self.dpreT16, xcatT16=self.xcatT16, dpre16=self.dpre16,
+                                       dpg=self.dpg, dgate=self.dgate, dproj=self.dproj),
+                                  dict(dout=lambda: self.dout, dxcat=lambda: self.dxcat, w1T16=lambda: self.w1T16))
+                else:  # (dout, dxcat, w1T16: only the unfused / unfolded step touches them)
+                    w = _LazyDict(dict(xa16=self.cxa16[m], h16=self.ch16[m], xb16=self.cxb16[m], dum=z(Bm, D), doutT16=zb(I, Bp), hT16=zb(H, Bp),
+                                       w2T16=zb(H, Kp), dh=z(Bm, H), dpre=z(Bm, H), dpreT16=zb(H, Bp), xcatT16=zb(Kp, Bp), dpre16=zb(Bm, H),
+                                       dpg=z(Bm, D), dgate=z(Bm, D), dproj=z(Bm, D)),
+                                  dict(dout=lambda: z(Bm, Kp), dxcat=lambda: z(Bm, Kp), w1T16=lambda: zb(Kp, H)))
                 self._ws.append(w)
         return self._ws
 
@@ -878,7 +916,7 @@ class DiffusionEngine:
                     self._bits_buf = torch.zeros(self.B_max, (self.I + 31) // 32, dtype=torch.int32, device=self.dev)
                 self._x0_bits = self._bits_buf
                 ops.csr_row_bits(x0.ptr, x0.col, x0.users, self.I, self._x0_bits[:B])
-                x0p = self.x0p[:B]  # (not filled: nothing on this path reads it)
+                x0p = self.act[0]["xcat"][:B]  # (a [B, Kp] placeholder: nothing on this path reads x_0 rows; the dense operand stays unallocated)
             else:
                 x0p = self._set_x0(x0)
             ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32, generator=self.t_gen)).to(torch.int32)
