@@ -284,64 +284,71 @@ struct ExpandFusedP {
 template <int D, int MODE>
 __global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFusedP A) {
   constexpr int KS = D / 32;
+  (void)sizeof(char[MODE >= 0 && MODE <= 2 ? 1 : -1]);
   constexpr int TLD = 72;  // bf16 elements per column of the transposed tile (64 rows + 8: 16-byte aligned, conflict-poor)
   __shared__ __attribute__((aligned(16))) __bf16 tt[256 * TLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, kg = lane >> 4;
   const int row0 = blockIdx.y * 64, colw = blockIdx.x * 256, col0 = colw + wave * 64;
   const int B = A.B, I = A.I, Kc = A.Kc;
-  // residual first: 16 float4 per lane in flight while the operands are fetched and multiplied
+  // Every load is issued up front, UNCONDITIONALLY, on clamped addresses (out-of-range lanes re-read the last row / last 4-column group and
+  // are masked when the value is used): a load inside a bounds branch, next to the stores and atomics below, made the compiler wait
+  // vmcnt(0) -- i.e. for those stores too -- at every use (27 such waits; loss-gradient mode 127 -> 75 us).  MODE 0: forward; MODE 1: loss
+  // gradient with dense x_0 rows; MODE 2: loss gradient with x_0 as bit masks.
+  constexpr bool LOSS = MODE != 0;
   float4 rr[4][4];
   float gc[4];
-  if (MODE == 1) {
+  long long rofs[4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int row = row0 + rt * 16 + fr;
-      gc[rt] = row < B ? (float)(A.gscale * A.w[row] * 2.0 / (double)I) : 0.f;
+  for (int rt = 0; rt < 4; ++rt) {
+    const int row = row0 + rt * 16 + fr, rc = min(row, B - 1);
+    rofs[rt] = (long long)rc;
+    gc[rt] = 0.f;
+    if (LOSS) {
+      const float g = (float)(A.gscale * A.w[rc] * 2.0 / (double)I);
+      gc[rt] = row < B ? g : 0.f;
     }
   }
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
-      rr[ct][rt] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int lim = MODE == 0 ? Kc : I;
-      if (row < B && col < lim) {
-        const float* p = A.R + (long long)row * A.ldr + col;
-        if (col + 3 < lim) rr[ct][rt] = *reinterpret_cast<const float4*>(p);
-        else {
-          rr[ct][rt].x = p[0];
-          if (col + 1 < lim) rr[ct][rt].y = p[1];
-          if (col + 2 < lim) rr[ct][rt].z = p[2];
-        }
-      }
+      const int cc = min(col0 + ct * 16 + kg * 4, Kc - 4);  // Kc % 4 == 0, rows readable up to Kc (host check)
+      rr[ct][rt] = *reinterpret_cast<const float4*>(A.R + rofs[rt] * A.ldr + cc);
     }
-  if (MODE == 1) {
+  if (MODE == 2) {  // 16 words per lane: the lane's 4 columns (col % 4 == 0) sit in one word; bits past I are zero
+    uint32_t wd[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int cc = min(col0 + ct * 16 + kg * 4, ((I + 31) & ~31) - 4);
+        wd[ct][rt] = A.X0b[rofs[rt] * A.ldb + (cc >> 5)] >> (cc & 31);
+      }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        float4& r = rr[ct][rt];
+        const uint32_t w_ = wd[ct][rt];
+        // (__fmul_rn: the product is rounded on its own, as when dmm_diff_loss stored it -- no contraction with the add of P F^T below)
+        r = make_float4(__fmul_rn(gc[rt], r.x - (float)(w_ & 1u)), __fmul_rn(gc[rt], r.y - (float)((w_ >> 1) & 1u)),
+                        __fmul_rn(gc[rt], r.z - (float)((w_ >> 2) & 1u)), __fmul_rn(gc[rt], r.w - (float)((w_ >> 3) & 1u)));
+      }
+  } else if (MODE == 1) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       float4 xx[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
-        xx[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < B && col < I && !A.X0) {  // bit mask: the lane's 4 columns (col % 4 == 0) sit in one word; bits past I are zero
-          const uint32_t wd = A.X0b[(long long)row * A.ldb + (col >> 5)] >> (col & 31);
-          xx[rt] = make_float4((float)(wd & 1u), (float)((wd >> 1) & 1u), (float)((wd >> 2) & 1u), (float)((wd >> 3) & 1u));
-        } else if (row < B && col < I) {
-          const float* p = A.X0 + (long long)row * A.ldx0 + col;
-          if (col + 3 < I) xx[rt] = *reinterpret_cast<const float4*>(p);
-          else {
-            xx[rt].x = p[0];
-            if (col + 1 < I) xx[rt].y = p[1];
-            if (col + 2 < I) xx[rt].z = p[2];
-          }
-        }
+        const int cc = min(col0 + ct * 16 + kg * 4, Kc - 4);  // (x_0 rows share the operand layout: readable up to Kc)
+        xx[rt] = *reinterpret_cast<const float4*>(A.X0 + rofs[rt] * A.ldx0 + cc);
       }
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         float4& r = rr[ct][rt];
-        r = make_float4(gc[rt] * (r.x - xx[rt].x), gc[rt] * (r.y - xx[rt].y), gc[rt] * (r.z - xx[rt].z), gc[rt] * (r.w - xx[rt].w));
+        r = make_float4(__fmul_rn(gc[rt], r.x - xx[rt].x), __fmul_rn(gc[rt], r.y - xx[rt].y), __fmul_rn(gc[rt], r.z - xx[rt].z),
+                        __fmul_rn(gc[rt], r.w - xx[rt].w));
       }
     }
   }
@@ -370,8 +377,12 @@ __global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFuse
       float v[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (col + j < I) v[j] += acc[j];
-        if (row >= B) v[j] = 0.f;
+        if (LOSS) {  // loss gradient: defined on the item columns only
+          v[j] = col + j < I ? v[j] + acc[j] : 0.f;
+        } else {     // forward: [x_t | temb | 0] beyond the item columns is the residual itself; nothing beyond Kc is stored
+          if (col + j < I) v[j] += acc[j];
+        }
+        if (row >= B || col >= Kc) v[j] = 0.f;
         cs[j] += v[j];
       }
       const bf16x4v b4 = bf16x4v{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFuse
 #pragma unroll
       for (int j = 0; j < 4; ++j) tt[(cl + j) * TLD + rl] = b4[j];
     }
-    if (MODE == 1) {  // column sums over the tile's 64 rows: reduce over fr (the 16 lanes of a kg group), then one atomic per column
+    if (LOSS) {  // column sums over the tile's 64 rows: reduce over fr (the 16 lanes of a kg group), then one atomic per column
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float c = cs[j];
@@ -496,7 +507,7 @@ extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, i
   DMM_CHECK_ARG(mode == 0 || ((a->X0 || (a->X0bits && a->ldbits * 32 >= a->I)) && a->w && a->csum), "dmm_item_expand_fused: mode 1 needs x0 (rows or bit masks), w and csum");
   const int Bp = (a->B + 63) & ~63;
   DMM_CHECK_ARG(a->ldp % 4 == 0 && a->ldf % 4 == 0 && a->ldr % 4 == 0 && (mode == 0 || !a->X0 || a->ldx0 % 4 == 0) && a->ldy % 4 == 0 && a->ldy >= a->Kc && a->ldt % 8 == 0 &&
-                    a->ldt >= Bp && (mode == 1 || a->ldr >= a->Kc) &&
+                    a->ldt >= Bp && a->ldr >= a->Kc && (mode == 0 || !a->X0 || a->ldx0 >= a->Kc) && (mode == 0 || a->X0 || a->ldbits * 32 >= ((a->I + 31) & ~31)) &&
                     (((uintptr_t)a->P | (uintptr_t)a->F | (uintptr_t)a->R | (uintptr_t)a->X0 | (uintptr_t)a->YT) & 15) == 0 && ((uintptr_t)a->Y16 & 7) == 0,
                 "dmm_item_expand_fused: operands must be 16-byte aligned (Y16: 8) with leading dimensions that are multiples of 4 (YT: of 8, >= round_up(B, 64))");
   ExpandFusedP p;
@@ -504,12 +515,15 @@ extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, i
   p.Y16 = (__bf16*)a->Y16; p.ldy = a->ldy; p.YT = (__bf16*)a->YT; p.ldt = a->ldt; p.csum = a->csum; p.B = a->B; p.I = a->I; p.Kc = a->Kc; p.Kt = a->Kt;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((a->Kc + 255) / 256, Bp / 64);
+  const int km = mode == 0 ? 0 : (a->X0 ? 1 : 2);
   if (D == 64) {
-    if (mode == 0) hipLaunchKernelGGL((item_expand_fused_kernel<64, 0>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((item_expand_fused_kernel<64, 1>), grid, dim3(256), 0, s, p);
+    if (km == 0) hipLaunchKernelGGL((item_expand_fused_kernel<64, 0>), grid, dim3(256), 0, s, p);
+    else if (km == 1) hipLaunchKernelGGL((item_expand_fused_kernel<64, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((item_expand_fused_kernel<64, 2>), grid, dim3(256), 0, s, p);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((item_expand_fused_kernel<128, 0>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((item_expand_fused_kernel<128, 1>), grid, dim3(256), 0, s, p);
+    if (km == 0) hipLaunchKernelGGL((item_expand_fused_kernel<128, 0>), grid, dim3(256), 0, s, p);
+    else if (km == 1) hipLaunchKernelGGL((item_expand_fused_kernel<128, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((item_expand_fused_kernel<128, 2>), grid, dim3(256), 0, s, p);
   }
   DMM_LAUNCH_CHECK("dmm_item_expand_fused");
   return 0;

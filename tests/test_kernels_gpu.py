@@ -759,8 +759,13 @@ def test_item_expand_fused_equals_the_separate_passes(dev, D, B, I):
     got16 = torch.full((B, Kp), 5.0, device=dev, dtype=torch.bfloat16); gotT = torch.full((I, Bp), 5.0, device=dev, dtype=torch.bfloat16)
     gotc = torch.zeros(I, device=dev)
     ops.item_expand_fused(dum2, F, out, got16, gotT, I, Kp, I, x0=x0, w=w, gscale=gscale, csum=gotc)
-    assert torch.equal(got16, want16), "loss gradient: row-major bf16 (columns >= I zero)"
-    assert torch.equal(gotT, wantT), "loss gradient: transposed bf16"
+    # (the same fp32 operations up to one fp32 ulp of the sum, which moves a value across a bf16 rounding boundary with probability ~2^-16: a
+    # handful of elements in 3e5 differ by one bf16 ulp)
+    scale = float(want16.float().abs().max())
+    for got, want, what in ((got16, want16, "row-major"), (gotT, wantT, "transposed")):
+        diff = (got.float() - want.float()).abs()
+        assert float((diff > 0).float().mean()) < 1e-4 and float(diff.max()) <= 2.0 ** -8 * scale, f"loss gradient, {what} bf16 operand"
+    assert float(got16[:, I:].float().abs().max()) == 0.0, "columns >= I zero"
     close(gotc, wantc, rtol=1e-4, atol=1e-6 * float(wantc.abs().max()) + 1e-9, what="column sums")
 
 
@@ -807,7 +812,10 @@ def test_x0_bit_masks_equal_the_dense_rows(dev):
         y16, yT, cs = torch.zeros(B, Kp, device=dev, dtype=torch.bfloat16), torch.zeros(I, Bp, device=dev, dtype=torch.bfloat16), torch.zeros(I, device=dev)
         ops.item_expand_fused(dum, F, out, y16, yT, I, Kp, I, w=w, gscale=1e-3, csum=cs, **kw)
         res.append((y16, yT, cs))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "fused loss gradient from bit masks"
+    sc = float(res[0][0].float().abs().max())
+    for k in (0, 1):
+        d_ = (res[0][k].float() - res[1][k].float()).abs()
+        assert float((d_ > 0).float().mean()) < 1e-4 and float(d_.max()) <= 2.0 ** -8 * sc, "fused loss gradient from bit masks"
     close(res[1][2], res[0][2], rtol=1e-4, atol=1e-6 * float(res[0][2].abs().max()) + 1e-12, what="column sums")
 
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""dmm_item_expand_fused alone at the diffusion step's shape (B = 4096, I = 6710, d = 64): forward mode and loss-gradient mode, HIP-event time."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffmm_amd import ops
+dev = torch.device("cuda:0")
+B, I, D, Kp = 4096, 6710, 64, 6720
+P, F = torch.randn(B, D, device=dev), torch.randn(I, D, device=dev)
+R = torch.randn(B, Kp, device=dev)
+y16, yT = torch.zeros(B, Kp, device=dev, dtype=torch.bfloat16), torch.zeros(Kp, B, device=dev, dtype=torch.bfloat16)
+w = torch.rand(B, device=dev, dtype=torch.float64) + 0.5
+bits = torch.randint(0, 2 ** 31 - 1, (B, (I + 31) // 32), device=dev, dtype=torch.int32)
+x0 = (torch.rand(B, Kp, device=dev) < 0.01).float()
+cs = torch.zeros(I, device=dev)
+def t(fn, n=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+print("forward      %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT, I, Kp, Kp)))
+print("loss, bits   %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0bits=bits)))
+print("loss, dense  %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0=x0)))
