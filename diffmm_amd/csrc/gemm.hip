@@ -208,26 +208,75 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatchP Bt) {
   }
 
   // ---- epilogue: lane holds column n = fr of each 32x32 tile, rows (reg&3) + 8*(reg>>2) + 4*fh ----
+  // Every operand is copied out of the kernel-argument struct once (read through the reference, each use was a scalar load + wait), the bias
+  // and -- per tile -- the residual / accumulate-into values are loaded before the tile's stores on clamped addresses, and the store kind is
+  // chosen outside the element loop: a load inside the per-element bounds branch made the compiler wait vmcnt(0) -- i.e. for the previous
+  // element's store -- 192 times per lane (the epilogue was a chain of 192 store round trips).
   const bool first_slice = blockIdx.z == 0;
+  float* const C = P.C;
+  const float* const Rp = P.R;
+  const float* const bias = P.bias;
+  const long long ldc = P.ldc, ldr = P.ldr;
+  const int M = P.M, N = P.N, act = P.act;
+  const bool atomic = P.split_k > 1, accum = P.accumulate != 0;
+  const float alpha = P.alpha, e1 = P.e1, e2 = P.e2;
+  float bn[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + fr;
+    bn[j] = (bias && first_slice) ? bias[n < N ? n : N - 1] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn * 64 + j * 32 + fr;
-      if (n >= P.N) continue;
-      const float bn = (P.bias && first_slice) ? P.bias[n] : 0.f;
+      if (n >= N) continue;
+      const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+      float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m >= P.M) continue;
-        float v = P.alpha * acc[i][j][r] + bn;
-        if (P.act == DMM_ACT_TANH) v = tanhf(v);
-        else if (P.act == DMM_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-        if (P.R) v = P.e1 * v + P.e2 * P.R[(long long)m * P.ldr + n];
-        float* c = P.C + (long long)m * P.ldc + n;
-        if (P.split_k > 1) atomicAdd(c, v);
-        else if (P.accumulate) *c += v;
-        else *c = v;
+      for (int r = 0; r < 16; ++r) v[r] = alpha * acc[i][j][r] + bn[j];
+      if (act == DMM_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+      } else if (act == DMM_ACT_SIGMOID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+      }
+      if (Rp) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          rv[r] = Rp[(long long)(m < M ? m : M - 1) * ldr + n];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = e1 * v[r] + e2 * rv[r];
+      }
+      if (atomic) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < M) atomicAdd(C + (long long)m * ldc + n, v[r]);
+        }
+      } else if (accum) {
+        float cv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          cv[r] = C[(long long)(m < M ? m : M - 1) * ldc + n];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < M) C[(long long)m * ldc + n] = cv[r] + v[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < M) C[(long long)m * ldc + n] = v[r];
+        }
       }
     }
 }
