@@ -102,6 +102,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBf16P& Pk, f32x16 (&acc)
                       (!P.R || (P.ldr % 4 == 0 && ((uintptr_t)P.R & 15) == 0)) && (!P.Cb || (P.ldcb % 4 == 0 && ((uintptr_t)P.Cb & 7) == 0)) &&
                       (!P.Rb || (P.ldrb % 4 == 0 && ((uintptr_t)P.Rb & 7) == 0));
   const bool has_r = P.R || P.Rb;
+  // the lane's four columns are the same in every chunk (64 % C4 == 0): their bias values are loaded ONCE, before any store (a bias load
+  // per element, inside the bounds branch, made every store wait for the one before it)
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int nl = n0 + wn * WN + (lane % C4) * 4;
+    if (P.bias) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b4[u] = P.bias[nl + u < P.N ? nl + u : P.N - 1];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     // residual rows are requested first so their latency overlaps the LDS transpose below
@@ -140,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBf16P& Pk, f32x16 (&acc)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (u < nv) {
-          float x = P.alpha * v[u] + (P.bias ? P.bias[n + u] : 0.f);
+          float x = P.alpha * v[u] + b4[u];
           if (P.act == DMM_ACT_TANH) x = P.C ? tanhf(x) : tanh_fast_bf16(x);  // bf16-only output: two transcendentals instead of ~40 instructions
           else if (P.act == DMM_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
           v[u] = x;
