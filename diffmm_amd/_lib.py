@@ -57,6 +57,10 @@ class ExpandFusedArgs(C.Structure):
                 ("csum", C.c_void_p), ("B", C.c_int32), ("I", C.c_int32), ("Kc", C.c_int32), ("Kt", C.c_int32), ("X0bits", C.c_void_p), ("ldbits", C.c_int64)]
 
 
+class RownormBwdProblem(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("y", C.c_void_p), ("norm", C.c_void_p), ("dx", C.c_void_p), ("csum", C.c_void_p), ("rows", C.c_int32)]
+
+
 class GatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("grad", C.c_void_p)]
 
@@ -89,6 +93,7 @@ _SIGS = {
     "dmm_temb_bias_table": (C.c_int, [_P, _P, _I, _P, _L, _I, _P, _I, _I, _P, _P]),
     "dmm_rownorm_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "dmm_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    "dmm_rownorm_bwd_batched": (C.c_int, [C.POINTER(RownormBwdProblem), _I, _I, _P]),
     "dmm_gcn_mix_fwd": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _L, _P]),
     "dmm_gcn_mix_partials": (C.c_int64, [_L]),
     "dmm_gcn_mix_bwd": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _I, _F, _P, _L, _P]),

@@ -2,6 +2,8 @@
 // All are HBM/L2-bandwidth kernels: 16-byte accesses per lane, grid-stride, <= 2048 workgroups.
 #include <stdarg.h>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace dmm {
@@ -60,6 +62,52 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restric
       o = make_float4((g.x - v.x * dot) * inv, (g.y - v.y * dot) * inv, (g.z - v.z * dot) * inv, (g.w - v.w * dot) * inv);
     }
     *reinterpret_cast<float4*>(dx + (size_t)r * D + 4 * l) = o;
+  }
+}
+
+// Backward of F.normalize for up to 4 tensors in one launch (blockIdx.y), with the column sums of the result added to csum[] (the bias
+// gradient of the Linear layer in front of the normalisation, Model.py:84-89): in the joint step this replaces 3 rownorm_bwd + 3 colsum launches
+// over the modalities' [I, d] gradients.  Column sums: per-thread partials over the rows it handles, combined through LDS, one atomic
+// per column and workgroup (csum pre-zeroed by the caller).
+struct RownormBwdP { const float* dy; const float* y; const float* norm; float* dx; float* csum; int rows; };
+struct RownormBwdBatch { RownormBwdP p[4]; };
+
+template <int D>
+__global__ __launch_bounds__(256) void rownorm_bwd_batched_kernel(const RownormBwdBatch batch) {
+  constexpr int LANES = D / 4, G = 256 / LANES;
+  __shared__ float4 part[256];
+  const RownormBwdP& P = batch.p[blockIdx.y];
+  const float* __restrict__ dy = P.dy; const float* __restrict__ y = P.y; const float* __restrict__ norm = P.norm;
+  float* __restrict__ dx = P.dx;
+  const int rows = P.rows;
+  const int l = threadIdx.x % LANES;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = blockIdx.x * G + threadIdx.x / LANES; r < rows; r += gridDim.x * G) {
+    const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * D + 4 * l);
+    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * D + 4 * l);
+    const float nrm = norm[r];
+    float4 o;
+    if (nrm < 1e-12f) {  // clamped branch of F.normalize: y = x / eps
+      o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+    } else {
+      const float dot = group_sum<LANES>(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
+      const float inv = 1.0f / nrm;
+      o = make_float4((g.x - v.x * dot) * inv, (g.y - v.y * dot) * inv, (g.z - v.z * dot) * inv, (g.w - v.w * dot) * inv);
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)r * D + 4 * l) = o;
+    cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+  }
+  if (!P.csum) return;  // (uniform over the workgroup)
+  part[threadIdx.x] = cs;
+  __syncthreads();
+  if (threadIdx.x < LANES) {
+    float4 a = part[threadIdx.x];
+    for (int g2 = 1; g2 < G; ++g2) {
+      const float4 o = part[g2 * LANES + threadIdx.x];
+      a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    float* c = P.csum + 4 * threadIdx.x;
+    atomicAdd(c + 0, a.x); atomicAdd(c + 1, a.y); atomicAdd(c + 2, a.z); atomicAdd(c + 3, a.w);
   }
 }
 
@@ -277,6 +325,35 @@ static int rownorm_dispatch(bool fwd, const float* a, const float* b, const floa
 }  // namespace dmm
 
 using namespace dmm;
+
+extern "C" int dmm_rownorm_bwd_batched(const dmm_rownorm_bwd_problem* p, int n, int D, void* stream) {
+  DMM_CHECK_ARG(p && n >= 1 && n <= 4, "dmm_rownorm_bwd_batched: 1..4 problems per launch");
+  RownormBwdBatch b;
+  memset(&b, 0, sizeof(b));
+  int max_rows = 0;
+  for (int i = 0; i < n; ++i) {
+    DMM_CHECK_ARG(p[i].dy && p[i].y && p[i].norm && p[i].dx && p[i].rows >= 0, "dmm_rownorm_bwd_batched: null operand (problem %d)", i);
+    b.p[i] = RownormBwdP{p[i].dy, p[i].y, p[i].norm, p[i].dx, p[i].csum, p[i].rows};
+    max_rows = max_rows > p[i].rows ? max_rows : p[i].rows;
+  }
+  if (max_rows == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+#define RNB_CASE(DD)                                                                                                          \
+  case DD: {                                                                                                                  \
+    const unsigned gx = grid_for(max_rows, 1024 / DD);                                                                        \
+    hipLaunchKernelGGL(rownorm_bwd_batched_kernel<DD>, dim3(gx > 64 ? 64 : gx, n), dim3(256), 0, s, b); /* <= 64 atomics per column */ \
+    break;                                                                                                                    \
+  }
+  switch (D) {
+    RNB_CASE(8) RNB_CASE(16) RNB_CASE(32) RNB_CASE(64) RNB_CASE(128) RNB_CASE(256)
+    default:
+      set_error("dmm_rownorm_bwd_batched: D=%d unsupported (8,16,32,64,128,256)", D);
+      return DMM_ERR_INVALID_ARG;
+  }
+#undef RNB_CASE
+  DMM_LAUNCH_CHECK("dmm_rownorm_bwd_batched");
+  return 0;
+}
 
 extern "C" int dmm_rownorm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream) {
   DMM_CHECK_ARG(x && y && rows >= 0, "dmm_rownorm_fwd: null operand");

@@ -317,8 +317,9 @@ class JointEngine:
         # the projection weight gradients are accumulated by K slices (atomics): one memset for all of them (d(modal_weight), behind
         # them in the flat buffer, was written by the mixing backward above and stays)
         ops.zero_(self.P.grad[ne:self.P.offsets["modal_weight"]])
-        for m, n in enumerate(names):
-            ops.rownorm_bwd(self.T[m][U:], self.nf[m], self.fnorm[m], self.dfeat[m])
+        # backward of the normalisation + the projection biases' gradients (column sums, into the region zeroed above): one launch for all modalities
+        ops.rownorm_bwd_batched([dict(dy=self.T[m][U:], y=self.nf[m], norm=self.fnorm[m], dx=self.dfeat[m], csum=self.P.g(f"{n}_layer.bias"))
+                                 for m, n in enumerate(names)])
         # dW_m = dfeat_m^T E_m: 64 x F outputs with K = I the parallel axis; one launch for all m
         if self._feat_kernels(precision):  # as E_m^T [F_m, I] x dfeat_m [I, d], stored transposed into the [d, F_m] gradient
             FT = self._features_T()
@@ -327,8 +328,6 @@ class JointEngine:
         else:  # generic GEMM, K split 128 (32 / 64 / 128 / 256 measured)
             ops.gemm_batched([dict(A=self.dfeat[m], B=self.feats[m], out=self.P.g(f"{n}_layer.weight"), trans_a=True, precision=precision, split_k=128)
                               for m, n in enumerate(names)])
-        for m, n in enumerate(names):
-            ops.colsum(self.dfeat[m], self.I, D, self.P.g(f"{n}_layer.bias"), add=True)  # (inside the region zeroed above)
         if update:
             self.apply_adam()
         self.rng_step += 1

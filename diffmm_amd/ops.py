@@ -318,6 +318,22 @@ def rownorm_fwd(x: Tensor, y: Optional[Tensor] = None, norm: Optional[Tensor] = 
     return y, norm
 
 
+def rownorm_bwd_batched(problems: Sequence[dict]) -> None:
+    """rownorm_bwd for up to 4 tensors of one width in one launch (dicts: dy, y, norm, dx and optionally csum [D], pre-zeroed, which receives
+    the column sums of dx)."""
+    D = problems[0]["dy"].shape[1]
+    arr = (L.RownormBwdProblem * len(problems))()
+    for a, p in zip(arr, problems):
+        dy, y, nrm, dx = p["dy"], p["y"], p["norm"], p["dx"]
+        for t in (dy, y, dx):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != D or t.shape[0] != dy.shape[0]:
+                raise ValueError("rownorm_bwd_batched: contiguous fp32 [rows, D] tensors")
+        a.dy, a.y, a.norm, a.dx, a.rows = L.ptr(dy), L.ptr(y), L.ptr(_f32c(nrm, "norm")), L.ptr(dx), dy.shape[0]
+        if p.get("csum") is not None:
+            a.csum = L.ptr(_f32c(p["csum"], "csum"))
+    L.call("dmm_rownorm_bwd_batched", arr, len(problems), D, L.stream())
+
+
 def rownorm_bwd(dy: Tensor, y: Tensor, norm: Tensor, dx: Optional[Tensor] = None) -> Tensor:
     dx = torch.empty_like(dy) if dx is None else dx
     L.call("dmm_rownorm_bwd", L.ptr(_f32c(dy, "dy")), L.ptr(_f32c(y, "y")), L.ptr(norm), L.ptr(_f32c(dx, "dx")), dy.shape[0], dy.shape[1],

@@ -409,8 +409,8 @@ class ShardedJointEngine:
         mw = self.P.offsets["modal_weight"]
         ops.zero_(self.P.grad[ne:mw])  # projection weights (accumulated by K slices) and biases; d(modal_weight) behind them was just written
         if i1 > i0:  # projection backward: this replica's slice of the items, the modalities' weight gradients in one launch
-            for m in range(M):
-                ops.rownorm_bwd(self.T[m][nu + i0:nu + i1], self.nf[m][i0:i1], self.fnorm[m][i0:i1], self.dfeat[m][i0:i1])
+            ops.rownorm_bwd_batched([dict(dy=self.T[m][nu + i0:nu + i1], y=self.nf[m][i0:i1], norm=self.fnorm[m][i0:i1], dx=self.dfeat[m][i0:i1],
+                                          csum=self.P.g(f"{nm}_layer.bias")) for m, nm in enumerate(names)])  # (+ the biases' gradients, region zeroed above)
             if self._feat_kernels(precision):
                 FT = self._features_T_slice()
                 ops.item_project_batched([dict(X=FT[m], F=self.dfeat[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), K=i1 - i0) for m, nm in enumerate(names)],
@@ -418,8 +418,6 @@ class ShardedJointEngine:
             else:
                 ops.gemm_batched([dict(A=self.dfeat[m][i0:i1], B=self.feats[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), trans_a=True, precision=precision,
                                        split_k=128) for m, nm in enumerate(names)])
-            for m, nm in enumerate(names):
-                ops.colsum(self.dfeat[m][i0:i1], i1 - i0, D, self.P.g(f"{nm}_layer.bias"), add=True)  # (inside the region zeroed above)
         self._exchange_end()
         ops.spmm_epilogue_rows(arr_b, 1, D)
         self._ar(self.P.grad[ne:])  # projections + modal_weight: partial sums over disjoint node sets

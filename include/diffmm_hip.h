@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 207
+#define DMM_VERSION 208
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -183,6 +183,14 @@ int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int te, const fl
  * fwd writes y = x / max(||x||, eps) and norm = ||x||.  bwd: dx = (dy - y (y.dy)) / ||x||  (dy / eps below eps). */
 int dmm_rownorm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream);
 int dmm_rownorm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream);
+/* dmm_rownorm_bwd for up to 4 tensors in one launch; csum (optional, [D], pre-zeroed) receives the column sums of dx -- the bias gradient of the
+ * Linear layer in front of the normalisation (Model.py:84-89): the joint step's three rownorm_bwd + three colsum launches in one */
+typedef struct dmm_rownorm_bwd_problem {
+  const float* dy; const float* y; const float* norm;
+  float* dx; float* csum;
+  int32_t rows;
+} dmm_rownorm_bwd_problem;
+int dmm_rownorm_bwd_batched(const dmm_rownorm_bwd_problem* p /*host array*/, int n, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Modal mixing of gcn_MM, Model.py:87,116-127:  mx = sum_m softmax(w)_m * (bx + maw * z_m).

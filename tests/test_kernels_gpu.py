@@ -1155,3 +1155,25 @@ torch.save(dict(lse=lse.cpu(), rl=rl.cpu(), dz=dz.cpu()), sys.argv[2])
         assert float((a["lse"] - b["lse"]).abs().max()) < 1e-4 and float((a["rl"] - b["rl"]).abs().max()) < 1e-6, f"precision {prec}: lse / row loss"
         scale = float(a["dz"].abs().max())
         assert float((a["dz"] - b["dz"]).abs().max()) < tol * scale, f"precision {prec}: gradients {float((a['dz'] - b['dz']).abs().max()) / scale:.2e} of the scale"
+
+
+@pytest.mark.parametrize("D", [8, 64, 128])
+def test_rownorm_bwd_batched_equals_the_separate_launches(dev, D):
+    """dmm_rownorm_bwd_batched (three tensors of different row counts in one launch, column sums added to pre-set vectors) against
+    dmm_rownorm_bwd + dmm_colsum."""
+    from diffmm_amd import ops
+    torch.manual_seed(D)
+    probs, want = [], []
+    for rows in (700, 33, 1):
+        x = torch.randn(rows, D, device=dev)
+        x[0] = 0.0  # the clamped branch of F.normalize
+        y, nrm = ops.rownorm_fwd(x)
+        dy = torch.randn(rows, D, device=dev)
+        dx_ref = ops.rownorm_bwd(dy, y, nrm)
+        cs_ref = torch.zeros(D, device=dev); ops.colsum(dx_ref, rows, D, cs_ref)
+        dx, cs = torch.full((rows, D), 7.0, device=dev), torch.full((D,), 0.5, device=dev)
+        probs.append(dict(dy=dy, y=y, norm=nrm, dx=dx, csum=cs)); want.append((dx_ref, cs_ref))
+    ops.rownorm_bwd_batched(probs)
+    for p_, (dx_ref, cs_ref) in zip(probs, want):
+        assert torch.equal(p_["dx"], dx_ref), "dx"
+        close(p_["csum"] - 0.5, cs_ref, rtol=1e-4, atol=1e-5 * float(cs_ref.abs().max()) + 1e-6, what="column sums")
