@@ -446,8 +446,9 @@ class DiffusionEngine:
         self.dev = torch.device(device)
         self.Kp = (items + te + 63) & ~63  # leading dimension of [x_t | temb | 0-pad]; also of out / dout.  Whole 64-wide K tiles: the
         # 256 x 256 LDS-DMA GEMM tile (csrc/gemm_bf16_8ph.hip) takes no K remainder
-        shapes = [("emb_layer.weight", (te, te)), ("emb_layer.bias", (te,)), ("in_layers.0.weight", (H, self.Kp)), ("in_layers.0.bias", (H,)),
-                  (self.L2 + ".weight", (items, H)), (self.L2 + ".bias", (items,)), ("gate_layer.weight", (D, D)), ("gate_layer.bias", (D,))]
+        # flat layout: the small tensors whose gradients are ACCUMULATED (atomics / column sums) first, so that one memset clears them all
+        shapes = [("emb_layer.weight", (te, te)), ("emb_layer.bias", (te,)), ("in_layers.0.bias", (H,)), (self.L2 + ".bias", (items,)),
+                  ("gate_layer.weight", (D, D)), ("gate_layer.bias", (D,)), ("in_layers.0.weight", (H, self.Kp)), (self.L2 + ".weight", (items, H))]
         for nm, din, dout in self.mids:
             shapes += [(nm + ".weight", (dout, din)), (nm + ".bias", (dout,))]
         self.P = [FlatParams(shapes, self.dev) for _ in range(M)]
@@ -815,14 +816,12 @@ class DiffusionEngine:
             a, P, w = self.act[m], self.P[m], W[m]
             # only the gradients that are ACCUMULATED (atomics: the time-embedding layer, the K-split gate weight) need zeroing; every other
             # entry of the 55 MB flat gradient buffer is overwritten by its GEMM / column sum
-            ops.zero_(P.grad[: P.offsets["in_layers.0.weight"]])
-            ops.zero_(P.g("gate_layer.weight"))
+            ops.zero_(P.grad[: P.offsets["in_layers.0.weight"]])  # emb_layer.*, the biases, gate_layer.*: everything accumulated into
             a_last = a["mid"][-1][:B] if self.mids else a["h"][:B]                                 # input of the last layer
             if self._fused_expand():
                 # dout = d loss / d out (MSE part) + dum F^T is never written in fp32: one kernel forms it and emits dout (bf16), dout^T (bf16)
                 # and its column sums (the output bias gradient, into the zeroed vector)
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, None, None, w["dum"][:B])
-                ops.zero_(P.g(self.L2 + ".bias"))
                 ops.item_expand_fused(w["dum"][:B], feats[m], a["out"][:B], w["xb16"][:B], w["doutT16"], I, self.Kp, I, w=a["w"], gscale=gscale,
                                       csum=P.g(self.L2 + ".bias"), **(dict(x0bits=self._x0_bits[:B]) if self._x0_bits is not None else dict(x0=x0p)))
             else:
@@ -833,7 +832,7 @@ class DiffusionEngine:
                 else:
                     ops.gemm(w["dum"][:B], feats[m], out=w["dout"][:B], trans_b=True, precision=1, N=I, accumulate=True)
                 ops.transpose_cast_bf16(w["dout"][:B], w["doutT16"], rows=B, cols=I, rows_pad=Bp)      # dout^T [I, B]
-                ops.colsum(w["dout"][:B], B, I, P.g(self.L2 + ".bias"))
+                ops.colsum(w["dout"][:B], B, I, P.g(self.L2 + ".bias"), add=True)
                 ops.cast_bf16(w["dout"][:B], w["xb16"][:B])                                             # dout (pad columns are zero)
             ops.transpose_cast_bf16(a_last, w["hT16"], rows=B, cols=H, rows_pad=Bp)                # h^T    [H, B]
             if not self._folded_products():  # (folded: the forward made it)
@@ -848,7 +847,7 @@ class DiffusionEngine:
             ops.transpose_cast_bf16(w["dpre"][:B], w["dpreT16"], rows=B, cols=H, rows_pad=Bp)      # dpre^T [H, B]
             if not self._fused_expand():  # (fused: written by the forward's expand kernel)
                 ops.transpose_cast_bf16(a["xcat"][:B], w["xcatT16"], rows=B, cols=Kp, rows_pad=Bp) # xcat^T [Kp, B]
-            ops.colsum(w["dpre"][:B], B, H, P.g("in_layers.0.bias"))
+            ops.colsum(w["dpre"][:B], B, H, P.g("in_layers.0.bias"), add=True)
             ops.cast_bf16(w["dpre"][:B], w["dpre16"][:B])
             if not self._folded_products():
                 ops.transpose_cast_bf16(P.view("in_layers.0.weight"), w["w1T16"], rows=H, cols=Kp) # W1^T   [Kp, H]
@@ -878,7 +877,7 @@ class DiffusionEngine:
                 ops.temb_bwd(a["t"][:B], w["dxcat"][:B], I, self.te, P.g("emb_layer.weight"), P.g("emb_layer.bias"))
                 self._project_items(w["dxcat"][:B], feats[m], w["dpg"][:B], 1)                      # d(proj*gate) = dx' F
             ops.gate_bwd(w["dpg"][:B], a["proj"][:B], a["gate"][:B], w["dproj"][:B], w["dgate"][:B])
-            ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"))
+            ops.colsum(w["dgate"][:B], B, D, P.g("gate_layer.bias"), add=True)
         # dWg = dgate_pre^T proj: a single d x d output tile with K = B -- split K over 32 workgroups (zeroed above), all modalities in one launch
         ops.gemm_batched([dict(A=W[m]["dgate"][:B], B=self.act[m]["proj"][:B], out=self.P[m].g("gate_layer.weight"), trans_a=True, precision=1, split_k=32)
                           for m in range(M)])

@@ -1045,7 +1045,8 @@ def test_csr_rows_equal_the_dense_path(dev):
         assert abs(md[m] - mc[m]) <= 1e-5 * abs(md[m]), "CSR-fed training step == dense-fed training step (loss; K-sliced products: summation order)"
         # (fp32 sums accumulated by K slices and then ROUNDED to a bf16 operand -- (W1x F)^T -- can land on the other side of a rounding
         # boundary from run to run: one bf16 ulp on one of 65k entries)
-        assert float((gd[m] - E.P[m].grad).abs().max()) <= 1e-4 * float(gd[m].abs().max()), "CSR-fed training step == dense-fed training step (gradients)"
+        # (observed: either ~1e-7 or, when one such flip happens, 2.8e-4 of the largest gradient entry)
+        assert float((gd[m] - E.P[m].grad).abs().max()) <= 1e-3 * float(gd[m].abs().max()), "CSR-fed training step == dense-fed training step (gradients)"
     dense = [v.clone() for v in E.generate_views_bf16(want)]
     sparse = E.generate_views_bf16_csr(rows)
     for m in range(M):
