@@ -464,9 +464,10 @@ class DiffusionEngine:
         self.B_max = B_max
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
         Kp = self.Kp
+        self._loss_block = torch.zeros(M, B_max, dtype=torch.float64, device=self.dev)  # per-row losses of all modalities: one reduction per step
         self.act = [dict(xcat=z(B_max, Kp), proj=z(B_max, D), gate=z(B_max, D), pg=z(B_max, D), h=z(B_max, H), out=z(B_max, Kp), um=z(B_max, D),
-                         t=torch.zeros(B_max, dtype=torch.int32, device=self.dev), loss=torch.zeros(B_max, dtype=torch.float64, device=self.dev))
-                    for _ in range(M)]
+                         t=torch.zeros(B_max, dtype=torch.int32, device=self.dev), loss=self._loss_block[m])
+                    for m in range(M)]
         R_mid = max(B_max, self.chain_rows)
         for a_ in self.act:  # activations of the mid layers (fp32, kept for the backward) and their gradients
             a_["mid"] = [z(R_mid, dout) for _, _, dout in self.mids]
@@ -802,7 +803,7 @@ class DiffusionEngine:
                     ops.csr_gather_sum_latent(rows.ptr, rows.col, rows.users, self._ie16, self._zero_d, self.ui[:B], self._ui16[:B])
                 else:
                     self._project_items(x0p, i_embs, self.ui[:B], 1)
-            a["w"] = self.w_table[a["t"][:B].long()]
+            a["w"] = self.w_table.index_select(0, a["t"][:B])
             if self._x0_bits is not None:
                 ops.diff_loss_bits(a["out"][:B], self._x0_bits[:B], a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, a["loss"][:B])
             else:
@@ -924,7 +925,7 @@ class DiffusionEngine:
             else:
                 for m in range(M):
                     self.loss_forward(m, x0p, ts[m], noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
-            sums = torch.stack([self.act[m]["loss"][:B].sum() for m in range(M)])
+            sums = self._loss_block[:, :B].sum(1)
         if self.shard_world > 1:
             import torch.distributed as dist
             dist.all_reduce(sums, group=self.shard_group)
