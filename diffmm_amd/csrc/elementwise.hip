@@ -243,13 +243,13 @@ struct AdamExtra {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, AdamExtra ex, float l2c, float step_size,
-                                                    float b1, float b2, float inv_sqrt_c2, float eps) {
+                                                    float b1, float b2, float inv_sqrt_c2, float eps, int64_t l2_n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float pv = p[i];
     float gr = g[i];
     for (int k = 0; k < ex.cnt; ++k)
       if (i < ex.n[k]) gr += ex.g[k][i];
-    gr = fmaf(l2c, pv, gr);
+    if (i < l2_n) gr = fmaf(l2c, pv, gr);  // the l2 term covers a prefix (the embedding rows of a flat buffer that also holds other weights)
     const float mm = b1 * m[i] + (1.0f - b1) * gr;
     const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
     m[i] = mm;
@@ -420,7 +420,12 @@ extern "C" int dmm_sumsq(const float* x, int64_t n, float scale, float* scratch,
 
 extern "C" int dmm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
                              int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream) {
-  DMM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && n_extra >= 0 && n_extra <= 4, "dmm_adam_step: bad arguments");
+  return dmm_adam_step_prefix(p, g, m, v, n, extra, extra_n, n_extra, l2_coef, lr, beta1, beta2, eps, step, stream, n);
+}
+
+extern "C" int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
+                                    int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n) {
+  DMM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && n_extra >= 0 && n_extra <= 4 && l2_n >= 0, "dmm_adam_step: bad arguments");
   AdamExtra ex = {};
   ex.cnt = n_extra;
   for (int k = 0; k < n_extra; ++k) {
@@ -429,7 +434,7 @@ extern "C" int dmm_adam_step(float* p, const float* g, float* m, float* v, int64
   }
   const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ex, l2_coef,
-                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps);
+                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps, l2_n);
   DMM_LAUNCH_CHECK("dmm_adam_step");
   return 0;
 }

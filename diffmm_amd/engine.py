@@ -348,7 +348,7 @@ class JointEngine:
             try:
                 with L.Recorder() as calls:
                     self.step(self.users_s[:B], self.pos_s[:B], self.neg_s[:B], noise=None, precision=precision, update=True)
-                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] == "dmm_adam_step"])
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in ("dmm_adam_step", "dmm_adam_step_prefix")])
             finally:
                 self._philox_refs = None
             self.rng_step -= 1  # recording ran step()'s bookkeeping once without launching anything
@@ -382,9 +382,8 @@ class JointEngine:
         P.step += 1
         ne = self.N * D
         extra = list(self.T)
-        ops.adam_step(P.data[:ne], P.grad[:ne], P.m[:ne], P.v[:ne], self.lr, P.step, extra=extra, extra_n=[U * D] * len(extra),
-                      l2_coef=2.0 * self.hp["reg"])
-        ops.adam_step(P.data[ne:], P.grad[ne:], P.m[ne:], P.v[ne:], self.lr, P.step)
+        # one launch for the whole flat buffer: the l2 term and the extra gradient rows touch the embedding prefix only
+        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, extra=extra, extra_n=[U * D] * len(extra), l2_coef=2.0 * self.hp["reg"], l2_n=ne)
 
     def full_grads(self) -> Dict[str, Tensor]:
         """Gradients as autograd would report them (for parity tests): folds the extras / l2 term that Adam absorbs."""

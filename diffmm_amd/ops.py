@@ -452,13 +452,17 @@ def sumsq(x: Tensor, scale: float, out: Tensor, scratch: Optional[Tensor] = None
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, extra: Sequence[Tensor] = (), extra_n: Sequence[int] = (),
-              l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+              l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, l2_n: Optional[int] = None) -> None:
+    """l2_n: the l2 term (l2_coef * p added to the gradient) covers the first l2_n elements only (default: all)."""
     n = p.numel()
     if not (g.numel() == n and m.numel() == n and v.numel() == n):
         raise ValueError("adam: size mismatch")
     ex = (C.c_void_p * max(1, len(extra)))(*[L.ptr(t) for t in extra]) if extra else (C.c_void_p * 1)()
     en = (C.c_int64 * max(1, len(extra)))(*extra_n) if extra else (C.c_int64 * 1)()
-    L.call("dmm_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream())
+    if l2_n is None:
+        L.call("dmm_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream())
+    else:  # (the argument positions of lr and step are those of dmm_adam_step: the recorded plans patch them in place)
+        L.call("dmm_adam_step_prefix", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream(), int(l2_n))
 
 
 # ------------------------------------------------------------------------------------------------

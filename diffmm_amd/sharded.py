@@ -438,7 +438,7 @@ class ShardedJointEngine:
             try:
                 with L.Recorder() as calls:
                     self._step_body(B, None, precision, True)
-                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] == "dmm_adam_step"])
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in ("dmm_adam_step", "dmm_adam_step_prefix")])
             finally:
                 self._philox_refs = None
             self.rng_step -= 1  # recording ran the bookkeeping once without launching anything
@@ -459,9 +459,7 @@ class ShardedJointEngine:
         P, nu, D = self.P, self.nu, self.D
         P.step += 1
         ne = self.n * D
-        ops.adam_step(P.data[:ne], P.grad[:ne], P.m[:ne], P.v[:ne], self.lr, P.step, extra=list(self.T), extra_n=[nu * D] * self.M,
-                      l2_coef=2.0 * self.hp["reg"])
-        ops.adam_step(P.data[ne:], P.grad[ne:], P.m[ne:], P.v[ne:], self.lr, P.step)
+        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, extra=list(self.T), extra_n=[nu * D] * self.M, l2_coef=2.0 * self.hp["reg"], l2_n=ne)
 
     def full_grads(self) -> Dict[str, Tensor]:
         """Gradients as autograd reports them on the unsharded model (parity tests): u_embs = the replica's OWN rows."""

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 208
+#define DMM_VERSION 209
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -276,6 +276,9 @@ int dmm_sumsq(const float* x, int64_t n, float scale, float* scratch, float* out
 int dmm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/,
                   const int64_t* extra_n /*host*/, int n_extra, float l2_coef, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);
+/* the same step with the l2 term applied to the first l2_n elements only (one launch for a flat buffer = [embedding rows | other weights]) */
+int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/, const int64_t* extra_n,
+                         int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n);
 
 /* ---------------------------------------------------------------------------------------------------
  * Diffusion path.
