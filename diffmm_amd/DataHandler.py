@@ -269,7 +269,10 @@ class DataHandler:
         cfg.data.user_num, cfg.data.item_num = U, I
         self.graph = g
         self.trainMat = sp.coo_matrix((np.ones(g.nnz, np.float32), (g.trn_rows, g.trn_cols)), shape=(U, I))
-        self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev)
+        # bf16 gather operands for graphs whose operand outgrows the caches (graph.spmm_operand_vec; the user-sharded engine plans its own
+        # local blocks, fp32)
+        self.spmm_vec = graph.spmm_operand_vec(U + I, int(cfg.base.latdim))
+        self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev, vec=self.spmm_vec)
         self.trainData = TrainData(g.trn_rows, g.trn_cols, cfg, dev)
         self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 1)
         self.testData = TestData(g.tst_rows, g.tst_cols, g.trn_rows, g.trn_cols, U, I, dev)

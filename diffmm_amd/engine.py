@@ -126,6 +126,7 @@ class JointEngine:
         self.feat = [self._feat_block[m] for m in range(M)]
         # E_m^T [F_m, round_up(I, 32)] (constant): the weight gradient dW_m = dfeat_m^T E_m runs as E_m^T x dfeat_m on the item-space kernel
         self._featsT = None
+        self._x16_bufs = None
         self._nf_block, self._fnorm_block = z(M, items, D), z(M, items)  # blocks: the modalities' row normalisation is one launch
         self.nf = [self._nf_block[m] for m in range(M)]
         self.fnorm = [self._fnorm_block[m] for m in range(M)]
@@ -183,6 +184,8 @@ class JointEngine:
 
     def set_adjacency(self, adj: Adjacency, modal_adj: Sequence[Adjacency]):
         assert adj.n == self.N and adj.D == self.D and len(modal_adj) == self.M
+        if any(a.vec != adj.vec for a in modal_adj):
+            raise ValueError("JointEngine.set_adjacency: all graphs of a step must be planned for the same operand type (Adjacency.vec)")
         self.adj, self.modal_adj = adj, list(modal_adj)
         # launch plans hold raw pointers into the adjacency arrays: drop every plan recorded for a graph set that is gone
         live = (adj.uid, tuple(a.uid for a in self.modal_adj))
@@ -218,10 +221,27 @@ class JointEngine:
                                    precision=precision) for m, n in enumerate(names)])
         ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1))  # all modalities' rows
 
+    def _x16(self) -> Optional[Dict[str, Tensor]]:
+        """bf16 copies of the SpMMs' gathered operands when the graphs are planned for them (Adjacency.vec == 8, graph.spmm_operand_vec): made by
+        the producing SpMM's epilogue (y16 / y_pert16) where there is one, by a cast launch otherwise (the embedding table, the mix, the
+        gradient rows filled by scatter-adds).  Everything else -- accumulation, the epilogue operands c1 / c2 / m1 / m2, every output the
+        losses read -- stays fp32."""
+        if self.adj is None or self.adj.vec != 8:
+            return None
+        if self._x16_bufs is None:
+            zb = lambda *s_: torch.zeros(s_, dtype=torch.bfloat16, device=self.dev)
+            N, M, D = self.N, self.M, self.D
+            b = dict(emb=zb(N, D), nf=zb(M, self.I, D), Mx=zb(N, D), X1p=zb(N, D), X2p=zb(N, D), g=zb(M + 3, N, D), dX2p=zb(N, D), dBx=zb(N, D))
+            self._x16_bufs = b
+        return self._x16_bufs
+
     def forward(self, noise: Optional[Sequence[Tensor]] = None, with_cl: bool = True, precision: int = 3, _arena_zeroed: bool = False):
         hp, A, emb = self.hp, self.adj, self.P.view("emb")
         nd = hp["noise_degree"]
         self._project(precision, zeroed=_arena_zeroed)
+        x16 = self._x16()
+        if x16 is not None:
+            return self._forward_x16(x16, noise, with_cl)
         lanes = self.D // 4
         seed, base = hp.get("seed", 1818), self.rng_step * 3 * self.N * lanes
         nz = lambda k: dict(noise=noise[k]) if noise is not None else dict(noise=None, seed=seed, offset=base + k * self.N * lanes)
@@ -244,6 +264,38 @@ class JointEngine:
             refs.append((arr, 1, 1))
         if with_cl:
             arr = ops.spmm_batched([ops.SpmmOp(A, self.X2p, y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **nz(2))])
+            if refs is not None:
+                refs.append((arr, 0, 2))
+
+    def _forward_x16(self, x16: Dict[str, Tensor], noise, with_cl: bool):
+        """forward() with bf16 gather operands: the same launches plus the casts of the embedding table, the normalised features and the mix."""
+        hp, A, emb, M, U = self.hp, self.adj, self.P.view("emb"), self.M, self.U
+        nd = hp["noise_degree"]
+        lanes = self.D // 4
+        seed, base = hp.get("seed", 1818), self.rng_step * 3 * self.N * lanes
+        nz = lambda k: dict(noise=noise[k]) if noise is not None else dict(noise=None, seed=seed, offset=base + k * self.N * lanes)
+        refs = self._philox_refs
+        ops.cast_bf16(emb, x16["emb"])
+        ops.cast_bf16(self._nf_block.view(-1, self.D), x16["nf"].view(-1, self.D))
+        batch = [ops.SpmmOp(self.modal_adj[m], x16["emb"][:U], y=self.Z[m], x_hi=x16["nf"][m], split=U) for m in range(M)]
+        if with_cl:
+            batch.append(ops.SpmmOp(A, x16["emb"], y=self.Bx, y_pert=self.X1p, y_pert16=x16["X1p"], noise_degree=nd, **nz(0)))
+        else:
+            batch.append(ops.SpmmOp(A, x16["emb"], y=self.Bx))
+        arr = ops.spmm_batched(batch)
+        if refs is not None and with_cl:
+            refs.append((arr, len(batch) - 1, 0))
+        ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx)
+        ops.cast_bf16(self.Mx, x16["Mx"])
+        s = 1.0 + hp["residual_weight"]
+        batch = [ops.SpmmOp(A, x16["Mx"], y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
+        if with_cl:
+            batch.append(ops.SpmmOp(A, x16["X1p"], y_pert=self.X2p, y_pert16=x16["X2p"], noise_degree=nd, **nz(1)))
+        arr = ops.spmm_batched(batch)
+        if refs is not None and with_cl:
+            refs.append((arr, 1, 1))
+        if with_cl:
+            arr = ops.spmm_batched([ops.SpmmOp(A, x16["X2p"], y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **nz(2))])
             if refs is not None:
                 refs.append((arr, 0, 2))
 
@@ -304,13 +356,23 @@ class JointEngine:
         ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
         A = self.adj
         s = 1.0 + hp["residual_weight"]
-        ops.spmm_batched([ops.SpmmOp(A, self.dFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
-                          ops.SpmmOp(A, self.dCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0)])
-        ops.spmm_batched([ops.SpmmOp(A, self.dX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
+        x16 = self._x16()
+        if x16 is None:
+            gFin, gCl1, gX2p, gBx, gZ, o16 = self.dFin, self.dCl1, self.dX2p, self.dBx, self.dZ, {}
+        else:  # bf16 gather operands: the scatter-added gradient rows are cast (dFin, dCl1 now; dZ after the mixing backward has added to them)
+            g16 = x16["g"]
+            ops.cast_bf16(self.gblock[:2].view(-1, D), g16[:2].view(-1, D))
+            gFin, gCl1, gX2p, gBx, gZ, o16 = g16[0], g16[1], x16["dX2p"], x16["dBx"], [g16[3 + m] for m in range(M)], dict(y16=x16["dX2p"])
+        ops.spmm_batched([ops.SpmmOp(A, gFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
+                          ops.SpmmOp(A, gCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0, **o16)])
+        ops.spmm_batched([ops.SpmmOp(A, gX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
         ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
                         dw=self.P.g("modal_weight"), partials=self.mix_partials)
-        batch = [ops.SpmmOp(A, self.dBx, y=self.P.g("emb"))]
-        batch += [ops.SpmmOp(self.modal_adj[m], self.dZ[m], y=self.T[m]) for m in range(M)]
+        if x16 is not None:
+            ops.cast_bf16(self.dBx, x16["dBx"])
+            ops.cast_bf16(self.gblock[3:].view(-1, D), x16["g"][3:].view(-1, D))
+        batch = [ops.SpmmOp(A, gBx, y=self.P.g("emb"))]
+        batch += [ops.SpmmOp(self.modal_adj[m], gZ[m], y=self.T[m]) for m in range(M)]
         ops.spmm_batched(batch)
         names = modality_names(M)
         ne = self.N * D

@@ -212,6 +212,17 @@ class Adjacency:
         return self.nnz * 8 + (self.n + 1) * 4 + 2 * self.n * self.D * elem_bytes
 
 
+def spmm_operand_vec(n_rows: int, D: int) -> int:
+    """Operand type of the joint phase's SpMMs: 8 = the gathered operand X is stored in bf16 (dmm_spmm_csr_bf16: fp32 accumulation, fp32
+    epilogue operands and outputs), 4 = fp32.  bf16 gathers pay where the kernel is bound by the bytes that miss the caches: DMM_SPMM_BF16=auto
+    (default) switches at an fp32 operand of >= 256 MiB (the Infinity Cache; 1M users x 100k items at d = 256: 1.83 -> 0.99 ms per
+    SpMM, profiles/README.md) and never at the shipped datasets' sizes, where the launch is latency-bound; =1 / =0 force it."""
+    env = __import__("os").environ.get("DMM_SPMM_BF16", "auto")
+    if env in ("0", "1"):
+        return 8 if env == "1" and D >= 16 else 4
+    return 8 if D >= 16 and n_rows * D * 4 >= (1 << 28) else 4
+
+
 def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
                    keep_host: bool = False, vec: int = 4) -> Adjacency:
     rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)
@@ -247,9 +258,13 @@ class DeviceGraphBuilder:
     are user u's items, distinct and ascending.  Bit-identical to `make_adjacency` on the same edges (tests/test_host_logic.py);
     the only host read-back is the 32-byte size record."""
 
-    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = TASK_LEN):
+    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = TASK_LEN, vec: int = 4):
         import ctypes as C
         from . import _lib as L
+        if vec not in (4, 8):
+            raise ValueError("vec must be 4 (fp32 operands) or 8 (bf16 operands)")
+        self.D_full, self.vec = D, vec
+        D = D * 4 // vec  # (bf16 operands: a lane owns 8 columns -- the task plan of width D / 2, as in adjacency_from_csr)
         self.U, self.I, self.N, self.D, self.task_len = users, items, users + items, D, task_len
         self.dev = user_ptr.device
         up = user_ptr.long()
@@ -315,8 +330,8 @@ class DeviceGraphBuilder:
             tasks = tasks[:n_tasks]
             if validate:
                 check_plan(rowptr.cpu().numpy().astype(np.int64), tasks.cpu().numpy(), self.D)
-            adjs.append(Adjacency(n=N, nnz=nnz, D=self.D, rowptr=rowptr, col=col, val=val, tasks=tasks, n_head_tasks=head, n_partial_blocks=n_partial,
-                                  fix=fix[:n_fix] if n_partial else None))
+            adjs.append(Adjacency(n=N, nnz=nnz, D=self.D_full, rowptr=rowptr, col=col, val=val, tasks=tasks, n_head_tasks=head, n_partial_blocks=n_partial,
+                                  fix=fix[:n_fix] if n_partial else None, vec=self.vec))
         return adjs
 
 

@@ -86,3 +86,45 @@ def test_joint_step_loss_grads_and_update_vs_oracle(dev, fx, cl_method):
         a, b = sd[k].cpu().numpy(), P[k].detach().numpy()
         close(a[big], b[big], rtol=1e-4, atol=2e-5, what="after Adam " + k)
         assert np.abs(a - b).max() <= 2.1e-3, "after Adam (tiny-gradient entries) " + k
+
+
+@pytest.mark.parametrize("fx,cl_method,nd", [("gcn_mid_M3", 0, 0.0), ("gcn_mid_M3", 0, 1.5), ("gcn_mid_M2", 1, 0.0)])
+def test_joint_step_with_bf16_gather_operands(dev, fx, cl_method, nd):
+    """The joint step on graphs planned for bf16 gather operands (Adjacency.vec = 8: what graph.spmm_operand_vec picks once the operand
+    outgrows the caches) against the fp32-operand step: same launches plus casts, fp32 accumulation and epilogues.  Tolerances are those of a
+    bf16-stored operand (2^-9 relative per element, averaged down by the row sums): losses 2e-3, gradients 2 % of each tensor's scale in the
+    worst element and 0.5 % in the l2 norm -- with the CL layers' perturbation switched off (noise_degree = 0): sign(y) * noise is discontinuous
+    where y crosses zero, so with it on the few elements whose sign the operand rounding flips move by a whole perturbation (measured: 0.1-0.2 %
+    of the elements, 3-5 % of the embedding gradients' l2 norm) and only loose bounds hold."""
+    from diffmm_amd import graph
+    z = load(fx + ".npz")
+    U, I, M, D = int(z["users"]), int(z["items"]), int(z["M"]), int(z["d"])
+    if D < 16:
+        pytest.skip("bf16 operands need d >= 16")
+    rng = np.random.default_rng(11)
+    B = 200
+    e = rng.integers(0, len(z["trn_rows"]), size=B)
+    users, pos = T(z["trn_rows"][e].astype(np.int32)).to(dev), T(z["trn_cols"][e].astype(np.int32)).to(dev)
+    neg = T(rng.integers(0, I, size=B).astype(np.int32)).to(dev)
+    noise = [T(rng.random((U + I, D)).astype(np.float32)).to(dev) for _ in range(3)]
+    res = []
+    for vec in (4, 8):
+        E = _engine_from_gcn_fixture(z, dev, cl_method=cl_method, noise_degree=nd)
+        adj = graph.make_adjacency(z["trn_rows"], z["trn_cols"], U, I, D, dev, vec=vec)
+        madj = [graph.make_adjacency(z[f"m{m}_rows"], z[f"m{m}_cols"], U, I, D, dev, vec=vec) for m in range(M)]
+        E.set_adjacency(adj, madj)
+        E.step(users, pos, neg, noise=noise, precision=3, update=False)
+        res.append((E.losses(), {k: v.clone() for k, v in E.full_grads().items()}, {k: v.clone() for k, v in E.gcn_output().items()}))
+        assert (E._x16() is not None) == (vec == 8)
+    (l4, g4, o4), (l8, g8, o8) = res
+    for k in ("bpr", "reg", "cl", "loss"):
+        close(l8[k], l4[k], rtol=2e-3, what=k)
+    for k in o4:
+        close(o8[k], o4[k], rtol=0, atol=8e-3 * float(o4[k].abs().max()), what="forward " + k)
+    report = {k: (float((g8[k] - g4[k]).abs().max()) / (float(g4[k].abs().max()) + 1e-30), float((g8[k] - g4[k]).norm()) / (float(g4[k].norm()) + 1e-30)) for k in g4}
+    tol = (2e-2, 5e-3) if nd == 0.0 else (0.3, 8e-2)
+    for k, (worst, l2) in report.items():
+        assert worst <= tol[0] and l2 <= tol[1], f"grad {k}: worst element / scale, l2 error / norm: {report}"
+    # mixed operand types in one step are refused
+    with pytest.raises(ValueError):
+        E.set_adjacency(adj, [graph.make_adjacency(z["m0_rows"], z["m0_cols"], U, I, D, dev, vec=4)] * M)

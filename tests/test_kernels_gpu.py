@@ -589,6 +589,11 @@ def test_device_graph_builder_equals_host_builder(dev, name, D, task_len):
             assert np.array_equal(adj.fix.cpu().numpy(), plan.fix)
     if name == "hub":
         assert plan.n_partial_blocks > 0 and np.diff(rp).max() > 4096
+    if D >= 16:  # planned for bf16 gather operands: the plan of width D / 2, labelled with the full width
+        a8 = graph.DeviceGraphBuilder(T(ptr, dev), users, n_items, D, task_len, vec=8).build(T(items.astype(np.int32), dev))
+        h8 = graph.adjacency_from_csr(rp, c, v, D, dev, task_len, vec=8)
+        assert a8.vec == 8 and a8.D == D and np.array_equal(a8.tasks.cpu().numpy(), h8.tasks.cpu().numpy()) and a8.n_head_tasks == h8.n_head_tasks
+        assert a8.n_partial_blocks == h8.n_partial_blocks and np.array_equal(a8.val.cpu().numpy(), v)
 
 
 # ------------------------------------------------------------------------------------------------

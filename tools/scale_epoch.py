@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--users", type=int, default=1_000_000); ap.add_argument("--items", type=int, default=100_000)
 ap.add_argument("--latdim", type=int, default=256); ap.add_argument("--T", type=int, default=40); ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--joint-iters", type=int, default=0); ap.add_argument("--precision", type=int, default=1)
+ap.add_argument("--no-test", action="store_true")
 a = ap.parse_args()
 t0 = time.time()
 g = synth.make_graph(a.users, a.items, feats=(128, 768, 128), seed=1818, heavy_p=0.011, heavy=(300, 520))
@@ -43,7 +44,7 @@ if a.joint_iters:
 torch.cuda.synchronize(); t0 = time.time()
 res = coach.trainEpoch()
 torch.cuda.synchronize(); t_epoch = time.time() - t0
-t0 = time.time(); tst = coach.testEpoch(); torch.cuda.synchronize(); t_test = time.time() - t0
+t0 = time.time(); tst = {} if a.no_test else coach.testEpoch(); torch.cuda.synchronize(); t_test = time.time() - t0
 n_joint_full = -(-g.nnz // a.batch)
 out = {"users": g.users, "items": g.items, "E": g.nnz, "d": a.latdim, "T": a.T, "batch": a.batch, "epoch_s": t_epoch, "phase_s": dict(zip(("diffusion", "rebuild", "joint"), coach.phase_seconds)),
        "joint_iters_run": a.joint_iters or n_joint_full, "joint_iters_full_epoch": n_joint_full, "test_s": t_test,

@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 bpr = [i for i, e in enumerate(ev) if "bpr_kernel" in e[2]]
 n_joint = int(sys.argv[2]) if len(sys.argv) > 2 else 18
-last_start = bpr[-(n_joint + 1)] + 1
+last_start = bpr[-(n_joint + 1)] + 1 if len(bpr) > n_joint else 0  # (a single-epoch trace: from the start)
 i0 = [i for i, e in enumerate(ev) if "qsample" in e[2] and i > last_start][0]
 tk = [i for i, e in enumerate(ev) if "topk_rows" in e[2] and i > i0]
 adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[2] and i0 < i < tk[0]]
