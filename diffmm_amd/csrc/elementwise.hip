@@ -4,6 +4,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace dmm {
@@ -117,7 +119,12 @@ __global__ __launch_bounds__(256) void rownorm_bwd_batched_kernel(const RownormB
 struct MixPtrs {
   const float* z[3];
   float* dz[3];
+  __bf16* dz16[3];  // optional bf16 copies of the updated dz (gather operands of the next SpMM)
 };
+typedef __bf16 ew_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_bf16x4(__bf16* base, int64_t i4, const float4& v) {
+  reinterpret_cast<ew_bf16x4*>(base)[i4] = ew_bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
 
 __device__ __forceinline__ void softmax3(const float* logits, int M, float (&w)[3]) {
   float mx = logits[0];
@@ -130,8 +137,9 @@ __device__ __forceinline__ void softmax3(const float* logits, int M, float (&w)[
   for (int m = 0; m < 3; ++m) w[m] /= s;
 }
 
+template <bool X16>
 __global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ bx, MixPtrs P, const float* __restrict__ logits,
-                                                       int M, float maw, float* __restrict__ mx, int64_t n4) {
+                                                       int M, float maw, float* __restrict__ mx, __bf16* __restrict__ mx16, int64_t n4) {
   float w[3];
   softmax3(logits, M, w);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -145,12 +153,14 @@ __global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ 
       o.w += w[m] * (b.w + maw * z.w);
     }
     reinterpret_cast<float4*>(mx)[i] = o;
+    if (X16) st_bf16x4(mx16, i, o);
   }
 }
 
 // dbx = sw*dmx + extra ; dz_m += maw*w_m*dmx ; partial[blk][m] = sum dmx * (bx + maw z_m)
+template <bool X16>
 __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dmx, const float* __restrict__ bx, MixPtrs P,
-                                                       const float* __restrict__ extra, float* __restrict__ dbx,
+                                                       const float* __restrict__ extra, float* __restrict__ dbx, __bf16* __restrict__ dbx16,
                                                        const float* __restrict__ logits, int M, float maw,
                                                        float* __restrict__ partials, int64_t n4, int64_t cnt0_end, int64_t cnt1_begin,
                                                        int64_t cnt1_end) {
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ 
       o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
     }
     reinterpret_cast<float4*>(dbx)[i] = o;
+    if (X16) st_bf16x4(dbx16, i, o);
     for (int m = 0; m < M; ++m) {
       const float4 z = reinterpret_cast<const float4*>(P.z[m])[i];
       // user-sharded layout: a replica counts its own users and its slice of the replicated item rows towards d(logits)
@@ -177,6 +188,7 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ 
       const float c = maw * w[m];
       d.x += c * g.x; d.y += c * g.y; d.z += c * g.z; d.w += c * g.w;
       reinterpret_cast<float4*>(P.dz[m])[i] = d;
+      if (X16) st_bf16x4(P.dz16[m], i, d);
     }
   }
   for (int m = 0; m < 3; ++m) {
@@ -366,24 +378,28 @@ extern "C" int dmm_rownorm_bwd(const float* dy, const float* y, const float* nor
   return rownorm_dispatch(false, dy, y, norm, dx, nullptr, rows, D, (hipStream_t)stream);
 }
 
-extern "C" int dmm_gcn_mix_fwd(const float* bx, const float* const* z, const float* w_logits, int M, float maw, float* mx,
-                               int64_t n, void* stream) {
+static int mix_fwd_launch(const float* bx, const float* const* z, const float* w_logits, int M, float maw, float* mx, void* mx16, int64_t n, void* stream) {
   DMM_CHECK_ARG(bx && z && w_logits && mx && (M == 2 || M == 3) && n % 4 == 0, "dmm_gcn_mix_fwd: bad arguments (M=%d n=%lld)", M, (long long)n);
   MixPtrs P = {};
   for (int m = 0; m < M; ++m) P.z[m] = z[m];
-  hipLaunchKernelGGL(mix_fwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, bx, P, w_logits, M, maw, mx, n / 4);
+  if (mx16) hipLaunchKernelGGL(mix_fwd_kernel<true>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, bx, P, w_logits, M, maw, mx, (__bf16*)mx16, n / 4);
+  else hipLaunchKernelGGL(mix_fwd_kernel<false>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, bx, P, w_logits, M, maw, mx, (__bf16*)nullptr, n / 4);
   DMM_LAUNCH_CHECK("dmm_gcn_mix_fwd");
   return 0;
 }
-extern "C" int64_t dmm_gcn_mix_partials(int64_t n) { return (int64_t)grid_for(n / 4, 256) * 3; }
-extern "C" int dmm_gcn_mix_bwd(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
-                               float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
-                               void* stream) {
-  return dmm_gcn_mix_bwd_counted(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, n, n, n, stream);
+extern "C" int dmm_gcn_mix_fwd(const float* bx, const float* const* z, const float* w_logits, int M, float maw, float* mx,
+                               int64_t n, void* stream) {
+  return mix_fwd_launch(bx, z, w_logits, M, maw, mx, nullptr, n, stream);
 }
-extern "C" int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
-                                       float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
-                                       int64_t count0_end, int64_t count1_begin, int64_t count1_end, void* stream) {
+extern "C" int dmm_gcn_mix_fwd_x16(const float* bx, const float* const* z, const float* w_logits, int M, float maw, float* mx, void* mx16,
+                                   int64_t n, void* stream) {
+  DMM_CHECK_ARG(mx16 && ((uintptr_t)mx16 & 7) == 0, "dmm_gcn_mix_fwd_x16: mx16 must be an 8-byte aligned buffer");
+  return mix_fwd_launch(bx, z, w_logits, M, maw, mx, mx16, n, stream);
+}
+extern "C" int64_t dmm_gcn_mix_partials(int64_t n) { return (int64_t)grid_for(n / 4, 256) * 3; }
+static int mix_bwd_launch(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra, float* dbx,
+                          const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, int64_t count0_end, int64_t count1_begin,
+                          int64_t count1_end, void* dbx16, void* const* dz16, void* stream) {
   DMM_CHECK_ARG(dmx && bx && z && dz && dbx && w_logits && dw_logits && partials && (M == 2 || M == 3) && n % 4 == 0,
                 "dmm_gcn_mix_bwd: bad arguments");
   DMM_CHECK_ARG(count0_end % 4 == 0 && count1_begin % 4 == 0 && count1_end % 4 == 0 && 0 <= count0_end && count0_end <= n && count1_begin <= count1_end && count1_end <= n,
@@ -392,12 +408,74 @@ extern "C" int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const 
   for (int m = 0; m < M; ++m) {
     P.z[m] = z[m];
     P.dz[m] = dz[m];
+    if (dz16) {
+      DMM_CHECK_ARG(dz16[m] && ((uintptr_t)dz16[m] & 7) == 0, "dmm_gcn_mix_bwd_x16: dz16[%d] must be an 8-byte aligned buffer", m);
+      P.dz16[m] = (__bf16*)dz16[m];
+    }
   }
   const unsigned grid = grid_for(n / 4, 256);
-  hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, w_logits, M, maw, partials, n / 4,
-                     count0_end / 4, count1_begin / 4, count1_end / 4);
+  if (dz16) hipLaunchKernelGGL(mix_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, (__bf16*)dbx16, w_logits, M, maw, partials, n / 4,
+                               count0_end / 4, count1_begin / 4, count1_end / 4);
+  else hipLaunchKernelGGL(mix_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, (__bf16*)nullptr, w_logits, M, maw, partials, n / 4,
+                          count0_end / 4, count1_begin / 4, count1_end / 4);
   hipLaunchKernelGGL(mix_bwd_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)grid, w_logits, M, dw_logits);
   DMM_LAUNCH_CHECK("dmm_gcn_mix_bwd");
+  return 0;
+}
+extern "C" int dmm_gcn_mix_bwd(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
+                               float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
+                               void* stream) {
+  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, n, n, n, nullptr, nullptr, stream);
+}
+extern "C" int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra,
+                                       float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n,
+                                       int64_t count0_end, int64_t count1_begin, int64_t count1_end, void* stream) {
+  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, count0_end, count1_begin, count1_end, nullptr, nullptr, stream);
+}
+extern "C" int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra, float* dbx,
+                                   const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, void* dbx16, void* const* dz16,
+                                   void* stream) {
+  DMM_CHECK_ARG(dbx16 && dz16 && ((uintptr_t)dbx16 & 7) == 0, "dmm_gcn_mix_bwd_x16: dbx16 / dz16 missing or misaligned");
+  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, n, n, n, dbx16, dz16, stream);
+}
+
+// The rows a joint minibatch's scatter-adds touch -- users[b], U + pos[b], U + neg[b] -- of up to 4 [N, D] tensors: dst row = bf16(src row), or
+// zeros where src[t] is NULL.  (The gradient tensors the losses scatter into are zero everywhere else: their bf16 gather copies are kept by
+// casting just these rows and clearing them again after use, instead of a pass over all N rows.)
+struct BatchRowsP { const float* src[4]; __bf16* dst[4]; };
+__global__ __launch_bounds__(256) void cast_batch_rows_kernel(BatchRowsP P, int D, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+                                                              const int32_t* __restrict__ neg, int B, int U) {
+  const int lanes = D / 8, per = 256 / lanes;
+  const int l = threadIdx.x % lanes;
+  const float* __restrict__ src = P.src[blockIdx.y];
+  __bf16* __restrict__ dst = P.dst[blockIdx.y];
+  for (int r = blockIdx.x * per + threadIdx.x / lanes; r < 3 * B; r += gridDim.x * per) {
+    const int which = r / B, b = r - which * B;
+    const int64_t row = which == 0 ? users[b] : (int64_t)U + (which == 1 ? pos[b] : neg[b]);
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    bf16x8v o;
+    if (src) {
+      const float4 a = *reinterpret_cast<const float4*>(src + row * D + l * 8), c = *reinterpret_cast<const float4*>(src + row * D + l * 8 + 4);
+      o = bf16x8v{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)c.x, (__bf16)c.y, (__bf16)c.z, (__bf16)c.w};
+    } else {
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8v*>(dst + row * D + l * 8) = o;
+  }
+}
+extern "C" int dmm_cast_batch_rows_bf16(const float* const* src, void* const* dst, int n_t, int D, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                                        int B, int U, void* stream) {
+  DMM_CHECK_ARG(dst && n_t >= 1 && n_t <= 4 && users && pos && neg && B > 0 && U >= 0, "dmm_cast_batch_rows_bf16: bad arguments");
+  DMM_CHECK_ARG(D >= 8 && D <= 2048 && D % 8 == 0 && 256 % (D / 8) == 0, "dmm_cast_batch_rows_bf16: D=%d unsupported (a multiple of 8 with 256 %% (D / 8) == 0)", D);
+  BatchRowsP P = {};
+  for (int t = 0; t < n_t; ++t) {
+    DMM_CHECK_ARG(dst[t] && ((uintptr_t)dst[t] & 15) == 0 && (!src || !src[t] || ((uintptr_t)src[t] & 15) == 0), "dmm_cast_batch_rows_bf16: tensor %d missing or misaligned", t);
+    P.src[t] = src ? src[t] : nullptr;
+    P.dst[t] = (__bf16*)dst[t];
+  }
+  const int per = 256 / (D / 8);
+  hipLaunchKernelGGL(cast_batch_rows_kernel, dim3(std::min(2048, (3 * B + per - 1) / per), n_t), dim3(256), 0, (hipStream_t)stream, P, D, users, pos, neg, B, U);
+  DMM_LAUNCH_CHECK("dmm_cast_batch_rows_bf16");
   return 0;
 }
 

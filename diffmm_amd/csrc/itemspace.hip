@@ -39,7 +39,9 @@ template <int D, int MT, bool FT, bool OUT_T, typename BatchT, bool XB = false>
 __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
   static_assert(!XB || MT == 1, "bf16 X: 64-row workgroups only");
   constexpr int NT = D / 16;
-  constexpr int LDT = IP_KS * 2 + 16;  // bytes per feature column in LDS (+16: the 16 columns of a fragment read hit distinct banks)
+  constexpr int KSG = D > 128 ? IP_KS / 2 : IP_KS;  // items per LDS stage (d = 256: half, so that D feature columns still fit 64 KiB)
+  constexpr int NSTEP = KSG / 32;
+  constexpr int LDT = KSG * 2 + 16;  // bytes per feature column in LDS (+16: the 16 columns of a fragment read hit distinct banks)
   __shared__ __attribute__((aligned(16))) char ft[D * LDT];
   const ProjP& P = batch.p[blockIdx.z];
   const float* __restrict__ X = P.X; const float* __restrict__ F = P.F; float* __restrict__ out = P.out;
@@ -60,14 +62,14 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
   for (int mt = 0; mt < MT; ++mt) xrow[mt] = X + (long long)min(row0 + mt * 16 + fr, B - 1) * ldx + kg * 8;
   const __bf16* xrow16 = reinterpret_cast<const __bf16*>(X) + (long long)min(row0 + fr, B - 1) * ldx + kg * 8;  // (XB)
 
-  for (int k0 = kbeg; k0 < kend; k0 += IP_KS) {
-    const int steps = min(IP_KS, (kend - k0 + 31) & ~31) / 32;
+  for (int k0 = kbeg; k0 < kend; k0 += KSG) {
+    const int steps = min(KSG, (kend - k0 + 31) & ~31) / 32;
     // MT == 1 (one 16-row tile per wave: two loads per lane and k-step would leave the loop latency-bound): the X fragments of the WHOLE stage
     // are requested up front, under the staging of F
-    float4 xs[MT == 1 ? 4 : 1][2];
+    float4 xs[MT == 1 ? NSTEP : 1][2];
     if (MT == 1) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NSTEP; ++s) {
         const int kq = k0 + min(s, steps - 1) * 32;
         if (XB) {
           xs[s][0] = *reinterpret_cast<const float4*>(xrow16 + kq);  // 8 bf16 = the MFMA fragment as it is
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
     // stage F[k0 .. k0+KS, :] transposed (column-major, bf16); items past the slice are zero, so whatever X holds there is ignored
     // (requesting a thread's 8 pieces up front instead of one per loop trip was measured: no gain at MT = 4, slower at MT = 1)
     if (!FT) {
-      for (int idx = threadIdx.x; idx < IP_KS * (D / 4); idx += 256) {
+      for (int idx = threadIdx.x; idx < KSG * (D / 4); idx += 256) {
         const int kk = idx / (D / 4), c4 = idx % (D / 4);
         const int k = k0 + kk;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
         *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 3) * LDT + kk * 2) = (__bf16)v.w;
       }
     } else {  // F is [D, K]: column c of the stage is a contiguous piece of row c
-      for (int idx = threadIdx.x; idx < D * (IP_KS / 4); idx += 256) {
-        const int c = idx / (IP_KS / 4), k4 = (idx % (IP_KS / 4)) * 4;
+      for (int idx = threadIdx.x; idx < D * (KSG / 4); idx += 256) {
+        const int c = idx / (KSG / 4), k4 = (idx % (KSG / 4)) * 4;
         const int k = k0 + k4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* f = F + (long long)c * ldf + k;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
     __syncthreads();
     if (MT == 1) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NSTEP; ++s) {
         if (s < steps) {
           const bf16x8 fa = XB ? __builtin_bit_cast(bf16x8, xs[s][0]) : is_cvt8(xs[s][0], xs[s][1]);
 #pragma unroll
@@ -157,17 +159,23 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
     // transposed result: through LDS, so that consecutive lanes add to consecutive addresses of out[c, row0 ..] (the accumulator layout
     // has consecutive lanes on consecutive COLUMNS: 16 cache lines per atomic instruction instead of 1-2)
     static_assert(!OUT_T || MT == 1, "transposed output: 64-row workgroups only");
-    float* tile = reinterpret_cast<float*>(ft);  // [D][65] floats <= D * LDT bytes
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) tile[(nt * 16 + fr) * 65 + wave * 16 + kg * 4 + r] = acc[0][nt][r];
-    __syncthreads();
+    // (d = 256: two halves of 128 columns, so that the tile fits the staging buffer)
+    constexpr int TC = D > 128 ? 128 : D, TNT = TC / 16;
+    static_assert(TC * 65 * 4 <= D * LDT, "transposed tile must fit the staging buffer");
+    float* tile = reinterpret_cast<float*>(ft);  // [TC][65] floats
     const int rbase = blockIdx.x * 64;
-    for (int idx = threadIdx.x; idx < D * 64; idx += 256) {
-      const int col = idx >> 6, rl = idx & 63;
-      if (rbase + rl < B) atomicAdd(out + (long long)col * ldo + rbase + rl, tile[col * 65 + rl]);
+#pragma unroll
+    for (int h = 0; h < D / TC; ++h) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < TNT; ++nt) tile[(nt * 16 + fr) * 65 + wave * 16 + kg * 4 + r] = acc[0][h * TNT + nt][r];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < TC * 64; idx += 256) {
+        const int col = idx >> 6, rl = idx & 63;
+        if (rbase + rl < B) atomicAdd(out + (long long)(h * TC + col) * ldo + rbase + rl, tile[col * 65 + rl]);
+      }
     }
     return;
   }
@@ -225,23 +233,44 @@ __global__ __launch_bounds__(256) void item_expand_kernel(const float* __restric
         }
       }
     }
-  bf16x8 ff[4][KS], fp[4][KS];
+  // (d = 256: products formed up front, 128 columns of d at a time -- see item_expand_fused_kernel)
+  constexpr bool CHUNKED = KS > 4;
+  constexpr int KC = CHUNKED ? 4 : KS;
+  bf16x8 ff[4][KC], fp[4][KC];
+  f32x4 accs[CHUNKED ? 4 : 1][CHUNKED ? 4 : 1];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int ch = 0; ch < KS / KC; ++ch) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float* f = F + (long long)min(col0 + t * 16 + fr, I - 1) * ldf + ks * 32 + kg * 8;
-      const float* p = P + (long long)min(row0 + t * 16 + fr, B - 1) * ldp + ks * 32 + kg * 8;
-      ff[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
-      fp[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KC; ++ks) {
+        const float* f = F + (long long)min(col0 + t * 16 + fr, I - 1) * ldf + (ch * KC + ks) * 32 + kg * 8;
+        const float* p = P + (long long)min(row0 + t * 16 + fr, B - 1) * ldp + (ch * KC + ks) * 32 + kg * 8;
+        ff[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
+        fp[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+      }
+    if (CHUNKED) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          f32x4 a = ch == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : accs[ct][rt];
+#pragma unroll
+          for (int ks = 0; ks < KC; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], a, 0, 0, 0);
+          accs[ct][rt] = a;
+        }
     }
+  }
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (CHUNKED) acc = accs[CHUNKED ? ct : 0][CHUNKED ? rt : 0];
+      else {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KC; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], acc, 0, 0, 0);
+      }
       // acc[r] = (item column col0 + ct*16 + kg*4 + r, row row0 + rt*16 + fr)
       const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
       if (row < B && col < I) {
@@ -352,16 +381,35 @@ __global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFuse
       }
     }
   }
-  bf16x8 ff[4][KS], fp[4][KS];
+  // d <= 128: the fragments of the whole d stay in registers and each product is formed where it is used.  d = 256: the products are formed up
+  // front, 128 columns of d at a time (the fragments of one half: 128 registers next to the 64 accumulators and the 64 residual registers).
+  constexpr bool CHUNKED = KS > 4;
+  constexpr int KC = CHUNKED ? 4 : KS;
+  bf16x8 ff[4][KC], fp[4][KC];
+  f32x4 accs[CHUNKED ? 4 : 1][CHUNKED ? 4 : 1];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int ch = 0; ch < KS / KC; ++ch) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float* f = A.F + (long long)min(col0 + t * 16 + fr, I - 1) * A.ldf + ks * 32 + kg * 8;
-      const float* p = A.P + (long long)min(row0 + t * 16 + fr, B - 1) * A.ldp + ks * 32 + kg * 8;
-      ff[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
-      fp[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KC; ++ks) {
+        const float* f = A.F + (long long)min(col0 + t * 16 + fr, I - 1) * A.ldf + (ch * KC + ks) * 32 + kg * 8;
+        const float* p = A.P + (long long)min(row0 + t * 16 + fr, B - 1) * A.ldp + (ch * KC + ks) * 32 + kg * 8;
+        ff[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(f), *reinterpret_cast<const float4*>(f + 4));
+        fp[t][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+      }
+    if (CHUNKED) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          f32x4 a = ch == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : accs[ct][rt];
+#pragma unroll
+          for (int ks = 0; ks < KC; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], a, 0, 0, 0);
+          accs[ct][rt] = a;
+        }
     }
+  }
   typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
@@ -369,8 +417,11 @@ __global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFuse
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (CHUNKED) acc = accs[CHUNKED ? ct : 0][CHUNKED ? rt : 0];
+      else {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KC; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ct][ks], fp[rt][ks], acc, 0, 0, 0);
+      }
       // acc[r] = (item column col0 + ct*16 + kg*4 + r, row row0 + rt*16 + fr)
       const int row = row0 + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
       const float4 r4 = rr[ct][rt];
@@ -420,16 +471,18 @@ using namespace dmm;
 template <int MT, bool FT, bool OUT_T, typename BatchT>
 static void project_launch(const BatchT& b, int n, int D, int rb, int ks, hipStream_t s) {
   if (D == 64) hipLaunchKernelGGL((item_project_kernel<64, MT, FT, OUT_T, BatchT>), dim3(rb, ks, n), dim3(256), 0, s, b);
-  else hipLaunchKernelGGL((item_project_kernel<128, MT, FT, OUT_T, BatchT>), dim3(rb, ks, n), dim3(256), 0, s, b);
+  else if (D == 128) hipLaunchKernelGGL((item_project_kernel<128, MT, FT, OUT_T, BatchT>), dim3(rb, ks, n), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((item_project_kernel<256, (MT > 2 ? 2 : MT), FT, OUT_T, BatchT>), dim3(rb, ks, n), dim3(256), 0, s, b);  // (128 accumulators per lane at most)
 }
 
 extern "C" int dmm_item_project(const float* X, int64_t ldx, const float* F, int64_t ldf, float* out, int64_t ldo, int B, int I, int D, void* stream) {
   DMM_CHECK_ARG(X && F && out && B > 0 && I > 0, "dmm_item_project: bad arguments");
-  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_project: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(D == 64 || D == 128 || D == 256, "dmm_item_project: D=%d unsupported (64, 128 or 256)", D);
   DMM_CHECK_ARG(ldx % 4 == 0 && ldf % 4 == 0 && (((uintptr_t)X | (uintptr_t)F) & 15) == 0 && ldx >= ((I + 31) & ~31),
                 "dmm_item_project: X and F rows must be 16-byte aligned and X rows readable up to round_up(I, 32)");
   // K slices: enough workgroups to fill the chip a few times over, slices a multiple of 32 items
-  const int rb = (B + 255) / 256;
+  const int wg_rows = D == 256 ? 128 : 256;  // rows per workgroup: 4 waves x 16 MT
+  const int rb = (B + wg_rows - 1) / wg_rows;
   static const int force_ks = [] { const char* e = getenv("DMM_ITEM_KS"); return e ? atoi(e) : 0; }();  // tuning knob
   int ks = force_ks > 0 ? force_ks : std::max(1, std::min(64, 384 / rb));
   int kchunk = (((I + ks - 1) / ks) + 31) & ~31;
@@ -450,7 +503,7 @@ extern "C" int dmm_item_project_batched_x16(const dmm_project_problem* p, int n,
 }
 static int project_batched(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, bool x_bf16, void* stream) {
   DMM_CHECK_ARG(p && n >= 1 && n <= 4, "dmm_item_project_batched: 1..4 problems per launch");
-  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_project_batched: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(D == 64 || D == 128 || D == 256, "dmm_item_project_batched: D=%d unsupported (64, 128 or 256)", D);
   ProjBatch b;
   memset(&b, 0, sizeof(b));
   int rb = 0, ks = 0, rows_all = 0;
@@ -477,7 +530,8 @@ static int project_batched(const dmm_project_problem* p, int n, int D, int f_tra
   hipStream_t s = (hipStream_t)stream;
   if (x_bf16) {
     if (D == 64) hipLaunchKernelGGL((item_project_kernel<64, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
-    else hipLaunchKernelGGL((item_project_kernel<128, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+    else if (D == 128) hipLaunchKernelGGL((item_project_kernel<128, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((item_project_kernel<256, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
   } else if (f_transposed && !out_transposed) project_launch<1, true, false>(b, n, D, rb, ks, s);
   else if (!f_transposed && out_transposed) project_launch<1, false, true>(b, n, D, rb, ks, s);
   else if (!f_transposed && !out_transposed) project_launch<1, false, false>(b, n, D, rb, ks, s);
@@ -489,19 +543,20 @@ static int project_batched(const dmm_project_problem* p, int n, int D, int f_tra
 extern "C" int dmm_item_expand(const float* P, int64_t ldp, const float* F, int64_t ldf, const float* R, int64_t ldr, float* Y, int64_t ldy, int B, int I,
                                int D, void* stream) {
   DMM_CHECK_ARG(P && F && R && Y && B > 0 && I > 0, "dmm_item_expand: bad arguments");
-  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_expand: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(D == 64 || D == 128 || D == 256, "dmm_item_expand: D=%d unsupported (64, 128 or 256)", D);
   DMM_CHECK_ARG(ldp % 4 == 0 && ldf % 4 == 0 && (((uintptr_t)P | (uintptr_t)F) & 15) == 0, "dmm_item_expand: P and F rows must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((I + 255) / 256, (B + 63) / 64);
   if (D == 64) hipLaunchKernelGGL(item_expand_kernel<64>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
-  else hipLaunchKernelGGL(item_expand_kernel<128>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
+  else if (D == 128) hipLaunchKernelGGL(item_expand_kernel<128>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
+  else hipLaunchKernelGGL(item_expand_kernel<256>, grid, dim3(256), 0, s, P, (long long)ldp, F, (long long)ldf, R, (long long)ldr, Y, (long long)ldy, B, I);
   DMM_LAUNCH_CHECK("dmm_item_expand");
   return 0;
 }
 
 extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, int D, void* stream) {
   DMM_CHECK_ARG(a && (mode == 0 || mode == 1), "dmm_item_expand_fused: mode must be 0 (forward) or 1 (loss gradient)");
-  DMM_CHECK_ARG(D == 64 || D == 128, "dmm_item_expand_fused: D=%d unsupported (64 or 128)", D);
+  DMM_CHECK_ARG(D == 64 || D == 128 || D == 256, "dmm_item_expand_fused: D=%d unsupported (64, 128 or 256)", D);
   DMM_CHECK_ARG(a->P && a->F && a->R && a->Y16 && a->YT && a->B > 0 && a->I > 0 && a->Kc >= a->I && a->Kc % 4 == 0 && a->Kt > 0 && a->Kt <= a->Kc,
                 "dmm_item_expand_fused: bad arguments");
   DMM_CHECK_ARG(mode == 0 || ((a->X0 || (a->X0bits && a->ldbits * 32 >= a->I)) && a->w && a->csum), "dmm_item_expand_fused: mode 1 needs x0 (rows or bit masks), w and csum");
@@ -520,10 +575,14 @@ extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, i
     if (km == 0) hipLaunchKernelGGL((item_expand_fused_kernel<64, 0>), grid, dim3(256), 0, s, p);
     else if (km == 1) hipLaunchKernelGGL((item_expand_fused_kernel<64, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((item_expand_fused_kernel<64, 2>), grid, dim3(256), 0, s, p);
-  } else {
+  } else if (D == 128) {
     if (km == 0) hipLaunchKernelGGL((item_expand_fused_kernel<128, 0>), grid, dim3(256), 0, s, p);
     else if (km == 1) hipLaunchKernelGGL((item_expand_fused_kernel<128, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((item_expand_fused_kernel<128, 2>), grid, dim3(256), 0, s, p);
+  } else {
+    if (km == 0) hipLaunchKernelGGL((item_expand_fused_kernel<256, 0>), grid, dim3(256), 0, s, p);
+    else if (km == 1) hipLaunchKernelGGL((item_expand_fused_kernel<256, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((item_expand_fused_kernel<256, 2>), grid, dim3(256), 0, s, p);
   }
   DMM_LAUNCH_CHECK("dmm_item_expand_fused");
   return 0;

@@ -194,7 +194,9 @@ class JointEngine:
 
     # -- forward of gcn_MM (+ optionally the 3 perturbed CL layers) ---------------------------------
     def _feat_kernels(self, precision: int) -> bool:
-        """bf16 single-product mode at d = 64 / 128 with feature widths that are whole 32-wide K steps (every shipped feature file)."""
+        """bf16 single-product mode at d = 64 / 128 with feature widths that are whole 32-wide K steps (every shipped feature file).  (d = 256:
+        the kernels exist, but with 64 rows per workgroup the staging of the [K, 256] operand outweighs the rows: 684 + 547 us against 495 + 290 us
+        on the generic GEMM at 100k items.)"""
         return precision == 1 and self.D in (64, 128) and all(f.shape[1] % 32 == 0 for f in self.feats) and \
             self.hp.get("feat_kernels", os.environ.get("DMM_FEAT_KERNELS", "1") != "0")
 
@@ -285,8 +287,7 @@ class JointEngine:
         arr = ops.spmm_batched(batch)
         if refs is not None and with_cl:
             refs.append((arr, len(batch) - 1, 0))
-        ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx)
-        ops.cast_bf16(self.Mx, x16["Mx"])
+        ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx, mx16=x16["Mx"])
         s = 1.0 + hp["residual_weight"]
         batch = [ops.SpmmOp(A, x16["Mx"], y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
         if with_cl:
@@ -359,18 +360,24 @@ class JointEngine:
         x16 = self._x16()
         if x16 is None:
             gFin, gCl1, gX2p, gBx, gZ, o16 = self.dFin, self.dCl1, self.dX2p, self.dBx, self.dZ, {}
-        else:  # bf16 gather operands: the scatter-added gradient rows are cast (dFin, dCl1 now; dZ after the mixing backward has added to them)
+        else:
+            # bf16 gather operands.  dFin and dCl1 are zero outside the minibatch's rows (the losses scatter into users[b], U + pos[b], U + neg[b]):
+            # their copies get just those rows, cleared again once the launch that gathers them is queued; the mixing backward writes the copies
+            # of its dense outputs itself
             g16 = x16["g"]
-            ops.cast_bf16(self.gblock[:2].view(-1, D), g16[:2].view(-1, D))
+            ops.cast_batch_rows_bf16([self.gblock[0], self.gblock[1]], [g16[0], g16[1]], users, pos, neg, U)
             gFin, gCl1, gX2p, gBx, gZ, o16 = g16[0], g16[1], x16["dX2p"], x16["dBx"], [g16[3 + m] for m in range(M)], dict(y16=x16["dX2p"])
         ops.spmm_batched([ops.SpmmOp(A, gFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
                           ops.SpmmOp(A, gCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0, **o16)])
-        ops.spmm_batched([ops.SpmmOp(A, gX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
-        ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
-                        dw=self.P.g("modal_weight"), partials=self.mix_partials)
         if x16 is not None:
-            ops.cast_bf16(self.dBx, x16["dBx"])
-            ops.cast_bf16(self.gblock[3:].view(-1, D), x16["g"][3:].view(-1, D))
+            ops.cast_batch_rows_bf16(None, [x16["g"][0], x16["g"][1]], users, pos, neg, U)
+        ops.spmm_batched([ops.SpmmOp(A, gX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
+        if x16 is None:
+            ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
+                            dw=self.P.g("modal_weight"), partials=self.mix_partials)
+        else:
+            ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
+                            dw=self.P.g("modal_weight"), partials=self.mix_partials, dbx16=x16["dBx"], dz16=gZ)
         batch = [ops.SpmmOp(A, gBx, y=self.P.g("emb"))]
         batch += [ops.SpmmOp(self.modal_adj[m], gZ[m], y=self.T[m]) for m in range(M)]
         ops.spmm_batched(batch)
@@ -677,8 +684,8 @@ class DiffusionEngine:
         return a["out"][:B, : self.I]
 
     def _item_kernels(self, precision: int) -> bool:
-        """The dedicated item-space kernels (csrc/itemspace.hip) cover the bf16 single-product mode at d = 64 / 128."""
-        return precision == 1 and self.D in (64, 128)
+        """The dedicated item-space kernels (csrc/itemspace.hip) cover the bf16 single-product mode at d = 64 / 128 / 256."""
+        return precision == 1 and self.D in (64, 128, 256)
 
     def _fused_expand(self) -> bool:
         """The batched bf16 training step writes the expand results straight into the next GEMMs' bf16 operands (dmm_item_expand_fused);
@@ -709,7 +716,7 @@ class DiffusionEngine:
         """out = X[:, :I] @ F"""
         if precision == 1:
             ops.zero_(out)
-        if self._item_kernels(precision):
+        if self._item_kernels(precision) and self.D <= 128:  # (d = 256: 128 rows per workgroup re-stage F too often -- 5.5 ms against 2.1 ms at 8192 x 100k)
             ops.item_project(X, F, out, self.I)
         else:
             ops.gemm(X, F, out=out, precision=precision, K=self.I, split_k=8 if precision == 1 else 1)

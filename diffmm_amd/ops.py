@@ -345,20 +345,60 @@ def _ptr_array(ts: Sequence[Tensor]):
     return (C.c_void_p * len(ts))(*[L.ptr(_f32c(t, "tensor list")) for t in ts])
 
 
-def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, mx: Optional[Tensor] = None) -> Tensor:
+def _ptr_array_any(ts: Sequence[Tensor]):
+    return (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+
+
+def _bf16_like(t: Tensor, ref: Tensor, nm: str) -> Tensor:
+    if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.numel() != ref.numel():
+        raise ValueError(f"{nm}: need a contiguous bfloat16 tensor of {ref.numel()} elements")
+    return t
+
+
+def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, mx: Optional[Tensor] = None, mx16: Optional[Tensor] = None) -> Tensor:
+    """mx16: also write a bf16 copy of the mix (the gather operand of the next SpMM on graphs planned for bf16 operands)."""
     mx = torch.empty_like(bx) if mx is None else mx
-    L.call("dmm_gcn_mix_fwd", L.ptr(_f32c(bx, "bx")), _ptr_array(z), L.ptr(w_logits), len(z), maw, L.ptr(mx), bx.numel(), L.stream())
+    if mx16 is not None:
+        L.call("dmm_gcn_mix_fwd_x16", L.ptr(_f32c(bx, "bx")), _ptr_array(z), L.ptr(w_logits), len(z), maw, L.ptr(mx), L.ptr(_bf16_like(mx16, bx, "mx16")),
+               bx.numel(), L.stream())
+    else:
+        L.call("dmm_gcn_mix_fwd", L.ptr(_f32c(bx, "bx")), _ptr_array(z), L.ptr(w_logits), len(z), maw, L.ptr(mx), bx.numel(), L.stream())
     return mx
 
 
+def cast_batch_rows_bf16(src: Optional[Sequence[Tensor]], dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int) -> None:
+    """Rows users[b], U + pos[b], U + neg[b] of up to 4 [N, D] tensors: dst[t] row = bf16(src[t] row); src = None writes zero rows."""
+    D = dst[0].shape[1]
+    for t in dst:
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 2 or t.shape != dst[0].shape:
+            raise ValueError("cast_batch_rows_bf16: dst tensors must be contiguous bfloat16 [N, D] of one shape")
+    if src is not None:
+        if len(src) != len(dst) or any(_f32c(s_, "src").shape != dst[0].shape for s_ in src):
+            raise ValueError("cast_batch_rows_bf16: src / dst shape mismatch")
+    for i_ in (users, pos, neg):
+        if i_.dtype != torch.int32 or not i_.is_contiguous() or i_.numel() != users.numel():
+            raise ValueError("cast_batch_rows_bf16: index lists must be contiguous int32 of one length")
+    L.call("dmm_cast_batch_rows_bf16", _ptr_array(src) if src is not None else None, _ptr_array_any(dst), len(dst), D, L.ptr(users), L.ptr(pos), L.ptr(neg),
+           users.numel(), U, L.stream())
+
+
 def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tensor], dbx_extra: Optional[Tensor], w_logits: Tensor, maw: float,
-                dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None, count: Optional[tuple] = None):
-    """count = (end0, begin1, end1) in elements: only [0, end0) and [begin1, end1) enter dw (user-sharded replicas); None = everything."""
+                dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None, count: Optional[tuple] = None,
+                dbx16: Optional[Tensor] = None, dz16: Optional[Sequence[Tensor]] = None):
+    """count = (end0, begin1, end1) in elements: only [0, end0) and [begin1, end1) enter dw (user-sharded replicas); None = everything.
+    dbx16 / dz16: also write bf16 copies of dbx and of the updated dz[m] (gather operands of the next SpMM; not together with count)."""
     n = dmx.numel()
     dbx = torch.empty_like(dmx) if dbx is None else dbx
     dw = torch.empty(len(z), dtype=torch.float32, device=dmx.device) if dw is None else dw
     if partials is None:
         partials = torch.empty(int(L.lib().dmm_gcn_mix_partials(n)), dtype=torch.float32, device=dmx.device)
+    if dbx16 is not None or dz16 is not None:
+        if count is not None or dbx16 is None or dz16 is None or len(dz16) != len(z):
+            raise ValueError("gcn_mix_bwd: dbx16 and dz16 go together (one per modality) and exclude count")
+        L.call("dmm_gcn_mix_bwd_x16", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
+               L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, L.ptr(_bf16_like(dbx16, dmx, "dbx16")),
+               _ptr_array_any([_bf16_like(t, dmx, "dz16") for t in dz16]), L.stream())
+        return dbx, dw
     c = (n, n, n) if count is None else tuple(int(v) for v in count)
     L.call("dmm_gcn_mix_bwd_counted", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
            L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, c[0], c[1], c[2], L.stream())

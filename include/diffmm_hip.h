@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 209
+#define DMM_VERSION 210
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -209,6 +209,19 @@ int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const float* cons
                             const float* dbx_extra, float* dbx, const float* w_logits, float* dw_logits, int M, float maw,
                             float* partials, int64_t n, int64_t count0_end, int64_t count1_begin, int64_t count1_end, void* stream);
 
+/* bf16 gather operands of the joint phase's SpMMs (graphs planned with vec = 8, dmm_spmm_csr_bf16) made where their fp32 source is produced:
+ * the mixing kernels also write bf16 copies of their outputs (mx16; dbx16 and the updated dz16[m]) ... */
+int dmm_gcn_mix_fwd_x16(const float* bx, const float* const* z /*host*/, const float* w_logits, int M, float maw, float* mx, void* mx16 /*bf16 [n]*/,
+                        int64_t n, void* stream);
+int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z /*host*/, float* const* dz /*host, in/out*/, const float* dbx_extra,
+                        float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, void* dbx16,
+                        void* const* dz16 /*host array of M bf16 buffers*/, void* stream);
+/* ... and the gradient tensors the losses scatter into (zero outside the minibatch's rows users[b], U + pos[b], U + neg[b]: Model.py:84-134's
+ * outputs indexed by ancs / poss / negs, Main.py:318-352) get their bf16 copies by casting just those rows of up to 4 [N, D] tensors; src == NULL or
+ * src[t] == NULL writes zeros (clearing the rows again after use keeps the copy zero elsewhere).  D % 8 == 0, 256 % (D / 8) == 0. */
+int dmm_cast_batch_rows_bf16(const float* const* src /*host array or NULL*/, void* const* dst /*host array of n_t bf16 [N, D]*/, int n_t, int D,
+                             const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int U, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Contrastive + ranking losses.  Utils/Utils.py:57-75 (InfoNCE), :78-98 (bpr_loss), :45-54 (l2_reg_loss).
  * Views are gathered and row-normalised once per (tensor, index) pair ("slot"); a term is a pair of slots.
@@ -357,7 +370,7 @@ int dmm_noised_start(const float* x0, int64_t ldx0, const float* randn, float sq
                      uint64_t seed, uint64_t offset, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * Item-space products of the diffusion training step (bf16-rounded operands, fp32 accumulation; D = 64 or 128):
+ * Item-space products of the diffusion training step (bf16-rounded operands, fp32 accumulation; D = 64, 128 or 256):
  *   dmm_item_project  out[B, D] += X[B, :I] . F[I, D]   -- Model.py:207 (x_t @ modal_feat), :413 (model_output @ model_feats), :414
  *                     (x_start @ itmEmbeds).  `out` is accumulated with atomics: zero it first.  X rows must be readable (finite
  *                     values) up to round_up(I, 32) columns; those columns are multiplied by zero.

@@ -669,12 +669,14 @@ def test_denoise_and_diffusion_loss_vs_reference(dev, name):
         assert err < 6e-2, f"bf16-path grad {k}: max err {err:.3e} of the gradient scale"
 
 
-def test_train_step_batched_bf16_matches_split_precision(dev):
+@pytest.mark.parametrize("D", [64, 256])
+def test_train_step_batched_bf16_matches_split_precision(dev, D):
     """The benchmark's training step (precision 1: the modalities' large GEMMs batched onto the bf16 NT kernels, 256 x 256 LDS-DMA
-    tile included at this size) against the same step in split-bf16 (~fp32) arithmetic, which the golden vectors pin."""
+    tile included at this size; the item-space kernels incl. their d = 256 forms) against the same step in split-bf16 (~fp32) arithmetic,
+    which the golden vectors pin."""
     from diffmm_amd.engine import DiffusionEngine
     torch.manual_seed(3)
-    items, D, H, M, T_, B = 2500, 64, 1024, 3, 20, 2048
+    items, H, M, T_, B = 2500, 1024, 3, 20, 2048
     hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3, seed=11)
     E = DiffusionEngine(items, D, H, 10, M, T_, hp, dev, B)
     for m in range(M):
@@ -700,7 +702,7 @@ def test_train_step_batched_bf16_matches_split_precision(dev):
             assert cos > 0.999, f"modality {m} grad {k}: cosine {cos:.5f}"
 
 
-@pytest.mark.parametrize("B,I,D", [(300, 700, 64), (4096, 6710, 64), (1116, 2531, 128)])
+@pytest.mark.parametrize("B,I,D", [(300, 700, 64), (4096, 6710, 64), (1116, 2531, 128), (700, 1900, 256)])
 def test_item_project_and_expand(dev, B, I, D):
     """csrc/itemspace.hip against fp64 products of the bf16-rounded operands (only the fp32 summation order differs)."""
     from diffmm_amd import ops
@@ -726,7 +728,7 @@ def test_item_project_and_expand(dev, B, I, D):
     assert torch.equal(Rc[:, I:], R[:, I:])
 
 
-@pytest.mark.parametrize("D,B,I", [(64, 300, 1000), (128, 130, 517)])
+@pytest.mark.parametrize("D,B,I", [(64, 300, 1000), (128, 130, 517), (256, 200, 777)])
 def test_item_expand_fused_equals_the_separate_passes(dev, D, B, I):
     """dmm_item_expand_fused against the passes it replaces, bit for bit where the arithmetic is the same: forward (item_expand -> cast_bf16,
     transpose_cast_bf16, incl. the time-embedding / pad columns and the zero batch-row padding of the transposed copy) and loss gradient
@@ -824,7 +826,7 @@ def test_x0_bit_masks_equal_the_dense_rows(dev):
     close(res[1][2], res[0][2], rtol=1e-4, atol=1e-6 * float(res[0][2].abs().max()) + 1e-12, what="column sums")
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
 def test_item_project_batched_layouts(dev, D):
     """dmm_item_project_batched (the joint step's modality projections and their weight gradients) against fp64 products of the bf16-rounded
     operands: F given as an nn.Linear weight [D, K] with a bias (forward), the result stored transposed (weight gradient), three problems of
@@ -1183,3 +1185,40 @@ def test_rownorm_bwd_batched_equals_the_separate_launches(dev, D):
     for p_, (dx_ref, cs_ref) in zip(probs, want):
         assert torch.equal(p_["dx"], dx_ref), "dx"
         close(p_["csum"] - 0.5, cs_ref, rtol=1e-4, atol=1e-5 * float(cs_ref.abs().max()) + 1e-6, what="column sums")
+
+
+def test_bf16_gather_copies_written_by_their_producers(dev):
+    """dmm_gcn_mix_fwd_x16 / dmm_gcn_mix_bwd_x16 (the mixing kernels also write the bf16 copies of their outputs) equal the plain kernels followed
+    by dmm_cast_bf16, bit for bit; dmm_cast_batch_rows_bf16 casts / clears exactly the rows users[b], U + pos[b], U + neg[b]."""
+    from diffmm_amd import ops
+    torch.manual_seed(5)
+    N, D, M, U = 3000, 32, 3, 1800
+    bx, z = torch.randn(N, D, device=dev), [torch.randn(N, D, device=dev) for _ in range(M)]
+    w = torch.randn(M, device=dev)
+    cast = lambda t: (lambda o: (ops.cast_bf16(t.view(-1, D), o.view(-1, D)), o)[1])(torch.zeros(t.shape, dtype=torch.bfloat16, device=dev))
+    mx_a = ops.gcn_mix_fwd(bx, z, w, 0.2)
+    mx16 = torch.zeros(N, D, dtype=torch.bfloat16, device=dev)
+    mx_b = ops.gcn_mix_fwd(bx, z, w, 0.2, mx16=mx16)
+    assert torch.equal(mx_a, mx_b) and torch.equal(mx16, cast(mx_a))
+    dmx, extra = torch.randn(N, D, device=dev), torch.randn(N, D, device=dev)
+    dz0 = [torch.randn(N, D, device=dev) for _ in range(M)]
+    dz_a, dz_b = [t.clone() for t in dz0], [t.clone() for t in dz0]
+    dbx_a, dw_a = ops.gcn_mix_bwd(dmx, bx, z, dz_a, extra, w, 0.2)
+    dbx16, dz16 = torch.zeros(N, D, dtype=torch.bfloat16, device=dev), [torch.zeros(N, D, dtype=torch.bfloat16, device=dev) for _ in range(M)]
+    dbx_b, dw_b = ops.gcn_mix_bwd(dmx, bx, z, dz_b, extra, w, 0.2, dbx16=dbx16, dz16=dz16)
+    assert torch.equal(dbx_a, dbx_b) and torch.equal(dw_a, dw_b) and all(torch.equal(a, b) for a, b in zip(dz_a, dz_b))
+    assert torch.equal(dbx16, cast(dbx_a)) and all(torch.equal(h, cast(f)) for h, f in zip(dz16, dz_a))
+    # batch rows
+    B = 257
+    users = torch.randint(0, U, (B,), device=dev, dtype=torch.int32)
+    pos, neg = torch.randint(0, N - U, (B,), device=dev, dtype=torch.int32), torch.randint(0, N - U, (B,), device=dev, dtype=torch.int32)
+    src = [torch.randn(N, D, device=dev), torch.randn(N, D, device=dev)]
+    dst = [torch.full((N, D), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    ops.cast_batch_rows_bf16(src, dst, users, pos, neg, U)
+    touched = torch.zeros(N, dtype=torch.bool, device=dev)
+    touched[users.long()] = True; touched[U + pos.long()] = True; touched[U + neg.long()] = True
+    for s_, d_ in zip(src, dst):
+        assert torch.equal(d_[touched], s_[touched].bfloat16()) and bool((d_[~touched] == 7.0).all())
+    ops.cast_batch_rows_bf16(None, dst, users, pos, neg, U)
+    for d_ in dst:
+        assert bool((d_[touched] == 0).all()) and bool((d_[~touched] == 7.0).all())
