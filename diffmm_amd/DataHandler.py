@@ -272,7 +272,8 @@ class DataHandler:
         # bf16 gather operands for graphs whose operand outgrows the caches (graph.spmm_operand_vec; the user-sharded engine plans its own
         # local blocks, fp32)
         self.spmm_vec = graph.spmm_operand_vec(U + I, int(cfg.base.latdim))
-        self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev, vec=self.spmm_vec)
+        self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev, vec=self.spmm_vec,
+                                               task_len=graph.spmm_task_len(self.spmm_vec))
         self.trainData = TrainData(g.trn_rows, g.trn_cols, cfg, dev)
         self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 1)
         self.testData = TestData(g.tst_rows, g.tst_cols, g.trn_rows, g.trn_cols, U, I, dev)

@@ -174,7 +174,7 @@ class Coach:
     def makeTorchAdj(self, u_list, i_list, edge_list=None) -> graph.Adjacency:
         cfg = self.config
         return graph.make_adjacency(np.asarray(u_list), np.asarray(i_list), int(cfg.data.user_num), int(cfg.data.item_num), int(cfg.base.latdim),
-                                    self.device, vec=self.base_adj.vec)
+                                    self.device, vec=self.base_adj.vec, task_len=graph.spmm_task_len(self.base_adj.vec))
 
     # ---------------------------------------------------------------------------------------------
     def trainEpoch(self, draws=None, modal_adj_override: Optional[List[graph.Adjacency]] = None) -> Dict[str, float]:
@@ -224,7 +224,8 @@ class Coach:
                 edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep,
                                          csr=(dd.ptr, dd.col32, 0))
                 if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
-                    self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim), vec=self.base_adj.vec)
+                    self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim), vec=self.base_adj.vec,
+                                                                  task_len=graph.spmm_task_len(self.base_adj.vec))
             else:  # own users only (local ids index the local CSR; the data rows are looked up by global id)
                 if getattr(self, "graph_builder", None) is None:
                     self.graph_builder = graph.ShardedGraphBuilder(self.local_ptr, lay.nu, lay.users, lay.items, int(cfg.base.latdim), self.rank, self.world,

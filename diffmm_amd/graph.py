@@ -223,6 +223,13 @@ def spmm_operand_vec(n_rows: int, D: int) -> int:
     return 8 if D >= 16 and n_rows * D * 4 >= (1 << 28) else 4
 
 
+def spmm_task_len(vec: int) -> int:
+    """Non-zeros per SpMM task: TASK_LEN (16: the latency-bound launches of the shipped datasets' sizes), 64 on the graphs planned for bf16
+    gather operands (vec = 8, i.e. operands beyond the caches): at 1M users x 100k items, d = 256 that cuts the rows longer than one workgroup's
+    share ("giant" rows: partial sums + fix-up launch) from 14341 to 686 (SpMM 981 -> 968 us, the fix-up launch 197 -> 30 us)."""
+    return TASK_LEN if vec == 4 or "DMM_TASK_LEN" in __import__("os").environ else 64
+
+
 def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
                    keep_host: bool = False, vec: int = 4) -> Adjacency:
     rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)

@@ -63,8 +63,9 @@ def test_sports_shape_single_and_user_sharded():
     _check(shard, 1)
     assert shard["modal_nnz_sum_over_replicas"] == [2 * single["E"] + N] * 2, "the replicas' blocks hold every entry of the rebuilt graphs exactly once"
     s, d = single["epochs"][0], shard["epochs"][0]
-    for k, tol in (("Loss", 0.01), ("BPR Loss", 0.01), ("CL loss", 0.01), ("reg loss", 0.08)):
+    for k, tol in (("Loss", 0.02), ("BPR Loss", 0.01), ("CL loss", 0.02), ("reg loss", 0.08)):
         # (the L2 term is almost all first-epoch embedding GROWTH, which follows the replicas' own Philox noise streams through the rebuilt graphs:
-        # 1.5 % and 4 % apart in two measured runs; the loss terms that are means over the minibatches agree to < 1 %)
+        # 1.5 % and 4 % apart in two measured runs; the loss terms that are means over the minibatches agree to about 1 %: the CL term -- whose
+        # perturbation sign(y) * noise flips with the streams -- was 1.05 % apart in one run of many, hence 2 %)
         assert abs(s["train"][k] - d["train"][k]) <= tol * abs(s["train"][k]), f"{k}: single {s['train'][k]:.5f} vs user-sharded {d['train'][k]:.5f}"
     assert abs(s["test"]["Recall"] - d["test"]["Recall"]) <= 0.15 * s["test"]["Recall"] + 0.005
