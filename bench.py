@@ -167,9 +167,11 @@ def roofline_spmm_shard(users: int = 1_000_000, items: int = 500_000, D: int = 6
     g = synth.make_graph(users, items, feats=(), seed=1818, heavy_p=0.011, heavy=(300, 520))
     dev = torch.device("cuda", torch.cuda.current_device())
     out = {}
-    for v in ("f32", "bf16_xy"):
+    names = {"f32": "spmm_kernel<64, 4> (fp32 X, Y)", "bf16_x": "spmm_kernel<64, 8> (bf16 X, fp32 Y; fp32 accumulate) -- what the joint engine launches "
+             "at this size (graph.spmm_operand_vec: the fp32 operand is beyond the 256 MiB Infinity Cache)", "bf16_xy": "spmm_kernel<64, 8> (bf16 X, Y; fp32 accumulate)"}
+    for v in ("f32", "bf16_x", "bf16_xy"):
         m = spmm_scale.measure(g, D, dev, v)
-        out[v] = {"bound": "hbm", "kernel": "spmm_kernel<64, 4> (fp32 X, Y)" if v == "f32" else "spmm_kernel<64, 8> (bf16 X, Y; fp32 accumulate)",
+        out[v] = {"bound": "hbm", "kernel": names[v],
                   "achieved": m["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": m["algorithmic_GBps"] / HBM_PEAK_GBS,
                   "traffic": None, "avg_launch_us": m["us_per_launch"], "algorithmic_bytes": m["algorithmic_bytes"], "gather_GBps": m["gather_GBps"]}
         torch.cuda.empty_cache()
