@@ -461,7 +461,7 @@ def test_adam_matches_torch(dev):
     close(p2, r2, rtol=1e-6, atol=1e-7, what="adam extras")
 
 
-@pytest.mark.parametrize("cols,kmax", [(9, 4), (200, 40), (6710, 600), (18357, 300), (21000, 50)])  # <= 8192 / <= 20480 columns: register-resident kernels; beyond: streaming kernel
+@pytest.mark.parametrize("cols,kmax", [(9, 4), (200, 40), (6710, 600), (18357, 300), (21000, 50), (100003, 520)])  # <= 8192 / <= 20480 columns: register-resident kernels; beyond: streaming kernel
 def test_topk_rows(dev, cols, kmax):
     from diffmm_amd import ops
     rng = np.random.default_rng(cols)
