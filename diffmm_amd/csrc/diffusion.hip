@@ -311,8 +311,8 @@ struct TopkStreamShared {
   int sel_k, sel_cnt, n_cand;
 };
 // bins[0 .. 256 Q): the bin holding rank kk counted from the top -> S.sel_prefix = its index, S.sel_k = rank inside it, S.sel_cnt = its count
-template <int Q>
-__device__ __forceinline__ void topk_find_bin(TopkStreamShared& S, int kk) {
+template <int Q, typename SH>
+__device__ __forceinline__ void topk_find_bin(SH& S, int kk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int top = 256 * Q - 1 - (int)threadIdx.x * Q;  // thread t owns bins top, top - 1, .., top - Q + 1
   int v[Q], sum = 0;
@@ -694,7 +694,8 @@ __global__ __launch_bounds__(256) void eval_topk_reg_kernel(float* __restrict__ 
 // The mask is applied to `score` in place (the caller's buffer is scratch for the next user batch anyway).
 __global__ __launch_bounds__(256) void eval_topk_kernel(float* __restrict__ score, long long ld, const int32_t* __restrict__ users,
                                                          const int64_t* __restrict__ trn_ptr, const int64_t* __restrict__ trn_col, int cols, int k,
-                                                         int32_t* __restrict__ out) {
+                                                         int32_t* __restrict__ out, int only_flagged) {
+  if (only_flagged && out[(long long)blockIdx.x * k] != -1) return;  // (uniform) rows eval_topk_stream_kernel finished
   __shared__ int hist[256];
   __shared__ uint32_t sel_prefix;
   __shared__ int sel_k, n_out;
@@ -764,6 +765,106 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(float* __restrict__ scor
   }
 }
 
+// The same for rows beyond the register-resident forms (> 20480 columns), in TWO reads of the row (see topk_rows_kernel): an 11-bit histogram finds
+// the bucket holding rank k; the second read collects that bucket's (key, column) pairs in LDS and the < k entries above it as winners; threshold,
+// ties (smaller column first) and the final order are resolved in LDS.  (eval_topk_kernel above -- four radix passes, a winners pass and a
+// one-thread scan of the row for the ties, ~50k dependent loads per row at 100k columns -- stays as the path of an over-full bucket, and was
+// 13 s per evaluation of 1M users x 100k items; this one: see DESIGN section 7.)
+struct EvalStreamShared {
+  int hist[TOPK_BINS];
+  uint32_t ckey[TOPK_CAND];
+  int ccol[TOPK_CAND];
+  int wsum[4];
+  uint32_t sel_prefix;
+  int sel_k, sel_cnt, n_cand, n_out, n_tie;
+  uint32_t wkey[64];
+  int wcol[64];
+};
+__global__ __launch_bounds__(256) void eval_topk_stream_kernel(float* __restrict__ score, long long ld, const int32_t* __restrict__ users,
+                                                                const int64_t* __restrict__ trn_ptr, const int64_t* __restrict__ trn_col, int cols, int k,
+                                                                int32_t* __restrict__ out) {
+  __shared__ EvalStreamShared S;
+  const int u = users[blockIdx.x];
+  float* __restrict__ r = score + (long long)blockIdx.x * ld;
+  for (long long p = trn_ptr[u] + threadIdx.x; p < trn_ptr[u + 1]; p += 256) r[trn_col[p]] = -1e8f;
+  for (int i = threadIdx.x; i < TOPK_BINS; i += 256) S.hist[i] = 0;
+  if (threadIdx.x == 0) { S.n_cand = 0; S.n_out = 0; S.n_tie = 0; }
+  __syncthreads();
+  const int kq = k < cols ? k : cols;
+  const bool vec = (ld % 4 == 0) && (((uintptr_t)score) & 15) == 0;
+  const int c4 = vec ? cols / 4 : 0;
+  for (int j = threadIdx.x; j < c4; j += 256) {
+    const float4 v = reinterpret_cast<const float4*>(r)[j];
+    atomicAdd(&S.hist[fkey(v.x) >> 21], 1); atomicAdd(&S.hist[fkey(v.y) >> 21], 1);
+    atomicAdd(&S.hist[fkey(v.z) >> 21], 1); atomicAdd(&S.hist[fkey(v.w) >> 21], 1);
+  }
+  for (int j = 4 * c4 + threadIdx.x; j < cols; j += 256) atomicAdd(&S.hist[fkey(r[j]) >> 21], 1);
+  __syncthreads();
+  topk_find_bin<TOPK_BINS / 256>(S, kq);
+  const uint32_t top11 = S.sel_prefix;
+  if (S.sel_cnt > TOPK_CAND) {  // (uniform) a row concentrated on one value: flagged (out[row, 0] = -1) for eval_topk_kernel, launched behind this one
+    if (threadIdx.x == 0) out[(long long)blockIdx.x * k] = -1;
+    return;
+  }
+  uint32_t prefix = top11 << 21, mask = 0xffe00000u;
+  int kk = S.sel_k;
+  auto take = [&](uint32_t key, int col) {
+    const uint32_t b = key >> 21;
+    if (b > top11) { const int o = atomicAdd(&S.n_out, 1); S.wkey[o] = key; S.wcol[o] = col; }  // fewer than k entries lie above the bucket
+    else if (b == top11) { const int c = atomicAdd(&S.n_cand, 1); S.ckey[c] = key; S.ccol[c] = col; }
+  };
+  for (int j = threadIdx.x; j < c4; j += 256) {
+    const float4 v = reinterpret_cast<const float4*>(r)[j];
+    take(fkey(v.x), 4 * j); take(fkey(v.y), 4 * j + 1); take(fkey(v.z), 4 * j + 2); take(fkey(v.w), 4 * j + 3);
+  }
+  for (int j = 4 * c4 + threadIdx.x; j < cols; j += 256) take(fkey(r[j]), j);
+  __syncthreads();
+  const int n_cand = S.n_cand;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = pass == 0 ? 13 : (pass == 1 ? 5 : 0);
+    const uint32_t dm = pass == 2 ? 31u : 255u;
+    S.hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_cand; i += 256) {
+      const uint32_t key = S.ckey[i];
+      if ((key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & dm], 1);
+    }
+    __syncthreads();
+    topk_find_bin<1>(S, kk);
+    prefix |= S.sel_prefix << shift;
+    kk = S.sel_k;
+    mask |= dm << shift;
+  }
+  const uint32_t T = prefix;
+  const int need_ties = kk;  // >= 1
+  for (int i = threadIdx.x; i < n_cand; i += 256) {
+    const uint32_t key = S.ckey[i];
+    if (key > T) { const int o = atomicAdd(&S.n_out, 1); S.wkey[o] = key; S.wcol[o] = S.ccol[i]; }
+    else if (key == T) atomicAdd(&S.n_tie, 1);
+  }
+  __syncthreads();
+  const bool all_ties = S.n_tie == need_ties;  // the usual case: the threshold value occurs once
+  for (int i = threadIdx.x; i < n_cand; i += 256) {
+    if (S.ckey[i] != T) continue;
+    bool in = all_ties;
+    if (!in) {  // the need_ties smallest columns among the ties
+      const int col = S.ccol[i];
+      int rank = 0;
+      for (int j = 0; j < n_cand; ++j) rank += (S.ckey[j] == T && S.ccol[j] < col) ? 1 : 0;
+      in = rank < need_ties;
+    }
+    if (in) { const int o = atomicAdd(&S.n_out, 1); S.wkey[o] = T; S.wcol[o] = S.ccol[i]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < kq) {  // descending key, ties -> smaller column
+    const uint32_t mk = S.wkey[threadIdx.x];
+    const int mc = S.wcol[threadIdx.x];
+    int rank = 0;
+    for (int b = 0; b < kq; ++b) rank += (S.wkey[b] > mk || (S.wkey[b] == mk && S.wcol[b] < mc)) ? 1 : 0;
+    out[(long long)blockIdx.x * k + rank] = mc;
+  }
+}
+
 // Coach.calcRes (Main.py:422-448) for one user per wave: lane j holds the j-th recommendation; recall = hits / |truth|,
 // ndcg = sum_hit 1/log2(j+2) / sum_{l < min(|truth|, k)} 1/log2(l+2), precision = hits / k.  fp64 like the reference's Python floats.
 __global__ __launch_bounds__(256) void eval_metrics_kernel(const int32_t* __restrict__ top, const int32_t* __restrict__ users,
@@ -809,7 +910,11 @@ extern "C" int dmm_eval_topk(float* score, int64_t ld, const int32_t* users, con
   DMM_CHECK_ARG(score && users && trn_ptr && trn_col && out && rows > 0 && cols > 0 && k >= 1 && k <= 64, "dmm_eval_topk: bad arguments (k <= 64)");
   if (cols <= 256 * 32) hipLaunchKernelGGL(eval_topk_reg_kernel<32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
   else if (cols <= 256 * 80) hipLaunchKernelGGL(eval_topk_reg_kernel<80>, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
-  else hipLaunchKernelGGL(eval_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
+  else {
+    static const int legacy = [] { const char* e = getenv("DMM_EVAL_TOPK_LEGACY"); return e ? atoi(e) : 0; }();  // (tests: the multi-pass kernel alone)
+    if (!legacy) hipLaunchKernelGGL(eval_topk_stream_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out);
+    hipLaunchKernelGGL(eval_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, score, (long long)ld, users, trn_ptr, trn_col, cols, k, out, legacy ? 0 : 1);
+  }
   DMM_LAUNCH_CHECK("dmm_eval_topk");
   return 0;
 }

@@ -490,7 +490,7 @@ def test_topk_rows(dev, cols, kmax):
         assert (out[ptr[u]:ptr[u + 1]] == -1).all()
 
 
-@pytest.mark.parametrize("cols,k", [(9, 4), (200, 20), (6710, 20), (6710, 64), (18357, 20), (21000, 20)])
+@pytest.mark.parametrize("cols,k", [(9, 4), (200, 20), (6710, 20), (6710, 64), (18357, 20), (21000, 20), (100003, 64)])
 def test_eval_topk(dev, cols, k):
     """Masked top-k of Coach.testEpoch (Main.py:403-411): exact column ids in descending score order; ties -> smaller id."""
     from diffmm_amd import ops
