@@ -28,7 +28,15 @@ cfg.base.latdim, cfg.hyper.steps, cfg.train.batch, cfg.data.name = a.latdim, a.T
 seed_it(cfg.base.seed)
 h = DataHandler(cfg)
 t0 = time.time(); h.LoadData(graph_data=g); print(f"LoadData {time.time() - t0:.1f}s", flush=True)
-coach = Coach(h, cfg, precision=a.precision)
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+if world > 1:  # user-sharded over `world` replicas (python -m torch.distributed.run --nproc-per-node W tools/scale_epoch.py ...; DMM_TEST_BACKEND=gloo
+    import torch.distributed as dist  # lets the replicas share one GPU: a functional check, not a timing)
+    dist.init_process_group(os.environ.get("DMM_TEST_BACKEND", "nccl"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+    cfg.base.gpu = str(torch.cuda.current_device())
+    coach = Coach(h, cfg, precision=a.precision, rank=rank, world=world)
+else:
+    coach = Coach(h, cfg, precision=a.precision)
 t0 = time.time(); coach.prepareModel(); torch.cuda.synchronize(); print(f"prepareModel {time.time() - t0:.1f}s, {torch.cuda.memory_allocated() / 2**30:.1f} GiB", flush=True)
 if a.joint_iters:
     full = h.trainLoader
@@ -49,4 +57,8 @@ n_joint_full = -(-g.nnz // a.batch)
 out = {"users": g.users, "items": g.items, "E": g.nnz, "d": a.latdim, "T": a.T, "batch": a.batch, "epoch_s": t_epoch, "phase_s": dict(zip(("diffusion", "rebuild", "joint"), coach.phase_seconds)),
        "joint_iters_run": a.joint_iters or n_joint_full, "joint_iters_full_epoch": n_joint_full, "test_s": t_test,
        "peak_alloc_GiB": torch.cuda.max_memory_allocated() / 2**30, "train": {k: float(v) for k, v in res.items()}, "test": tst}
-print(json.dumps(out), flush=True)
+out["world"] = world
+if rank == 0:
+    print(json.dumps(out), flush=True)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
