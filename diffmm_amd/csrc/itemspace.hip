@@ -311,7 +311,7 @@ struct ExpandFusedP {
 };
 
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void item_expand_fused_kernel(const ExpandFusedP A) {
+__global__ __launch_bounds__(256, (D > 128 ? 3 : 1)) void item_expand_fused_kernel(const ExpandFusedP A) {
   constexpr int KS = D / 32;
   (void)sizeof(char[MODE >= 0 && MODE <= 2 ? 1 : -1]);
   constexpr int TLD = 72;  // bf16 elements per column of the transposed tile (64 rows + 8: 16-byte aligned, conflict-poor)
