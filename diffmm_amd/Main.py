@@ -86,7 +86,9 @@ class Coach:
             DE.hp["seed"] = int(DE.hp.get("seed", 1818)) + 7919 * self.rank  # the replicas' rows draw from different Philox streams
             DE.t_gen = torch.Generator(device=self.device)
             DE.t_gen.manual_seed(int(cfg.base.seed) + 101 * (self.rank + 1))
-            self.base_adj = make_sharded_adjacency(lay, h.graph.trn_rows, h.graph.trn_cols, int(cfg.base.latdim), self.device)
+            vec = graph.spmm_operand_vec(lay.n_local, int(cfg.base.latdim))  # by the size of the replica's own operand [own users ; items]
+            self.base_adj = make_sharded_adjacency(lay, h.graph.trn_rows, h.graph.trn_cols, int(cfg.base.latdim), self.device,
+                                                   task_len=graph.spmm_task_len(vec), vec=vec)
             self.local_ptr = (dd.ptr[lay.u0:lay.u1 + 1] - dd.ptr[lay.u0]).contiguous()  # CSR of the own users' train items
             self.local_ptr32 = self.local_ptr.to(torch.int32)
 
@@ -229,7 +231,7 @@ class Coach:
             else:  # own users only (local ids index the local CSR; the data rows are looked up by global id)
                 if getattr(self, "graph_builder", None) is None:
                     self.graph_builder = graph.ShardedGraphBuilder(self.local_ptr, lay.nu, lay.users, lay.items, int(cfg.base.latdim), self.rank, self.world,
-                                                                   group=self.group)
+                                                                   group=self.group, task_len=graph.spmm_task_len(self.base_adj.vec), vec=self.base_adj.vec)
                     self._own_local = torch.arange(lay.nu, device=dev)
                 edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [self._own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
                                          sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0))

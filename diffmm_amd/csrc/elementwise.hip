@@ -433,10 +433,10 @@ extern "C" int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const 
   return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, count0_end, count1_begin, count1_end, nullptr, nullptr, stream);
 }
 extern "C" int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra, float* dbx,
-                                   const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, void* dbx16, void* const* dz16,
-                                   void* stream) {
+                                   const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, int64_t count0_end,
+                                   int64_t count1_begin, int64_t count1_end, void* dbx16, void* const* dz16, void* stream) {
   DMM_CHECK_ARG(dbx16 && dz16 && ((uintptr_t)dbx16 & 7) == 0, "dmm_gcn_mix_bwd_x16: dbx16 / dz16 missing or misaligned");
-  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, n, n, n, dbx16, dz16, stream);
+  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, count0_end, count1_begin, count1_end, dbx16, dz16, stream);
 }
 
 // The rows a joint minibatch's scatter-adds touch -- users[b], U + pos[b], U + neg[b] -- of up to 4 [N, D] tensors: dst row = bf16(src row), or

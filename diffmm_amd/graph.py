@@ -350,9 +350,13 @@ class ShardedGraphBuilder:
     add up to it, each item self loop on exactly one replica (i % world == rank)."""
 
     def __init__(self, user_ptr_local: torch.Tensor, users_local: int, users_global: int, items: int, D: int, rank: int, world: int, group=None,
-                 task_len: int = TASK_LEN):
+                 task_len: int = TASK_LEN, vec: int = 4):
         import ctypes as C
         from . import _lib as L
+        if vec not in (4, 8):
+            raise ValueError("vec must be 4 (fp32 operands) or 8 (bf16 operands)")
+        self.D_full, self.vec = D, vec
+        D = D * 4 // vec  # (bf16 operands: the task plan of width D / 2, as in adjacency_from_csr)
         self.nu, self.U, self.I, self.D, self.task_len = users_local, users_global, items, D, task_len
         self.rank, self.world, self.group = rank, world, group
         self.n = users_local + items
@@ -406,6 +410,6 @@ class ShardedGraphBuilder:
             tasks = tasks[:n_tasks]
             if validate:
                 check_plan(rowptr.cpu().numpy().astype(np.int64), tasks.cpu().numpy(), self.D)
-            adjs.append(Adjacency(n=n, nnz=nnz_d, D=self.D, rowptr=rowptr, col=col[:nnz_d], val=val[:nnz_d], tasks=tasks, n_head_tasks=head,
-                                  n_partial_blocks=n_partial, fix=fix[:n_fix] if n_partial else None))
+            adjs.append(Adjacency(n=n, nnz=nnz_d, D=self.D_full, rowptr=rowptr, col=col[:nnz_d], val=val[:nnz_d], tasks=tasks, n_head_tasks=head,
+                                  n_partial_blocks=n_partial, fix=fix[:n_fix] if n_partial else None, vec=self.vec))
         return adjs

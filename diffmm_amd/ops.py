@@ -386,20 +386,20 @@ def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tenso
                 dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None, count: Optional[tuple] = None,
                 dbx16: Optional[Tensor] = None, dz16: Optional[Sequence[Tensor]] = None):
     """count = (end0, begin1, end1) in elements: only [0, end0) and [begin1, end1) enter dw (user-sharded replicas); None = everything.
-    dbx16 / dz16: also write bf16 copies of dbx and of the updated dz[m] (gather operands of the next SpMM; not together with count)."""
+    dbx16 / dz16: also write bf16 copies of dbx and of the updated dz[m] (gather operands of the next SpMM)."""
     n = dmx.numel()
     dbx = torch.empty_like(dmx) if dbx is None else dbx
     dw = torch.empty(len(z), dtype=torch.float32, device=dmx.device) if dw is None else dw
     if partials is None:
         partials = torch.empty(int(L.lib().dmm_gcn_mix_partials(n)), dtype=torch.float32, device=dmx.device)
+    c = (n, n, n) if count is None else tuple(int(v) for v in count)
     if dbx16 is not None or dz16 is not None:
-        if count is not None or dbx16 is None or dz16 is None or len(dz16) != len(z):
-            raise ValueError("gcn_mix_bwd: dbx16 and dz16 go together (one per modality) and exclude count")
+        if dbx16 is None or dz16 is None or len(dz16) != len(z):
+            raise ValueError("gcn_mix_bwd: dbx16 and dz16 go together (one per modality)")
         L.call("dmm_gcn_mix_bwd_x16", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
-               L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, L.ptr(_bf16_like(dbx16, dmx, "dbx16")),
+               L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, c[0], c[1], c[2], L.ptr(_bf16_like(dbx16, dmx, "dbx16")),
                _ptr_array_any([_bf16_like(t, dmx, "dz16") for t in dz16]), L.stream())
         return dbx, dw
-    c = (n, n, n) if count is None else tuple(int(v) for v in count)
     L.call("dmm_gcn_mix_bwd_counted", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
            L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, c[0], c[1], c[2], L.stream())
     return dbx, dw

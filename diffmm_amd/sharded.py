@@ -162,6 +162,7 @@ class ShardedJointEngine:
         self.arange = torch.arange(B_max, dtype=torch.int32, device=self.dev)
         self._plans: Dict[tuple, dict] = {}
         self._philox_refs: Optional[list] = None
+        self._x16_bufs: Optional[Dict[str, Tensor]] = None
 
     # -- parameters ------------------------------------------------------------------------------------
     @property
@@ -188,12 +189,25 @@ class ShardedJointEngine:
 
     def set_adjacency(self, adj: graph.Adjacency, modal_adj: Sequence[graph.Adjacency]):
         assert adj.n == self.n and adj.D == self.D and len(modal_adj) == self.M and all(a.n == self.n for a in modal_adj)
+        if any(a.vec != adj.vec for a in modal_adj):
+            raise ValueError("ShardedJointEngine.set_adjacency: all graphs of a step must be planned for the same operand type (Adjacency.vec)")
         self.adj, self.modal_adj = adj, list(modal_adj)
         live = (adj.uid, tuple(a.uid for a in self.modal_adj))
         for k in [k for k in self._plans if (k[2], k[3]) != live]:
             del self._plans[k]
 
     # -- one SpMM launch on the sharded layout -------------------------------------------------------------
+    def _x16(self) -> Optional[Dict[str, Tensor]]:
+        """bf16 copies of the SpMMs' gathered operands when the local blocks are planned for them (Adjacency.vec == 8; JointEngine._x16): the item rows'
+        copies are finished by dmm_spmm_epilogue_rows together with their fp32 rows, so the replicas' copies stay bit-identical."""
+        if self.adj is None or self.adj.vec != 8:
+            return None
+        if self._x16_bufs is None:
+            zb = lambda *s_: torch.zeros(s_, dtype=torch.bfloat16, device=self.dev)
+            n, M, D = self.n, self.M, self.D
+            self._x16_bufs = dict(emb=zb(n, D), nf=zb(M, self.I, D), Mx=zb(n, D), X1p=zb(n, D), X2p=zb(n, D), g=zb(M + 3, n, D), dX2p=zb(n, D), dBx=zb(n, D))
+        return self._x16_bufs
+
     def _ar(self, t: Tensor):
         if self.world > 1:
             L.call_py(_all_reduce, t, self.group)
@@ -276,8 +290,16 @@ class ShardedJointEngine:
         self._project(precision)
         refs = self._philox_refs
         M = self.M
-        modal = [dict(adj=self.modal_adj[m], x_lo=self.u_embs, y=self.Z[m], x_hi=self.nf[m], split=self.nu) for m in range(M)]
-        base = dict(adj=A, x_lo=emb, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **self._rng(0, noise)) if with_cl else dict(adj=A, x_lo=emb, y=self.Bx)
+        x16 = self._x16()
+        if x16 is None:
+            xe, xu, xnf, xMx, xX1, xX2, o1, o2, mo = emb, self.u_embs, self.nf, self.Mx, self.X1p, self.X2p, {}, {}, {}
+        else:  # bf16 gather operands (JointEngine._forward_x16): casts of the embedding table and the normalised features, producer-made copies behind them
+            ops.cast_bf16(emb, x16["emb"])
+            ops.cast_bf16(self._nf_block.view(-1, self.D), x16["nf"].view(-1, self.D))
+            xe, xu, xnf, xMx, xX1, xX2 = x16["emb"], x16["emb"][: self.nu], [x16["nf"][m] for m in range(M)], x16["Mx"], x16["X1p"], x16["X2p"]
+            o1, o2, mo = dict(y_pert16=x16["X1p"]), dict(y_pert16=x16["X2p"]), dict(mx16=x16["Mx"])
+        modal = [dict(adj=self.modal_adj[m], x_lo=xu, y=self.Z[m], x_hi=xnf[m], split=self.nu) for m in range(M)]
+        base = dict(adj=A, x_lo=xe, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **o1, **self._rng(0, noise)) if with_cl else dict(adj=A, x_lo=xe, y=self.Bx)
         # the modal graphs' partials are exchanged under the base graph's launch
         arr_m = self._spmm_local(modal, 0)
         self._exchange_begin(0, M)
@@ -288,16 +310,16 @@ class ShardedJointEngine:
         ops.spmm_epilogue_rows(arr, 1, self.D)
         if refs is not None and with_cl:
             refs.append((arr, 0, 0))
-        ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx)
+        ops.gcn_mix_fwd(self.Bx, self.Z, self.P.view("modal_weight"), hp["modal_adj_weight"], self.Mx, **mo)
         s = 1.0 + hp["residual_weight"]
-        batch = [dict(adj=A, x_lo=self.Mx, y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
+        batch = [dict(adj=A, x_lo=xMx, y=self.Fin, alpha=s, c1=self.Mx, beta=s)]
         if with_cl:
-            batch.append(dict(adj=A, x_lo=self.X1p, y_pert=self.X2p, noise_degree=nd, **self._rng(1, noise)))
+            batch.append(dict(adj=A, x_lo=xX1, y_pert=self.X2p, noise_degree=nd, **o2, **self._rng(1, noise)))
         arr = self._spmm(batch)
         if refs is not None and with_cl:
             refs.append((arr, 1, 1))
         if with_cl:
-            arr = self._spmm([dict(adj=A, x_lo=self.X2p, y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **self._rng(2, noise))])
+            arr = self._spmm([dict(adj=A, x_lo=xX2, y_pert=self.X3p, noise_degree=nd, y_mean=self.CL1, m1=self.X1p, m2=self.X2p, **self._rng(2, noise))])
             if refs is not None:
                 refs.append((arr, 0, 2))
 
@@ -389,18 +411,26 @@ class ShardedJointEngine:
         ops.scatter_add_rows(ops.Slots([(v[0], users, v[1]) for v in views]), B, D, self.seg_s, dub)
         A = self.adj
         s = 1.0 + hp["residual_weight"]
-        self._spmm([dict(adj=A, x_lo=self.dFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
-                    dict(adj=A, x_lo=self.dCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0)])
-        self._spmm([dict(adj=A, x_lo=self.dX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
+        x16 = self._x16()
+        if x16 is None:
+            gFin, gCl1, gX2p, gBx, gZ, o16, mo = self.dFin, self.dCl1, self.dX2p, self.dBx, self.dZ, {}, {}
+        else:  # bf16 gather operands: the scatter-added gradient rows are cast, the mixing backward writes the copies of its outputs itself
+            g16 = x16["g"]
+            ops.cast_bf16(self.gblock[:2].view(-1, D), g16[:2].view(-1, D))
+            gFin, gCl1, gX2p, gBx, gZ = g16[0], g16[1], x16["dX2p"], x16["dBx"], [g16[3 + m] for m in range(M)]
+            o16, mo = dict(y16=x16["dX2p"]), dict(dbx16=x16["dBx"], dz16=gZ)
+        self._spmm([dict(adj=A, x_lo=gFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
+                    dict(adj=A, x_lo=gCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0, **o16)])
+        self._spmm([dict(adj=A, x_lo=gX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
         i0, i1 = self.layout.item_slice()
         ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
-                        dw=self.P.g("modal_weight"), partials=self.mix_partials, count=(nu * D, (nu + i0) * D, (nu + i1) * D))
+                        dw=self.P.g("modal_weight"), partials=self.mix_partials, count=(nu * D, (nu + i0) * D, (nu + i1) * D), **mo)
         # last backward SpMMs.  Gradient exchange overlapped with the remaining backward work: the modal graphs' item partials (they feed
         # the projection gradients) travel under the base graph's SpMM; the base graph's item partials (= d i_embs) travel under the
         # projection backward.
-        arr_m = self._spmm_local([dict(adj=self.modal_adj[m], x_lo=self.dZ[m], y=self.T[m]) for m in range(M)], 0)
+        arr_m = self._spmm_local([dict(adj=self.modal_adj[m], x_lo=gZ[m], y=self.T[m]) for m in range(M)], 0)
         self._exchange_begin(0, M)
-        arr_b = self._spmm_local([dict(adj=A, x_lo=self.dBx, y=self.P.g("emb"))], M)
+        arr_b = self._spmm_local([dict(adj=A, x_lo=gBx, y=self.P.g("emb"))], M)
         self._exchange_end()
         ops.spmm_epilogue_rows(arr_m, M, D)
         self._exchange_begin(M, 1)
@@ -482,7 +512,8 @@ class ShardedJointEngine:
         return {"loss": bpr + reg + cl, "bpr": bpr, "reg": reg, "cl": cl}
 
 
-def make_sharded_adjacency(layout: ShardLayout, trn_rows: np.ndarray, trn_cols: np.ndarray, D: int, device, task_len: int = graph.TASK_LEN) -> graph.Adjacency:
+def make_sharded_adjacency(layout: ShardLayout, trn_rows: np.ndarray, trn_cols: np.ndarray, D: int, device, task_len: int = graph.TASK_LEN,
+                           vec: int = 4) -> graph.Adjacency:
     """The replica's local block of the normalised bipartite adjacency of (trn_rows, trn_cols): host build (base graph, once per run)."""
     rowptr, col, val = shard.local_block_csr(trn_rows, trn_cols, layout.users, layout.items, layout.u0, layout.u1, layout.rank, layout.world)
-    return graph.adjacency_from_csr(rowptr, col, val, D, device, task_len)
+    return graph.adjacency_from_csr(rowptr, col, val, D, device, task_len, vec=vec)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 210
+#define DMM_VERSION 211
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -214,7 +214,8 @@ int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const float* cons
 int dmm_gcn_mix_fwd_x16(const float* bx, const float* const* z /*host*/, const float* w_logits, int M, float maw, float* mx, void* mx16 /*bf16 [n]*/,
                         int64_t n, void* stream);
 int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z /*host*/, float* const* dz /*host, in/out*/, const float* dbx_extra,
-                        float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, void* dbx16,
+                        float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, int64_t count0_end,
+                        int64_t count1_begin, int64_t count1_end /*as dmm_gcn_mix_bwd_counted; n, n, n = everything*/, void* dbx16,
                         void* const* dz16 /*host array of M bf16 buffers*/, void* stream);
 /* ... and the gradient tensors the losses scatter into (zero outside the minibatch's rows users[b], U + pos[b], U + neg[b]: Model.py:84-134's
  * outputs indexed by ancs / poss / negs, Main.py:318-352) get their bf16 copies by casting just those rows of up to 4 [N, D] tensors; src == NULL or

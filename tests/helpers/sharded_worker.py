@@ -28,13 +28,14 @@ def problem(fx: str, cl_method: int):
     return z, U, I, M, D, users, pos, neg, noise, hp
 
 
-def build_sharded(z, U, I, M, D, hp, dev, rank, world, group=None, B_max=256):
+def build_sharded(z, U, I, M, D, hp, dev, rank, world, group=None, B_max=256, vec=None):
     from diffmm_amd import sharded
     lay = sharded.ShardLayout.make(z["trn_rows"], U, I, world, rank)
     E = sharded.ShardedJointEngine(lay, D, [torch.from_numpy(z[f"feat{m}"]) for m in range(M)], hp, dev, B_max, group=group)
     E.load_reference_state({k[2:]: z[k] for k in z.files if k.startswith("p/")})
-    adj = sharded.make_sharded_adjacency(lay, z["trn_rows"], z["trn_cols"], D, dev)
-    madj = [sharded.make_sharded_adjacency(lay, z[f"m{m}_rows"], z[f"m{m}_cols"], D, dev) for m in range(M)]
+    vec = int(os.environ.get("DMM_TEST_SPMM_VEC", "4")) if vec is None else vec  # 8: local blocks planned for bf16 gather operands
+    adj = sharded.make_sharded_adjacency(lay, z["trn_rows"], z["trn_cols"], D, dev, vec=vec)
+    madj = [sharded.make_sharded_adjacency(lay, z[f"m{m}_rows"], z[f"m{m}_cols"], D, dev, vec=vec) for m in range(M)]
     E.set_adjacency(adj, madj)
     return lay, E
 
