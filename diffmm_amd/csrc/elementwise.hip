@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ 
 }
 
 // dbx = sw*dmx + extra ; dz_m += maw*w_m*dmx ; partial[blk][m] = sum dmx * (bx + maw z_m)
-template <bool X16>
+template <bool X16, bool OVER = false>  // OVER: dz_m = maw w_m dmx (dz is not read: nothing was accumulated into it before this launch)
 __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dmx, const float* __restrict__ bx, MixPtrs P,
                                                        const float* __restrict__ extra, float* __restrict__ dbx, __bf16* __restrict__ dbx16,
                                                        const float* __restrict__ logits, int M, float maw,
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ 
       // user-sharded layout: a replica counts its own users and its slice of the replicated item rows towards d(logits)
       if (i < cnt0_end || (i >= cnt1_begin && i < cnt1_end))
         acc[m] += g.x * (b.x + maw * z.x) + g.y * (b.y + maw * z.y) + g.z * (b.z + maw * z.z) + g.w * (b.w + maw * z.w);
-      float4 d = reinterpret_cast<float4*>(P.dz[m])[i];
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!OVER) d = reinterpret_cast<float4*>(P.dz[m])[i];
       const float c = maw * w[m];
       d.x += c * g.x; d.y += c * g.y; d.z += c * g.z; d.w += c * g.w;
       reinterpret_cast<float4*>(P.dz[m])[i] = d;
@@ -399,9 +400,10 @@ extern "C" int dmm_gcn_mix_fwd_x16(const float* bx, const float* const* z, const
 extern "C" int64_t dmm_gcn_mix_partials(int64_t n) { return (int64_t)grid_for(n / 4, 256) * 3; }
 static int mix_bwd_launch(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra, float* dbx,
                           const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, int64_t count0_end, int64_t count1_begin,
-                          int64_t count1_end, void* dbx16, void* const* dz16, void* stream) {
+                          int64_t count1_end, void* dbx16, void* const* dz16, void* stream, int dz_overwrite = 0) {
   DMM_CHECK_ARG(dmx && bx && z && dz && dbx && w_logits && dw_logits && partials && (M == 2 || M == 3) && n % 4 == 0,
                 "dmm_gcn_mix_bwd: bad arguments");
+  DMM_CHECK_ARG(!dz_overwrite || dz16, "dmm_gcn_mix_bwd: dz_overwrite is a mode of the x16 entry point");
   DMM_CHECK_ARG(count0_end % 4 == 0 && count1_begin % 4 == 0 && count1_end % 4 == 0 && 0 <= count0_end && count0_end <= n && count1_begin <= count1_end && count1_end <= n,
                 "dmm_gcn_mix_bwd_counted: counted ranges must be multiples of 4 inside [0, n]");
   MixPtrs P = {};
@@ -414,7 +416,9 @@ static int mix_bwd_launch(const float* dmx, const float* bx, const float* const*
     }
   }
   const unsigned grid = grid_for(n / 4, 256);
-  if (dz16) hipLaunchKernelGGL(mix_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, (__bf16*)dbx16, w_logits, M, maw, partials, n / 4,
+  if (dz16 && dz_overwrite) hipLaunchKernelGGL((mix_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, (__bf16*)dbx16, w_logits, M,
+                                               maw, partials, n / 4, count0_end / 4, count1_begin / 4, count1_end / 4);
+  else if (dz16) hipLaunchKernelGGL(mix_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, (__bf16*)dbx16, w_logits, M, maw, partials, n / 4,
                                count0_end / 4, count1_begin / 4, count1_end / 4);
   else hipLaunchKernelGGL(mix_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dmx, bx, P, dbx_extra, dbx, (__bf16*)nullptr, w_logits, M, maw, partials, n / 4,
                           count0_end / 4, count1_begin / 4, count1_end / 4);
@@ -434,9 +438,9 @@ extern "C" int dmm_gcn_mix_bwd_counted(const float* dmx, const float* bx, const 
 }
 extern "C" int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z, float* const* dz, const float* dbx_extra, float* dbx,
                                    const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, int64_t count0_end,
-                                   int64_t count1_begin, int64_t count1_end, void* dbx16, void* const* dz16, void* stream) {
+                                   int64_t count1_begin, int64_t count1_end, void* dbx16, void* const* dz16, int dz_overwrite, void* stream) {
   DMM_CHECK_ARG(dbx16 && dz16 && ((uintptr_t)dbx16 & 7) == 0, "dmm_gcn_mix_bwd_x16: dbx16 / dz16 missing or misaligned");
-  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, count0_end, count1_begin, count1_end, dbx16, dz16, stream);
+  return mix_bwd_launch(dmx, bx, z, dz, dbx_extra, dbx, w_logits, dw_logits, M, maw, partials, n, count0_end, count1_begin, count1_end, dbx16, dz16, stream, dz_overwrite);
 }
 
 // The rows a joint minibatch's scatter-adds touch -- users[b], U + pos[b], U + neg[b] -- of up to 4 [N, D] tensors: dst row = bf16(src row), or
@@ -462,6 +466,35 @@ __global__ __launch_bounds__(256) void cast_batch_rows_kernel(BatchRowsP P, int 
     }
     *reinterpret_cast<bf16x8v*>(dst + row * D + l * 8) = o;
   }
+}
+// The same rows of up to 8 tensors of any element size cleared: row_bytes[t] bytes per row (a multiple of 16)
+struct BatchRowsZeroP { char* dst[8]; int row_bytes[8]; };
+__global__ __launch_bounds__(256) void zero_batch_rows_kernel(BatchRowsZeroP P, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+                                                              const int32_t* __restrict__ neg, int B, int U) {
+  char* __restrict__ dst = P.dst[blockIdx.y];
+  const int rb = P.row_bytes[blockIdx.y], lanes = rb / 16;  // 16-byte pieces per row
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)3 * B * lanes; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / lanes), l = (int)(e % lanes);
+    const int which = r / B, b = r - which * B;
+    const int64_t row = which == 0 ? users[b] : (int64_t)U + (which == 1 ? pos[b] : neg[b]);
+    *reinterpret_cast<uint4*>(dst + row * rb + (int64_t)l * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+extern "C" int dmm_zero_batch_rows(void* const* dst, const int32_t* row_bytes, int n_t, const int32_t* users, const int32_t* pos, const int32_t* neg, int B,
+                                   int U, void* stream) {
+  DMM_CHECK_ARG(dst && row_bytes && n_t >= 1 && n_t <= 8 && users && pos && neg && B > 0 && U >= 0, "dmm_zero_batch_rows: bad arguments");
+  BatchRowsZeroP P = {};
+  int max_lanes = 0;
+  for (int t = 0; t < n_t; ++t) {
+    DMM_CHECK_ARG(dst[t] && ((uintptr_t)dst[t] & 15) == 0 && row_bytes[t] > 0 && row_bytes[t] % 16 == 0, "dmm_zero_batch_rows: tensor %d missing, misaligned or rows not whole 16-byte pieces", t);
+    P.dst[t] = (char*)dst[t];
+    P.row_bytes[t] = row_bytes[t];
+    max_lanes = std::max(max_lanes, row_bytes[t] / 16);
+  }
+  const int64_t work = (int64_t)3 * B * max_lanes;
+  hipLaunchKernelGGL(zero_batch_rows_kernel, dim3((unsigned)std::min<int64_t>(4096, (work + 255) / 256), n_t), dim3(256), 0, (hipStream_t)stream, P, users, pos, neg, B, U);
+  DMM_LAUNCH_CHECK("dmm_zero_batch_rows");
+  return 0;
 }
 extern "C" int dmm_cast_batch_rows_bf16(const float* const* src, void* const* dst, int n_t, int D, const int32_t* users, const int32_t* pos, const int32_t* neg,
                                         int B, int U, void* stream) {

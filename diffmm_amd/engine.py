@@ -186,6 +186,10 @@ class JointEngine:
         assert adj.n == self.N and adj.D == self.D and len(modal_adj) == self.M
         if any(a.vec != adj.vec for a in modal_adj):
             raise ValueError("JointEngine.set_adjacency: all graphs of a step must be planned for the same operand type (Adjacency.vec)")
+        if adj.vec == 8 and (self.adj is None or self.adj.vec != 8):
+            ops.zero_(self.gblock)  # the bf16-operand step keeps the scatter targets clean row by row instead of clearing them: start clean
+            if self._x16_bufs is not None:
+                ops.zero_(self._x16_bufs["g"])
         self.adj, self.modal_adj = adj, list(modal_adj)
         # launch plans hold raw pointers into the adjacency arrays: drop every plan recorded for a graph set that is gone
         live = (adj.uid, tuple(a.uid for a in self.modal_adj))
@@ -336,7 +340,14 @@ class JointEngine:
         assert B <= self.B_max
         if noise is None and update and self._philox_refs is None:
             return self._step_planned(users, pos, neg, precision)
-        ops.zero_(self._zero_arena)  # gradient rows filled by scatter-adds, InfoNCE row gradients, K-sliced projections: one memset
+        x16 = self._x16()
+        if x16 is None:
+            ops.zero_(self._zero_arena)  # gradient rows filled by scatter-adds, InfoNCE row gradients, K-sliced projections: one memset
+        else:
+            # graphs beyond the caches (bf16 gather operands): the (M + 3) N d scatter targets are NOT cleared by a pass over all rows.  dFin /
+            # dCl1 / dCl2 are zero outside the minibatch's rows and get those rows cleared again once they are consumed (below); the dZ_m are
+            # written, not accumulated into, by the mixing backward, and the CL gradients are scattered into them afterwards.
+            ops.zero_(self._zero_arena[(M + 3) * N * D:])
         self.forward(noise=noise, with_cl=True, precision=precision, _arena_zeroed=True)
         slots, terms = self._slots_terms(users, pos)
         nT = self.n_terms
@@ -354,13 +365,14 @@ class JointEngine:
         ops.segment_sum(row_loss, nT + 1, B, 1.0, self.loss_parts)
         ops.sumsq(self.P.view("emb"), hp["reg"], self.loss_parts[nT + 1:], self.sumsq_scratch)
         # ---- backward ----
-        ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
         A = self.adj
         s = 1.0 + hp["residual_weight"]
-        x16 = self._x16()
         if x16 is None:
+            ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
             gFin, gCl1, gX2p, gBx, gZ, o16 = self.dFin, self.dCl1, self.dX2p, self.dBx, self.dZ, {}
         else:
+            modal = range(2, 2 + 2 * M)  # the slots of the modality views: their gradients go into dZ_m, behind the mixing backward
+            ops.scatter_normalize_bwd(ops.Slots([(e_[0], e_[1], None if i_ in modal else e_[2]) for i_, e_ in enumerate(slots.entries)]), B, D, zhat, znorm, dzhat)
             # bf16 gather operands.  dFin and dCl1 are zero outside the minibatch's rows (the losses scatter into users[b], U + pos[b], U + neg[b]):
             # their copies get just those rows, cleared again once the launch that gathers them is queued; the mixing backward writes the copies
             # of its dense outputs itself
@@ -369,15 +381,18 @@ class JointEngine:
             gFin, gCl1, gX2p, gBx, gZ, o16 = g16[0], g16[1], x16["dX2p"], x16["dBx"], [g16[3 + m] for m in range(M)], dict(y16=x16["dX2p"])
         ops.spmm_batched([ops.SpmmOp(A, gFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
                           ops.SpmmOp(A, gCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0, **o16)])
-        if x16 is not None:
-            ops.cast_batch_rows_bf16(None, [x16["g"][0], x16["g"][1]], users, pos, neg, U)
         ops.spmm_batched([ops.SpmmOp(A, gX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
         if x16 is None:
             ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
                             dw=self.P.g("modal_weight"), partials=self.mix_partials)
         else:
+            # dFin, dCl1, dCl2 and the two bf16 copies are consumed: their minibatch rows are cleared (they stay zero for the next step)
+            ops.zero_batch_rows([self.gblock[0], self.gblock[1], self.gblock[2], x16["g"][0], x16["g"][1]], users, pos, neg, U)
             ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
-                            dw=self.P.g("modal_weight"), partials=self.mix_partials, dbx16=x16["dBx"], dz16=gZ)
+                            dw=self.P.g("modal_weight"), partials=self.mix_partials, dbx16=x16["dBx"], dz16=gZ, dz_overwrite=True)
+            # the CL gradients of the modality views on top, then the bf16 copies of the rows they touched
+            ops.scatter_normalize_bwd(ops.Slots([(e_[0], e_[1], e_[2] if i_ in modal else None) for i_, e_ in enumerate(slots.entries)]), B, D, zhat, znorm, dzhat)
+            ops.cast_batch_rows_bf16(self.dZ, gZ, users, pos, neg, U)
         batch = [ops.SpmmOp(A, gBx, y=self.P.g("emb"))]
         batch += [ops.SpmmOp(self.modal_adj[m], gZ[m], y=self.T[m]) for m in range(M)]
         ops.spmm_batched(batch)

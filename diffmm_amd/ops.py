@@ -366,6 +366,19 @@ def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, m
     return mx
 
 
+def zero_batch_rows(dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int) -> None:
+    """Rows users[b], U + pos[b], U + neg[b] of up to 8 contiguous [N, D] tensors (fp32 and / or bf16) cleared in one launch."""
+    rb = []
+    for t in dst:
+        if not t.is_contiguous() or t.dim() != 2 or (t.shape[1] * t.element_size()) % 16:
+            raise ValueError("zero_batch_rows: contiguous 2-D tensors whose rows are whole 16-byte pieces")
+        rb.append(t.shape[1] * t.element_size())
+    for i_ in (users, pos, neg):
+        if i_.dtype != torch.int32 or not i_.is_contiguous() or i_.numel() != users.numel():
+            raise ValueError("zero_batch_rows: index lists must be contiguous int32 of one length")
+    L.call("dmm_zero_batch_rows", _ptr_array_any(dst), (C.c_int32 * len(rb))(*rb), len(dst), L.ptr(users), L.ptr(pos), L.ptr(neg), users.numel(), U, L.stream())
+
+
 def cast_batch_rows_bf16(src: Optional[Sequence[Tensor]], dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int) -> None:
     """Rows users[b], U + pos[b], U + neg[b] of up to 4 [N, D] tensors: dst[t] row = bf16(src[t] row); src = None writes zero rows."""
     D = dst[0].shape[1]
@@ -384,9 +397,10 @@ def cast_batch_rows_bf16(src: Optional[Sequence[Tensor]], dst: Sequence[Tensor],
 
 def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tensor], dbx_extra: Optional[Tensor], w_logits: Tensor, maw: float,
                 dbx: Optional[Tensor] = None, dw: Optional[Tensor] = None, partials: Optional[Tensor] = None, count: Optional[tuple] = None,
-                dbx16: Optional[Tensor] = None, dz16: Optional[Sequence[Tensor]] = None):
+                dbx16: Optional[Tensor] = None, dz16: Optional[Sequence[Tensor]] = None, dz_overwrite: bool = False):
     """count = (end0, begin1, end1) in elements: only [0, end0) and [begin1, end1) enter dw (user-sharded replicas); None = everything.
-    dbx16 / dz16: also write bf16 copies of dbx and of the updated dz[m] (gather operands of the next SpMM)."""
+    dbx16 / dz16: also write bf16 copies of dbx and of the updated dz[m] (gather operands of the next SpMM); with them dz_overwrite: dz[m] is
+    written, not accumulated into (nothing was scattered into it before this launch: it needs no clearing and is not read)."""
     n = dmx.numel()
     dbx = torch.empty_like(dmx) if dbx is None else dbx
     dw = torch.empty(len(z), dtype=torch.float32, device=dmx.device) if dw is None else dw
@@ -398,8 +412,10 @@ def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tenso
             raise ValueError("gcn_mix_bwd: dbx16 and dz16 go together (one per modality)")
         L.call("dmm_gcn_mix_bwd_x16", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
                L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, c[0], c[1], c[2], L.ptr(_bf16_like(dbx16, dmx, "dbx16")),
-               _ptr_array_any([_bf16_like(t, dmx, "dz16") for t in dz16]), L.stream())
+               _ptr_array_any([_bf16_like(t, dmx, "dz16") for t in dz16]), 1 if dz_overwrite else 0, L.stream())
         return dbx, dw
+    if dz_overwrite:
+        raise ValueError("gcn_mix_bwd: dz_overwrite needs dbx16 / dz16")
     L.call("dmm_gcn_mix_bwd_counted", L.ptr(_f32c(dmx, "dmx")), L.ptr(_f32c(bx, "bx")), _ptr_array(z), _ptr_array(dz), L.ptr(dbx_extra), L.ptr(dbx),
            L.ptr(w_logits), L.ptr(dw), len(z), maw, L.ptr(partials), n, c[0], c[1], c[2], L.stream())
     return dbx, dw

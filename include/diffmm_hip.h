@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 211
+#define DMM_VERSION 212
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -216,10 +216,13 @@ int dmm_gcn_mix_fwd_x16(const float* bx, const float* const* z /*host*/, const f
 int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z /*host*/, float* const* dz /*host, in/out*/, const float* dbx_extra,
                         float* dbx, const float* w_logits, float* dw_logits, int M, float maw, float* partials, int64_t n, int64_t count0_end,
                         int64_t count1_begin, int64_t count1_end /*as dmm_gcn_mix_bwd_counted; n, n, n = everything*/, void* dbx16,
-                        void* const* dz16 /*host array of M bf16 buffers*/, void* stream);
+                        void* const* dz16 /*host array of M bf16 buffers*/, int dz_overwrite /*1: dz_m = maw w_m dmx, dz is not read*/, void* stream);
 /* ... and the gradient tensors the losses scatter into (zero outside the minibatch's rows users[b], U + pos[b], U + neg[b]: Model.py:84-134's
  * outputs indexed by ancs / poss / negs, Main.py:318-352) get their bf16 copies by casting just those rows of up to 4 [N, D] tensors; src == NULL or
  * src[t] == NULL writes zeros (clearing the rows again after use keeps the copy zero elsewhere).  D % 8 == 0, 256 % (D / 8) == 0. */
+/* the same rows of up to 8 tensors cleared, row_bytes[t] bytes per row (multiples of 16): fp32 and bf16 tensors in one launch */
+int dmm_zero_batch_rows(void* const* dst /*host*/, const int32_t* row_bytes /*host*/, int n_t, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                        int B, int U, void* stream);
 int dmm_cast_batch_rows_bf16(const float* const* src /*host array or NULL*/, void* const* dst /*host array of n_t bf16 [N, D]*/, int n_t, int D,
                              const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int U, void* stream);
 

@@ -113,9 +113,13 @@ def test_joint_step_with_bf16_gather_operands(dev, fx, cl_method, nd):
         adj = graph.make_adjacency(z["trn_rows"], z["trn_cols"], U, I, D, dev, vec=vec)
         madj = [graph.make_adjacency(z[f"m{m}_rows"], z[f"m{m}_cols"], U, I, D, dev, vec=vec) for m in range(M)]
         E.set_adjacency(adj, madj)
+        # a first step on OTHER rows: the bf16-operand step clears its scatter targets row by row, so whatever it leaves behind would show below
+        E.step(users.flip(0).roll(7) % U, (pos + 3) % I, (neg + 5) % I, noise=noise, precision=3, update=False)
         E.step(users, pos, neg, noise=noise, precision=3, update=False)
         res.append((E.losses(), {k: v.clone() for k, v in E.full_grads().items()}, {k: v.clone() for k, v in E.gcn_output().items()}))
         assert (E._x16() is not None) == (vec == 8)
+        if vec == 8:
+            assert float(E.gblock[:3].abs().max()) == 0.0 and float(E._x16()["g"][:2].float().abs().max()) == 0.0, "scatter targets left clean"
     (l4, g4, o4), (l8, g8, o8) = res
     for k in ("bpr", "reg", "cl", "loss"):
         close(l8[k], l4[k], rtol=2e-3, what=k)

@@ -1222,3 +1222,14 @@ def test_bf16_gather_copies_written_by_their_producers(dev):
     ops.cast_batch_rows_bf16(None, dst, users, pos, neg, U)
     for d_ in dst:
         assert bool((d_[touched] == 0).all()) and bool((d_[~touched] == 7.0).all())
+    # dmm_zero_batch_rows: fp32 and bf16 tensors in one launch
+    mixed = [torch.full((N, D), 3.0, device=dev), torch.full((N, D), 3.0, dtype=torch.bfloat16, device=dev), torch.full((N, D), 3.0, device=dev)]
+    ops.zero_batch_rows(mixed, users, pos, neg, U)
+    for d_ in mixed:
+        assert bool((d_[touched] == 0).all()) and bool((d_[~touched] == 3.0).all())
+    # dz_overwrite: dz_m = maw w_m dmx whatever dz held
+    junk = [torch.full((N, D), 9.0, device=dev) for _ in range(M)]
+    ops.gcn_mix_bwd(dmx, bx, z, junk, extra, w, 0.2, dbx16=dbx16, dz16=dz16, dz_overwrite=True)
+    zero = [torch.zeros(N, D, device=dev) for _ in range(M)]
+    ops.gcn_mix_bwd(dmx, bx, z, zero, extra, w, 0.2)
+    assert all(torch.equal(a, b) for a, b in zip(junk, zero)) and all(torch.equal(h, cast(f)) for h, f in zip(dz16, zero))

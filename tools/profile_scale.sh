@@ -6,5 +6,5 @@ timeout -k 10 800 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 S=$(find /tmp/prof_scale -name "scale_kernel_stats.csv" | head -1)
 cp $S $O/scale_kernel_stats.csv
 T=$(find /tmp/prof_scale -name "scale_kernel_trace.csv" | head -1)
-python3 tools/trace_phases.py $T 1000 45 > $O/phases.txt 2>&1
+python3 tools/trace_phases.py $T 1000 45 > $O/phases.txt 2>&1; python3 tools/trace_gaps.py $T > $O/gaps.txt 2>&1
 tail -2 $O/scale.log | cut -c1-600; head -70 $O/phases.txt
