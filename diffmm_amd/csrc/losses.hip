@@ -663,7 +663,11 @@ constexpr int INB_MAX_B = 8192;  // the term's lse vector (4 B per batch row) si
 template <int D, int PREC>
 static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat, int pass_base = 0) {
   // walk splits per (term, pass): 1 / 2 / 4 / 8 measured 123.5 / 117.6 / 113.8 / ~125 us at B = 4096, 8 terms (more waves per SIMD against more atomics)
-  static const int ksplit = [] { const char* e = getenv("DMM_INFONCE_LDS_KSPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  // (B = 8192, d = 256, 8 terms, where the launch has 1024 workgroups without any split: 1 / 2 / 4 / 8 -> 2277 / 2315 / 2395 / 2558 us: the split is
+  // sized to about 1024 workgroups per launch)
+  static const int forced = [] { const char* e = getenv("DMM_INFONCE_LDS_KSPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
+  const int wgs = (int)(grid.x * grid.y * grid.z);
+  const int ksplit = forced ? forced : (wgs >= 1024 ? 1 : (wgs > 512 ? 2 : 4));  // (grid = [B / 128, terms, 2 passes]: 512 at the bench shape)
   grid.z *= ksplit;
   static const bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
