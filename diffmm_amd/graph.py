@@ -8,6 +8,7 @@ pointers / column ids, fp32 values) plus the task list the HIP SpMM kernel consu
 from __future__ import annotations
 
 import itertools
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -170,7 +171,7 @@ def check_plan(rowptr: np.ndarray, tasks: np.ndarray, D: int) -> None:
 
 
 _adjacency_uid = itertools.count(1)
-TASK_LEN = int(__import__("os").environ.get("DMM_TASK_LEN", "16"))  # non-zeros per SpMM task (DMM_TASK_LEN: tuning knob).  At TikTok size the joint
+TASK_LEN = int(os.environ.get("DMM_TASK_LEN", "16"))  # non-zeros per SpMM task (DMM_TASK_LEN: tuning knob).  At TikTok size the joint
 # iteration takes 15.9 / 15.8 / 16.0 / 16.5 / 16.9 ms per epoch at 8 / 12 / 16 / 24 / 32: shorter tasks = more waves to hide the gather latency
 
 
@@ -217,7 +218,7 @@ def spmm_operand_vec(n_rows: int, D: int) -> int:
     epilogue operands and outputs), 4 = fp32.  bf16 gathers pay where the kernel is bound by the bytes that miss the caches: DMM_SPMM_BF16=auto
     (default) switches at an fp32 operand of >= 256 MiB (the Infinity Cache; 1M users x 100k items at d = 256: 1.83 -> 0.99 ms per
     SpMM, profiles/README.md) and never at the shipped datasets' sizes, where the launch is latency-bound; =1 / =0 force it."""
-    env = __import__("os").environ.get("DMM_SPMM_BF16", "auto")
+    env = os.environ.get("DMM_SPMM_BF16", "auto")
     if env in ("0", "1"):
         return 8 if env == "1" and D >= 16 else 4
     return 8 if D >= 16 and n_rows * D * 4 >= (1 << 28) else 4
@@ -227,7 +228,7 @@ def spmm_task_len(vec: int) -> int:
     """Non-zeros per SpMM task: TASK_LEN (16: the latency-bound launches of the shipped datasets' sizes), 64 on the graphs planned for bf16
     gather operands (vec = 8, i.e. operands beyond the caches): at 1M users x 100k items, d = 256 that cuts the rows longer than one workgroup's
     share ("giant" rows: partial sums + fix-up launch) from 14341 to 686 (SpMM 981 -> 968 us, the fix-up launch 197 -> 30 us)."""
-    return TASK_LEN if vec == 4 or "DMM_TASK_LEN" in __import__("os").environ else 64
+    return TASK_LEN if vec == 4 or "DMM_TASK_LEN" in os.environ else 64
 
 
 def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
