@@ -866,7 +866,11 @@ class DiffusionEngine:
                 ops.transpose_cast_bf16(self.P[m].view(self.L2 + ".weight"), W[m]["w2T16"], rows=I, cols=self.H)  # W2^T [H, I -> Kp]
                 self._FT32[m][:, :I].copy_(feats[m].t())
                 ops.gemv_rows(self._FT32[m], self.P[m].view(self.L2 + ".bias"), self._b2F[m], cols=I)
-            ops.item_project_batched_x16([dict(X=W[m]["w2T16"], F=feats[m], out=self._G2f[m], K=I) for m in range(M)], self.D)
+            if self.D <= 128:
+                ops.item_project_batched_x16([dict(X=W[m]["w2T16"], F=feats[m], out=self._G2f[m], K=I) for m in range(M)], self.D)
+            else:  # d = 256: 64-row workgroups re-stage the [K, 256] operand too often (1.68 ms against 0.76 ms on the K-split generic GEMM at 100k items)
+                ops.gemm_batched([dict(A=feats[m], B=self.P[m].view(self.L2 + ".weight"), out=self._G2f[m], trans_a=True, precision=1, K=I, split_k=32)
+                                  for m in range(M)])
             ops.cast_bf16(self._G2f.view(-1, self.H), self._G2_16.view(-1, self.H))
             ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self._G2_16[m], out=self.act[m]["um"][:B], bias=self._b2F[m]) for m in range(M)])
         for m in range(M):
@@ -944,8 +948,12 @@ class DiffusionEngine:
             # modalities (the same product as a K-sliced generic GEMM: 84 us; as the bf16 NT kernel: 130 us on 48 workgroups), then one cast
             self._folded_prepare()
             ops.zero_(self._Gf)
-            ops.item_project_batched([dict(X=self.P[m].view("in_layers.0.weight"), F=feats[m], out=self._Gf[m], K=I) for m in range(M)], D,
-                                     out_transposed=True)
+            if D <= 128:
+                ops.item_project_batched([dict(X=self.P[m].view("in_layers.0.weight"), F=feats[m], out=self._Gf[m], K=I) for m in range(M)], D,
+                                         out_transposed=True)
+            else:  # (d = 256: see the forward's F^T W2)
+                ops.gemm_batched([dict(A=feats[m], B=self.P[m].view("in_layers.0.weight"), out=self._Gf[m], trans_a=True, trans_b=True, precision=1, K=I,
+                                       split_k=32) for m in range(M)])
             ops.cast_bf16(self._Gf.view(-1, H), self._G16.view(-1, H))
             ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=self._G1[m], out=W[m]["dpg"][:B]) for m in range(M)])
             for m in range(M):
