@@ -276,7 +276,9 @@ class Coach:
         u0 = lay.u0 if lay is not None else 0
         uf, itf = J.Fin[:nu], J.Fin[nu:]
         td, k = h.testData, int(self.config.base.topk)
-        tb = int(self.config.train.test_batch)
+        # the reference ranks test_batch users at a time (Main.py:396-411); the metrics are per-user sums, so the batch size only sets how many launches
+        # the evaluation takes: up to 8192 users per launch here (score buffer <= 2 GiB) -- 37 host-paced rounds -> 2 at TikTok shape
+        tb = max(int(self.config.train.test_batch), min(8192, max(1, (1 << 29) // max(1, J.I))))
         users_all, u32_all = td._users_d, td._users_i32
         if lay is not None:
             keep = (users_all >= lay.u0) & (users_all < lay.u1)
