@@ -201,6 +201,7 @@ class Coach:
         feats = [J.feat[m] for m in range(M)]
         reg_term = DE.reg_term(J.i_embs)  # i_embs does not move in this phase either
         dl = [0.0] * M
+        step_means = []
         diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
         for idx in diff_batches:
             own = idx if lay is None else idx[(idx >= lay.u0) & (idx < lay.u1)]
@@ -211,9 +212,14 @@ class Coach:
                 for m in range(M):
                     t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
                     noise.append(draws.randn((x0.shape[0], int(cfg.data.item_num))).to(dev))
-            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]))
+            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]),
+                                  host_means=prec != 1)
+            step_means.append(means)
+        if step_means and isinstance(step_means[0], torch.Tensor):  # bf16 mode: the steps left their means on the device -- one read for the whole phase
+            step_means = torch.stack(step_means).tolist()
+        for means in step_means:  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
             tot = sum(means)
-            for m in range(M):  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
+            for m in range(M):
                 dl[m] += means[m]
             for m in range(M):
                 dl[m] /= tot

@@ -54,7 +54,8 @@ class ProjectProblem(C.Structure):
 class ExpandFusedArgs(C.Structure):
     _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("F", C.c_void_p), ("ldf", C.c_int64), ("R", C.c_void_p), ("ldr", C.c_int64), ("X0", C.c_void_p),
                 ("ldx0", C.c_int64), ("w", C.c_void_p), ("gscale", C.c_double), ("Y16", C.c_void_p), ("ldy", C.c_int64), ("YT", C.c_void_p), ("ldt", C.c_int64),
-                ("csum", C.c_void_p), ("B", C.c_int32), ("I", C.c_int32), ("Kc", C.c_int32), ("Kt", C.c_int32), ("X0bits", C.c_void_p), ("ldbits", C.c_int64)]
+                ("csum", C.c_void_p), ("B", C.c_int32), ("I", C.c_int32), ("Kc", C.c_int32), ("Kt", C.c_int32), ("X0bits", C.c_void_p), ("ldbits", C.c_int64),
+                ("gscale_dev", C.c_void_p)]
 
 
 class RownormBwdProblem(C.Structure):
@@ -130,7 +131,7 @@ _SIGS = {
     "dmm_add_inplace": (C.c_int, [_P, _P, _F, _L, _P]),
     "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dmm_colsum_add": (C.c_int, [_P, _L, _I, _I, _P, _P]),
-    "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P]),
+    "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P, _P]),
     "dmm_diff_loss_bits": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _P, _P]),
     "dmm_csr_row_bits": (C.c_int, [_P, _P, _P, _I, _I, _P, _L, _P]),
     "dmm_qsample_temb_bits": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),

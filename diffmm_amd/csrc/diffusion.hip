@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict_
                                                          const double* __restrict__ w, const float* __restrict__ um,
                                                          const float* __restrict__ ui, int I, int d, float sim_weight, double reg_term,
                                                          double gscale, double* __restrict__ loss, float* __restrict__ dout,
-                                                         float* __restrict__ dum, const uint32_t* __restrict__ bits, long long ldb) {
+                                                         float* __restrict__ dum, const uint32_t* __restrict__ bits, long long ldb,
+                                                         const double* __restrict__ gs_dev) {
+  if (gs_dev) gscale *= *gs_dev;  // a factor of the gradient scale that only exists on the device (1 / sum of the minibatch's losses)
   __shared__ double smd[4];
   __shared__ float smf[4];
   const int b = blockIdx.x;
@@ -1035,10 +1037,11 @@ extern "C" int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, i
 }
 
 extern "C" int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w, const float* um, const float* ui, int B, int I, int d,
-                             float sim_weight, double reg_term, double gscale, double* loss, float* dout, float* dum, void* stream) {
+                             float sim_weight, double reg_term, double gscale, double* loss, float* dout, float* dum, const double* gscale_dev,
+                             void* stream) {
   DMM_CHECK_ARG(out && x0 && w && um && ui && (loss || dum) && B > 0 && I > 0 && d > 0, "dmm_diff_loss: bad arguments");
   hipLaunchKernelGGL(diff_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, x0, (long long)ld, w, um, ui, I, d, sim_weight, reg_term,
-                     gscale, loss, dout, dum, (const uint32_t*)nullptr, 0ll);
+                     gscale, loss, dout, dum, (const uint32_t*)nullptr, 0ll, gscale_dev);
   DMM_LAUNCH_CHECK("dmm_diff_loss");
   return 0;
 }
@@ -1047,7 +1050,7 @@ extern "C" int dmm_diff_loss_bits(const float* out, int64_t ld, const uint32_t* 
                                   int I, int d, float sim_weight, double reg_term, double* loss, void* stream) {
   DMM_CHECK_ARG(out && x0bits && w && um && ui && loss && B > 0 && I > 0 && d > 0 && ldb * 32 >= I, "dmm_diff_loss_bits: bad arguments");
   hipLaunchKernelGGL(diff_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, (const float*)nullptr, (long long)ld, w, um, ui, I, d, sim_weight,
-                     reg_term, 0.0, loss, (float*)nullptr, (float*)nullptr, x0bits, (long long)ldb);
+                     reg_term, 0.0, loss, (float*)nullptr, (float*)nullptr, x0bits, (long long)ldb, (const double*)nullptr);
   DMM_LAUNCH_CHECK("dmm_diff_loss_bits");
   return 0;
 }

@@ -304,6 +304,7 @@ struct ExpandFusedP {
   const float* X0; long long ldx0;  // MODE 1: x_0 rows (dense) ...
   const uint32_t* X0b; long long ldb;  // ... or as bit masks (used when X0 is NULL)
   const double* w; double gscale;   // MODE 1: per-row loss weights
+  const double* gs_dev;             // MODE 1: optional device-side factor of gscale
   __bf16* Y16; long long ldy;       // [B, >= Kc]
   __bf16* YT; long long ldt;        // [Kt, >= Bp]
   float* csum;                      // MODE 1: [I]
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, (D > 128 ? 3 : 1)) void item_expand_fused_kern
     rofs[rt] = (long long)rc;
     gc[rt] = 0.f;
     if (LOSS) {
-      const float g = (float)(A.gscale * A.w[rc] * 2.0 / (double)I);
+      const float g = (float)(A.gscale * (A.gs_dev ? *A.gs_dev : 1.0) * A.w[rc] * 2.0 / (double)I);
       gc[rt] = row < B ? g : 0.f;
     }
   }
@@ -566,7 +567,7 @@ extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, i
                     (((uintptr_t)a->P | (uintptr_t)a->F | (uintptr_t)a->R | (uintptr_t)a->X0 | (uintptr_t)a->YT) & 15) == 0 && ((uintptr_t)a->Y16 & 7) == 0,
                 "dmm_item_expand_fused: operands must be 16-byte aligned (Y16: 8) with leading dimensions that are multiples of 4 (YT: of 8, >= round_up(B, 64))");
   ExpandFusedP p;
-  p.P = a->P; p.ldp = a->ldp; p.F = a->F; p.ldf = a->ldf; p.R = a->R; p.ldr = a->ldr; p.X0 = a->X0; p.ldx0 = a->ldx0; p.X0b = a->X0bits; p.ldb = a->ldbits; p.w = a->w; p.gscale = a->gscale;
+  p.P = a->P; p.ldp = a->ldp; p.F = a->F; p.ldf = a->ldf; p.R = a->R; p.ldr = a->ldr; p.X0 = a->X0; p.ldx0 = a->ldx0; p.X0b = a->X0bits; p.ldb = a->ldbits; p.w = a->w; p.gscale = a->gscale; p.gs_dev = a->gscale_dev;
   p.Y16 = (__bf16*)a->Y16; p.ldy = a->ldy; p.YT = (__bf16*)a->YT; p.ldt = a->ldt; p.csum = a->csum; p.B = a->B; p.I = a->I; p.Kc = a->Kc; p.Kt = a->Kt;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((a->Kc + 255) / 256, Bp / 64);

@@ -896,7 +896,7 @@ class DiffusionEngine:
             else:
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
 
-    def _backward_batched(self, x0p: Tensor, feats, reg_term: float, gscale: float):
+    def _backward_batched(self, x0p: Tensor, feats, reg_term: float, gscale: float, gs_dev: Optional[Tensor] = None):
         B, I, H, D, Kp, M = x0p.shape[0], self.I, self.H, self.D, self.Kp, self.M
         W = self._workspaces()
         Bp = (B + 63) & ~63
@@ -909,12 +909,13 @@ class DiffusionEngine:
             if self._fused_expand():
                 # dout = d loss / d out (MSE part) + dum F^T is never written in fp32: one kernel forms it and emits dout (bf16), dout^T (bf16)
                 # and its column sums (the output bias gradient, into the zeroed vector)
-                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, None, None, w["dum"][:B])
+                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, None, None, w["dum"][:B],
+                              gscale_dev=gs_dev)
                 ops.item_expand_fused(w["dum"][:B], feats[m], a["out"][:B], w["xb16"][:B], w["doutT16"], I, self.Kp, I, w=a["w"], gscale=gscale,
-                                      csum=P.g(self.L2 + ".bias"), **(dict(x0bits=self._x0_bits[:B]) if self._x0_bits is not None else dict(x0=x0p)))
+                                      gscale_dev=gs_dev, csum=P.g(self.L2 + ".bias"), **(dict(x0bits=self._x0_bits[:B]) if self._x0_bits is not None else dict(x0=x0p)))
             else:
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
-                              w["dum"][:B])
+                              w["dum"][:B], gscale_dev=gs_dev)
                 if self._item_kernels(1):
                     ops.item_expand(w["dum"][:B], feats[m], w["dout"][:B], w["dout"][:B], I)                                    # dout += dum F^T
                 else:
@@ -986,10 +987,12 @@ class DiffusionEngine:
 
     def train_step(self, x0: Tensor, feats: Sequence[Tensor], i_embs: Tensor, t: Optional[Sequence[Tensor]] = None,
                    noise: Optional[Sequence[Tensor]] = None, precision: int = 3, update: bool = True, reg_term: Optional[float] = None,
-                   global_rows: Optional[int] = None) -> List[float]:
+                   global_rows: Optional[int] = None, host_means: bool = True):
         """One iteration of Main.py:145-192 over all modalities.  `feats` are the projected, detached modality features.
         User-sharded (shard_world > 1): x0 holds only the minibatch rows of the users this replica owns (possibly none) and
-        `global_rows` is the size of the whole minibatch; the per-modality loss means and the gradients are summed over the replicas."""
+        `global_rows` is the size of the whole minibatch; the per-modality loss means and the gradients are summed over the replicas.
+        Returns the modalities' loss means as floats -- or, with host_means = False (bf16 mode), as a float64 device tensor: the backward's
+        scale 1 / (minibatch size x sum of the means) (Main.py:176) then reaches the kernels as a device scalar and the step reads nothing back."""
         B, M = x0.shape[0], self.M
         Bg = int(global_rows) if global_rows is not None else B
         if reg_term is None:
@@ -1020,6 +1023,18 @@ class DiffusionEngine:
         if self.shard_world > 1:
             import torch.distributed as dist
             dist.all_reduce(sums, group=self.shard_group)
+        if not host_means and precision == 1:
+            means = sums / Bg
+            if B:  # 1 / (Bg * sum(means)) = 1 / sum(sums)
+                self._backward_batched(x0p, feats, reg_term, 1.0, gs_dev=torch.reciprocal(sums.sum()).reshape(1))
+            else:
+                for m in range(M):
+                    ops.zero_(self.P[m].grad)
+            if update:
+                for m in range(M):
+                    self.reduce_and_step(m)
+            self.rng_step += 1
+            return means
         means = (sums / Bg).tolist()  # ONE host read per iteration (the reference syncs per modality: .item(), Main.py:155,159,172)
         total = sum(means)
         if B:

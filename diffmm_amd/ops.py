@@ -649,16 +649,23 @@ def colsum(x: Tensor, rows: int, cols: int, out: Tensor, add: bool = False) -> N
     L.call("dmm_colsum_add" if add else "dmm_colsum", L.ptr(x), x.stride(0), rows, cols, L.ptr(out), L.stream())
 
 
+def _gs_dev(t: Optional[Tensor]):
+    if t is not None and (t.dtype != torch.float64 or t.numel() != 1):
+        raise ValueError("gscale_dev: a one-element float64 device tensor")
+    return L.ptr(t)
+
+
 def diff_loss(out: Tensor, x0: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, gscale: float,
-              loss: Optional[Tensor], dout: Optional[Tensor], dum: Optional[Tensor]) -> None:
-    """loss None and dout None: only dum (the gradient through the similarity term) is computed; the [B, I] rows are not read."""
+              loss: Optional[Tensor], dout: Optional[Tensor], dum: Optional[Tensor], gscale_dev: Optional[Tensor] = None) -> None:
+    """loss None and dout None: only dum (the gradient through the similarity term) is computed; the [B, I] rows are not read.
+    gscale_dev: a float64 device scalar multiplied into gscale (no host read of the minibatch's loss total)."""
     B, d = um.shape
     if out.stride(0) != x0.stride(0) or (dout is not None and dout.stride(0) != out.stride(0)):
         raise ValueError("diff_loss: out, x0 and dout must share one leading dimension")
     if w.dtype != torch.float64 or (loss is not None and loss.dtype != torch.float64):
         raise ValueError("diff_loss: w and loss are float64")
     L.call("dmm_diff_loss", L.ptr(out), L.ptr(x0), out.stride(0), L.ptr(w), L.ptr(um), L.ptr(ui), B, I, d, sim_weight, reg_term, gscale,
-                                  L.ptr(loss), L.ptr(dout), L.ptr(dum), L.stream())
+                                  L.ptr(loss), L.ptr(dout), L.ptr(dum), _gs_dev(gscale_dev), L.stream())
 
 
 def topk_rows(x: Tensor, row_ids: Tensor, out_ptr: Tensor, out_idx: Tensor, cols: int) -> None:
@@ -744,7 +751,8 @@ def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:
 
 
 def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, I: int, Kc: int, Kt: int, x0: Optional[Tensor] = None,
-                      w: Optional[Tensor] = None, gscale: float = 0.0, csum: Optional[Tensor] = None, x0bits: Optional[Tensor] = None) -> None:
+                      w: Optional[Tensor] = None, gscale: float = 0.0, csum: Optional[Tensor] = None, x0bits: Optional[Tensor] = None,
+                      gscale_dev: Optional[Tensor] = None) -> None:
     """item_expand whose result goes straight into the bf16 operands of the next GEMMs (Y16 [B, Kc] row-major, YT [Kt, round_up(B, 64)]
     transposed).  x0 / w / csum given: the loss-gradient form v = gscale w[b] 2/I (R - x0) + P F^T with its column sums added to csum."""
     B, D = P.shape[0], P.shape[1]
@@ -763,6 +771,7 @@ def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, 
         if w.dtype != torch.float64 or csum is None or csum.numel() < I:
             raise ValueError("item_expand_fused: w is float64 [B], csum fp32 [I]")
         a.w, a.gscale, a.csum = L.ptr(w), float(gscale), L.ptr(_f32c(csum, "csum"))
+        a.gscale_dev = _gs_dev(gscale_dev)
         if x0 is not None:
             a.X0, a.ldx0 = L.ptr(x0), x0.stride(0)
         else:  # x_0 as bit masks (csr_row_bits)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 212
+#define DMM_VERSION 213
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -358,7 +358,9 @@ int dmm_colsum_add(const float* x, int64_t ldx, int rows, int cols, float* out /
  * loss == NULL and dout == NULL: only d loss / d um (the [B, I] rows are not read; dmm_item_expand_fused mode 1 forms d loss / d out). */
 int dmm_diff_loss(const float* out, const float* x0, int64_t ld, const double* w /*[B]*/, const float* um,
                   const float* ui, int B, int I, int d, float sim_weight, double reg_term, double gscale,
-                  double* loss /*[B] or NULL*/, float* dout /*[B,ld] or NULL*/, float* dum /*[B,d] or NULL*/, void* stream);
+                  double* loss /*[B] or NULL*/, float* dout /*[B,ld] or NULL*/, float* dum /*[B,d] or NULL*/,
+                  const double* gscale_dev /*NULL, or a device scalar multiplied into gscale: Main.py:176 divides every modality's loss by the minibatch's
+                                             loss total before backward -- with it the step needs no host read of that total*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Rebuild: per-row top-k with k = the user's degree (Main.py:224-230).  One workgroup per row; writes the k
@@ -398,6 +400,7 @@ typedef struct dmm_expand_fused_args {
   float* csum;                   /* mode 1: [I], accumulated into */
   int32_t B, I, Kc, Kt;
   const uint32_t* X0bits; int64_t ldbits; /* mode 1, X0 == NULL: x_0 as bit masks (dmm_csr_row_bits), ldbits words per row */
+  const double* gscale_dev;               /* mode 1: NULL, or a device scalar multiplied into gscale (see dmm_diff_loss) */
 } dmm_expand_fused_args;
 int dmm_item_expand_fused(const dmm_expand_fused_args* a /*host*/, int mode, int D, void* stream);
 /* The same product for up to 4 problems in one launch, 64 rows per workgroup (many short rows), with the layouts of the joint step's

@@ -702,6 +702,33 @@ def test_train_step_batched_bf16_matches_split_precision(dev, D):
             assert cos > 0.999, f"modality {m} grad {k}: cosine {cos:.5f}"
 
 
+def test_train_step_device_side_gradient_scale(dev):
+    """train_step(host_means=False): the backward's scale 1 / (minibatch x sum of the loss means) (Main.py:176) reaches the kernels as a device scalar
+    and the means come back as a device tensor -- same means and same gradients as the step that reads the means back first."""
+    from diffmm_amd.engine import DiffusionEngine
+    torch.manual_seed(9)
+    items, D, H, M, T_, B = 1500, 64, 1024, 3, 20, 700
+    hp = dict(noise_scale=0.1, noise_min=0.0001, noise_max=0.02, sim_weight=0.1, reg=1e-5, lr=1e-3, seed=11)
+    E = DiffusionEngine(items, D, H, 10, M, T_, hp, dev, B)
+    for m in range(M):
+        E.P[m].data.normal_(0, 0.02)
+        E.P[m].view("in_layers.0.weight")[:, items + 10:].zero_()
+    x0 = (torch.rand(B, items, device=dev) < 0.004).float()
+    feats = [torch.nn.functional.normalize(torch.randn(items, D, device=dev)) for _ in range(M)]
+    ie = torch.randn(items, D, device=dev) * 0.1
+    t = [torch.randint(0, T_, (B,), device=dev, dtype=torch.int32) for _ in range(M)]
+    noise = [torch.randn(B, items, device=dev) for _ in range(M)]
+    host = E.train_step(x0, feats, ie, t=t, noise=noise, precision=1, update=False)
+    g_host = [E.P[m].grad.clone() for m in range(M)]
+    devm = E.train_step(x0, feats, ie, t=t, noise=noise, precision=1, update=False, host_means=False)
+    assert isinstance(devm, torch.Tensor) and devm.dtype == torch.float64
+    close(devm, np.asarray(host), rtol=1e-4, what="loss means")  # (two forwards of the bf16 step differ by the order of their K-slice atomics: ~2e-6)
+    for m in range(M):
+        scale = float(g_host[m].abs().max())
+        assert float((E.P[m].grad - g_host[m]).abs().max()) <= 1e-3 * scale, f"modality {m}: gradients with the device-side scale"  # (two runs of the bf16 step differ by atomics order: 1e-4)
+
+
+
 @pytest.mark.parametrize("B,I,D", [(300, 700, 64), (4096, 6710, 64), (1116, 2531, 128), (700, 1900, 256)])
 def test_item_project_and_expand(dev, B, I, D):
     """csrc/itemspace.hip against fp64 products of the bf16-rounded operands (only the fp32 summation order differs)."""
