@@ -3,9 +3,10 @@
 
 The three phases of an epoch (diffusion training, reverse-chain rebuild of the modality graphs, joint BPR +
 contrastive training) run on diffmm_amd.engine (HIP kernels only); with several GPUs on diffmm_amd.sharded (users sharded over
-the replicas, one process per GPU).  Host synchronisation points per epoch: one per
-diffusion iteration (the loss normalisation needs host values, as in the reference), one per modality for the
-rebuilt edge list, one at the end of the joint phase for the logged losses.
+the replicas, one process per GPU).  Host synchronisation points per epoch: one per diffusion PHASE in bf16 mode (the steps leave
+their loss means on the device; the loss normalisation of Main.py:175-176 reaches the backward kernels as a device scalar -- the ~fp32
+parity mode reads the means back per iteration, as the reference does), one per rebuilt graph set (which also reads the reverse chain's
+error word, before the graphs are used), one at the end of the joint phase for the logged losses.
 """
 from __future__ import annotations
 
@@ -118,11 +119,16 @@ class Coach:
                     _log(self.makePrint("Test", epoch, result))
                 if save:
                     self.save_checkpoint(save)
-                best, his_max = self.best, self.his_max
-                _log(f"Current best: Epoch: {best['epoch']}, Recall: {best['Recall']:.5f}({his_max[0]:.5f}), NDCG: {best['NDCG']:.5f}"
-                     f"({his_max[1]:.5f}), Precision: {best['Precision']:.5f}({his_max[2]:.5f})")
+                _log("Current best: " + self._best_line())
+            _log("Best epoch: " + self._best_line(prefix=""))  # the reference's closing line (Main.py:80)
         except KeyboardInterrupt:
             _log("Training interrupted by user!")
+            _log("Current best: " + self._best_line())
+
+    def _best_line(self, prefix: str = "Epoch: ") -> str:
+        best, his_max = self.best, self.his_max
+        return (f"{prefix}{best['epoch']}, Recall: {best['Recall']:.5f}({his_max[0]:.5f}), NDCG: {best['NDCG']:.5f}({his_max[1]:.5f}), "
+                f"Precision: {best['Precision']:.5f}({his_max[2]:.5f})")
 
     # -- checkpoint / resume (absent in the reference) ----------------------------------------------------------------
     def _flat_models(self):
@@ -241,7 +247,8 @@ class Coach:
                     self._own_local = torch.arange(lay.nu, device=dev)
                 edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [self._own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
                                          sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0))
-            adjs = self.graph_builder.build_all(edges)
+            adjs = self.graph_builder.build_all(edges)  # (reads the graphs' sizes back: the host is synchronised here)
+            DE.check_chain_error()  # a timed-out group barrier of dmm_latent_chain invalidates these graphs: raise BEFORE any Adam step uses them
         else:
             adjs = list(modal_adj_override)
         self.image_adj, self.text_adj = adjs[0], adjs[1]
@@ -260,7 +267,8 @@ class Coach:
             dist.all_reduce(acc[nT + 1:nT + 2], group=self.group)
             acc = torch.cat([acc[:nT + 1], acc[nT + 1:nT + 2] + acc[nT + 2:nT + 3]])
         a = acc.cpu().numpy()
-        DE.check_chain_error()  # (the host has just synchronised: one more word) a timed-out group barrier of dmm_latent_chain invalidates the epoch
+        if lay is not None:
+            self.check_replicas()
         self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]
         cl, bpr, reg = float(a[:nT].sum()), float(a[nT]), float(a[nT + 1])
         result = {"Loss": (bpr + reg + cl) / train_steps, "BPR Loss": bpr / train_steps, "reg loss": reg / train_steps, "CL loss": cl / train_steps}
@@ -268,6 +276,23 @@ class Coach:
             result[f"{n} loss"] = dl[m] / diffusion_steps
         self.epoch_idx += 1
         return result
+
+    def check_replicas(self) -> None:
+        """User-sharded runs: the replicated parameters (item embeddings, projections, modal_weight, every Denoise) and their Adam state
+        must be bit-identical on all replicas -- they only ever receive all-reduced gradients (sharded.py).  One pass over them per epoch:
+        a 64-bit sum of their bit patterns, MIN and MAX over the replicas must agree.  A mismatch raises on every replica."""
+        import torch.distributed as dist
+        J, DE = self.model.engine, self.diff_engine
+        lo = J.nu * J.D
+        parts = [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t for p in DE.P for t in (p.data, p.m, p.v)]
+        sums = torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in parts])
+        mn, mx = sums.clone(), sums.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        if not bool((mn == mx).all()):
+            bad = (mn != mx).nonzero().flatten().tolist()
+            raise RuntimeError(f"user-sharded run: replicated state differs between the replicas (checksum groups {bad}; 0-2 = joint model data/m/v, "
+                               f"then data/m/v per Denoise) at epoch {self.epoch_idx}")
 
     # ---------------------------------------------------------------------------------------------
     def testEpoch(self) -> Dict[str, float]:
@@ -347,19 +372,18 @@ def main(argv=None) -> None:
         print(f"Error loading configuration file: {e}")
         raise SystemExit(1)
     seed_it(config.base.seed)
-    from .Utils.Log import Log
-    main_log = Log("main", config.data.name)
-    main_log.info("Start")
-    for section, options in vars(config).items():
-        main_log.info(f"{section}: {options}")
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    if rank == 0:  # one log file and one console copy per run, whatever the number of replicas
+        from .Utils.Log import Log
+        main_log = Log("main", config.data.name)
+        main_log.info("Start")
+        for section, options in vars(config).items():
+            main_log.info(f"{section}: {options}")
     if world > 1:  # python -m torch.distributed.run --nproc-per-node N -m diffmm_amd.Main -c ...: one process per GPU, users sharded
         import torch.distributed as dist
         config.base.gpu = str(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
         torch.cuda.set_device(int(config.base.gpu))
         dist.init_process_group(os.environ.get("DMM_BACKEND", "nccl"))
-        if rank != 0:
-            main_log = None  # one log
     handler = DataHandler(config)
     _log("Load Data")
     handler.LoadData()

@@ -86,6 +86,7 @@ _SIGS = {
     "dmm_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmBf16Args), _P]),
     "dmm_gemm_bf16_nt_batched": (C.c_int, [C.POINTER(GemmBf16Args), _I, _P]),
     "dmm_latent_chain": (C.c_int, [C.POINTER(LatentChainArgs), _I, _I, _I, _I, _P, C.c_float, _P, _I, _P]),
+    "dmm_latent_chain_supported": (C.c_int, [_I]),
     "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_transpose_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_cast_bf16_split": (C.c_int, [_P, _L, _P, _P, _L, _I, _I, _I, _P]),

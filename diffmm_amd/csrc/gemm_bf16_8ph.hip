@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "gemm_bf16.h"
 
@@ -657,22 +658,43 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
   }
 }
 
-int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
+static void latent_chain_attrs() {
   static bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     return true;
   }();
   (void)once;
+}
+
+// CUs the persistent kernel may count on, per device: 0 when a workgroup of it does not fit a CU at all (occupancy query), else the device's CU count
+// (DMM_LATENT_CUS overrides it: a CU-masked or partitioned device the runtime does not describe).
+static int latent_chain_cus() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  static std::atomic<int> cached[64];
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v) return v - 1;
+  latent_chain_attrs();
+  int n = 0, occ = 0;
+  if (const char* e = getenv("DMM_LATENT_CUS")) n = atoi(e);
+  else if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 0) n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(latent_chain_8ph_kernel<true>), 512, P8_LDS) != hipSuccess || occ < 1) n = 0;
+  cached[dev].store(n + 1, std::memory_order_relaxed);
+  return n;
+}
+
+// The group barrier needs all H / 256 member workgroups of the 8 groups of a launch slice co-resident: 8 * H / 256 CUs at least.
+bool latent_chain_supported(int H) { return H >= 256 && H % 256 == 0 && H <= 2048 && latent_chain_cus() >= 8 * (H / 256); }
+
+int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
+  latent_chain_attrs();
   // write-through h' stores and no release fence (default; rebuild 5.57 -> 5.20 ms at the bench shape) or plain stores + agent release (0)
   static const int wt = [] { const char* e = getenv("DMM_LATENT_WT"); return e ? atoi(e) : 1; }();
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
+  const int cus = latent_chain_cus();
   const int nt = base.H / 256;
-  const int per = std::max(8, (cus / nt) & ~7);  // groups per launch: every member workgroup gets a CU of its own
+  if (cus < 8 * nt) return -1;  // the groups of a launch could not all be resident: the caller runs one launch per step instead
+  const int per = (cus / nt) & ~7;  // groups per launch: every member workgroup gets a CU of its own
   const int total = n_mod * base.rbs;
   for (int g0 = 0; g0 < total; g0 += per) {
     LatentBatch b = base;
@@ -737,10 +759,17 @@ extern "C" int dmm_latent_chain(const dmm_latent_chain_args* a, int n_mod, int r
   }
   b.coef = coef; b.flags = flags; b.s_init = s_init; b.rows = rows; b.H = H; b.T = T; b.rbs = (rows + 255) / 256; b.err_at = flags_len - 1;
   const int rc = launch_latent_chain_8ph(b, n_mod, (hipStream_t)stream);
+  if (rc == -1) {
+    dmm::set_error("dmm_latent_chain: this device cannot keep the %d workgroups of a launch slice co-resident (dmm_latent_chain_supported(%d) == 0): "
+                   "run the chain as one dmm_gemm_bf16_nt launch per step", 8 * (H / 256), H);
+    return DMM_ERR_UNSUPPORTED;
+  }
   if (rc) { dmm::set_error("dmm_latent_chain: hipMemsetAsync failed (%d)", rc); return rc; }
   DMM_LAUNCH_CHECK("dmm_latent_chain");
   return 0;
 }
+
+extern "C" int dmm_latent_chain_supported(int H) { return dmm::latent_chain_supported(H) ? 1 : 0; }
 
 #ifdef P8_TIMING
 extern "C" int dmm_debug_p8_stamps(unsigned long long* host, int n) {

@@ -581,6 +581,7 @@ class DiffusionEngine:
         self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
         self._w1T_chain = None  # bf16 W1^T per modality, allocated by the first CSR chain start
+        self._latent_ok: Optional[bool] = None  # dmm_latent_chain_supported(H) on this device, asked once
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
         self._x0_rows, self._ie16 = None, None  # the current training batch as CSR rows (if it came as such); bf16 i_embs for its gather
         self._FT16 = None  # F^T operands of the folded products (_folded_prepare)
@@ -1107,7 +1108,11 @@ class DiffusionEngine:
         """The persistent kernel covers the shipped Denoise shape (one hidden width, a multiple of 256); hp latent_fused / DMM_LATENT_FUSED=0
         forces one launch per step (also the path for k > 1 hidden widths: their mid layers run between the steps)."""
         on = self.hp.get("latent_fused", os.environ.get("DMM_LATENT_FUSED", "1") != "0")
-        return bool(on) and not self.mids and self.H % 256 == 0 and 256 <= self.H <= 2048 and self.T >= 2
+        if not (bool(on) and not self.mids and self.H % 256 == 0 and 256 <= self.H <= 2048 and self.T >= 2):
+            return False
+        if self._latent_ok is None:  # the group barrier needs a launch slice co-resident: not on a device with fewer than 8 H / 256 CUs (CU mask, partition)
+            self._latent_ok = bool(L.lib().dmm_latent_chain_supported(int(self.H)))
+        return self._latent_ok
 
     def check_chain_error(self):
         """Raises if a group barrier of the persistent latent-chain kernel ever timed out (its results would be invalid).  Reads one device

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 213
+#define DMM_VERSION 300
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4
@@ -165,6 +165,10 @@ typedef struct dmm_latent_chain_args {
 } dmm_latent_chain_args;
 int dmm_latent_chain(const dmm_latent_chain_args* a /*host array*/, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
                      int flags_len, void* stream);
+/* 1 when the current device can keep a launch slice of the persistent kernel co-resident (>= 8 * H / 256 CUs, one workgroup of it fits a CU), which
+ * its group barrier needs; 0 otherwise -- dmm_latent_chain then returns DMM_ERR_UNSUPPORTED without launching and the caller runs one
+ * dmm_gemm_bf16_nt launch per step.  (Host query, no stream; DMM_LATENT_CUS=<n> overrides the CU count on a masked / partitioned device.) */
+int dmm_latent_chain_supported(int H);
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
 int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream);

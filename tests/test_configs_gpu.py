@@ -1,6 +1,6 @@
 """BASELINE.json configurations 3 and 4 at their full shapes, live on the GPU (they used to be run by hand only):
-  * config 3 -- Amazon-Baby shape (19445 x 7050, image + text, d = 64, T = 40, conf/baby.toml incl. its noised chain start
-    sampling_step = 5 and the modality-vs-modality contrastive branch cl_method = 1): two epochs;
+  * config 3 -- Amazon-Baby shape (19445 x 7050, image + text, d = 64, T = 40, conf/baby.toml: sampling_step = 0 as the reference's
+    Conf.py would run it, the modality-vs-modality contrastive branch cl_method = 1): two epochs;
   * config 4 -- Sports shape (35598 x 18357, image + text, d = 128, T = 200, batch 8192): one epoch on one GPU, and the same epoch
     user-sharded over two replicas (gloo on this GPU; the 8-GPU RCCL run is the driver's) -- the same minibatches and the same number
     of optimiser steps, so the epoch's losses must agree (the replicas draw their Gaussian / timestep noise from other streams).
@@ -36,7 +36,7 @@ def _check(out, epochs):
 def test_baby_shape_two_epochs():
     need_gpu()
     out = run_config("baby", 64, 40, 4096, 2)
-    assert (out["users"], out["items"], out["M"]) == (19445, 7050, 2) and out["sampling_step"] == 5
+    assert (out["users"], out["items"], out["M"]) == (19445, 7050, 2) and out["sampling_step"] == 0
     _check(out, 2)
     N = out["users"] + out["items"]
     for e in out["epochs"]:
