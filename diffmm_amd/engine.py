@@ -561,15 +561,25 @@ class DiffusionEngine:
         # when the step runs on bit masks), the fp32 loss gradient and d[x'|temb] (fused expand / folded products write neither), the second
         # ping-pong set of the STEPWISE chain (the latent chain has no item-sized state).  At 1M x 100k they are 50 of 149 GiB.
         self._lazy = dict(x0p=_Lazy(lambda: z(B_max, Kp)), dout=_Lazy(lambda: z(B_max, Kp)), dxcat=_Lazy(lambda: z(B_max, Kp)),
-                          cxb=_Lazy(lambda: [z(self.chain_rows, Kp) for _ in range(M)]), w1T16=_Lazy(lambda: zb(Kp, H)))
+                          cxb=_Lazy(lambda: [z(self.dense_rows_max, Kp) for _ in range(M)]), w1T16=_Lazy(lambda: zb(Kp, H)))
         self.ui = z(B_max, D)
         self.dum, self.dpg, self.dgate, self.dproj = z(B_max, D), z(B_max, D), z(B_max, D), z(B_max, D)
         self.dh, self.dpre = z(self.chain_rows, H), z(B_max, H)
         R = self.chain_rows
         zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=self.dev)
+        # Item-sized chain state.  The latent chain (default) has none between its steps: only its LAST step forms [rows, I] views, which the
+        # top-k consumes at once -- so when R rows of them would be large (hp chain_view_bytes / DMM_CHAIN_VIEW_BYTES, 8 GiB over the
+        # modalities) the views are formed `view_rows` rows at a time ("lean": at 1.25M x 1M the full set would be 200 GB) and the bf16
+        # item-sized buffers keep only the training step's B_max rows.  The stepwise chain (chain_mode = "stepwise", the ~fp32 parity
+        # mode) needs the full ping-pong sets and is refused in lean mode.
+        budget = int(self.hp.get("chain_view_bytes", os.environ.get("DMM_CHAIN_VIEW_BYTES", 8 << 30)))
+        self.lean = self._latent_mode() and M * R * Kp * 4 > budget
+        self.view_rows = R if not self.lean else min(R, max(256, budget // (M * Kp * 4) // 256 * 256))
+        self.dense_rows_max = R if not self.lean else B_max  # rows a dense chain start (sampling_step > 0) may bring per launch sequence
         # ping-pong buffers of the reverse chain, one set per modality (the modalities' chains advance together, batched launches)
-        self.cxa = [z(R, Kp) for _ in range(M)]
-        self.cxa16, self.cxb16, self.ch16 = [zb(R, Kp) for _ in range(M)], [zb(R, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
+        self.cxa = [z(self.view_rows, Kp) for _ in range(M)]
+        r16 = self.dense_rows_max
+        self.cxa16, self.cxb16, self.ch16 = [zb(r16, Kp) for _ in range(M)], [zb(r16, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
         self.xa, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
         self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
         if any(w % 8 for w in hidden):
@@ -580,6 +590,7 @@ class DiffusionEngine:
         self.bias_t = [z(T, H) for _ in range(M)]  # per-timestep layer-1 bias of the reverse chain (b1 + W1[:, I:] . temb(t))
         self.I8 = (items + 7) & ~7
         self._chain_plans: Dict[tuple, list] = {}
+        self._view_plans: Dict[tuple, list] = {}  # the latent chain's last step per row chunk (_latent_views)
         self._w1T_chain = None  # bf16 W1^T per modality, allocated by the first CSR chain start
         self._latent_ok: Optional[bool] = None  # dmm_latent_chain_supported(H) on this device, asked once
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
@@ -1161,6 +1172,15 @@ class DiffusionEngine:
         z_T is a gather of W1x^T rows when x_T = x_0 comes as CSR rows, else one layer-1 GEMM on the dense x_T (sampling_step > 0).  Any
         mid layers (k > 1 hidden widths) run between h_t and the latent GEMM as in the stepwise chain.  Returns [B, I] fp32 views."""
         mods = list(range(self.M)) if mods is None else list(mods)
+        h0, B = self._latent_h0(rows=rows, xT=xT, B=B, mods=mods)
+        if B > self.view_rows:
+            raise ValueError(f"generate_views_latent: {B} rows of [rows, I] views exceed the engine's view_rows = {self.view_rows} (lean chain buffers): "
+                             "use rebuild_edges, which forms and consumes them in row chunks")
+        return self._latent_views(h0, 0, B, mods)
+
+    def _latent_h0(self, rows: Optional[CsrRows] = None, xT=None, B: Optional[int] = None, mods: Optional[Sequence[int]] = None):
+        """The latent chain down to h_0 (bf16 [B, H] per modality; see generate_views_latent).  Returns ({m: h_0}, B)."""
+        mods = list(range(self.M)) if mods is None else list(mods)
         T, I, H = self.T, self.I, self.H
         self._latent_alloc()
         lat = self._lat
@@ -1168,14 +1188,18 @@ class DiffusionEngine:
             self._refresh_bf16_weights(m)
         if rows is not None:
             B = rows.shape[0]
+            if B > self.chain_rows:
+                raise ValueError(f"latent chain: {B} rows > chain_rows = {self.chain_rows}")
             self._csr_users[:B].copy_(rows.users)
             key = ("latent-csr", B, rows.ptr.data_ptr(), rows.col.data_ptr(), tuple(mods))
         else:
+            if B > self.dense_rows_max:
+                raise ValueError(f"latent chain: a dense start of {B} rows > {self.dense_rows_max} (lean chain buffers keep B_max rows)")
             for m, x in zip(mods, xT):  # fp32 staging; cast to the bf16 operand inside the plan
                 self.cxb[m][:B, :I].copy_(x)
             key = ("latent-dense", B, tuple(mods))
-        plan = self._chain_plans.get(key)
-        if plan is None:
+        entry = self._chain_plans.get(key)
+        if entry is None:
             with L.Recorder() as plan:
                 z, z2 = {m: lat["za"][m][:B] for m in mods}, {m: lat["zb"][m][:B] for m in mods}
                 if os.environ.get("DMM_LATENT_INPLACE", "0") == "1":
@@ -1198,13 +1222,28 @@ class DiffusionEngine:
                     for i in range(T - 1, 0, -1):
                         ops.gemm_bf16_nt_batched([self._latent_step_args(m, i, self._mids_chain(m, h[m]), z[m], z2[m], h2[m]) for m in mods])
                         z, z2, h, h2 = z2, z, h2, h
-                ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h[m]), B=self.w2_16[m], out=self.cxa[m][:B], bias=lat["b2_last"][m], alpha=float(self.c1[0]), N=I)
-                                          for m in mods])
             if len(self._chain_plans) > 16:
                 self._chain_plans.clear()
-            self._chain_plans[key] = plan
+            entry = self._chain_plans[key] = (plan, h)
+        L.replay(entry[0])
+        return entry[1], B
+
+    def _latent_views(self, h0: Dict[int, Tensor], r0: int, r1: int, mods: Sequence[int]) -> List[Tensor]:
+        """Last step of the latent chain for rows r0 .. r1 of h_0: x_0' = c1[0] (h_0 W2^T + b2), the ONE item-sized GEMM of the chain, into the
+        first r1 - r0 rows of the view buffers (valid until the next call)."""
+        n, I, lat = r1 - r0, self.I, self._lat
+        assert 0 < n <= self.view_rows
+        key = ("latent-view", n, tuple(mods), tuple(int(h0[m].data_ptr()) for m in mods), r0)
+        plan = self._view_plans.get(key)
+        if plan is None:
+            with L.Recorder() as plan:
+                ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h0[m][r0:r1]), B=self.w2_16[m], out=self.cxa[m][:n], bias=lat["b2_last"][m],
+                                               alpha=float(self.c1[0]), N=I) for m in mods])
+            if len(self._view_plans) > 256:
+                self._view_plans.clear()
+            self._view_plans[key] = plan
         L.replay(plan)
-        return [self.cxa[m][:B, :I] for m in mods]
+        return [self.cxa[m][:n, :I] for m in mods]
 
     def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
         """Reverse chain on the dedicated bf16 NT GEMM: bf16 weights / activations as MFMA operands, fp32 accumulation, the
@@ -1446,7 +1485,8 @@ class DiffusionEngine:
         if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow
             all_users = torch.cat([b.reshape(-1) for b in user_batches])
             n = int(all_users.numel())
-            n_chunks = max(1, -(-n // self.chain_rows))
+            cap = self.chain_rows if (csr is not None and sampling_step == 0) else self.dense_rows_max
+            n_chunks = max(1, -(-n // cap))
             per = max(1, -(-n // n_chunks))
             user_batches = [all_users[s:s + per] for s in range(0, n, per)]
         latent = precision == 1 and self._latent_mode()
@@ -1455,16 +1495,28 @@ class DiffusionEngine:
                 continue
             if csr is not None and precision == 1 and sampling_step == 0:  # x_0 stays CSR: no dense [rows, I] operand is built
                 rows = CsrRows(csr[0], csr[1], ub + int(csr[2]))
-                views = self.generate_views_latent(rows=rows) if latent else self.generate_views_bf16_csr(rows)
-                self._topk_all(views, ub.to(torch.int32), deg_ptr, out)
+                if latent:  # the [rows, I] views are formed view_rows rows at a time and consumed by the top-k at once
+                    h0, n = self._latent_h0(rows=rows)
+                    ub32 = ub.to(torch.int32)
+                    for r0 in range(0, n, self.view_rows):
+                        r1 = min(n, r0 + self.view_rows)
+                        self._topk_all(self._latent_views(h0, r0, r1, range(self.M)), ub32[r0:r1], deg_ptr, out)
+                else:
+                    self._topk_all(self.generate_views_bf16_csr(rows), ub.to(torch.int32), deg_ptr, out)
                 continue
             x0 = dense_rows(ub)
             if latent:  # dense start: x_0 itself, or each modality's own noised x_T (drawn one at a time into a shared buffer)
                 starts = (self.noised_start(m, x0, sampling_step) for m in range(self.M)) if sampling_step else [x0] * self.M
-                views = self.generate_views_latent(xT=starts, B=x0.shape[0])
-                for m in range(self.M):
-                    ops.topk_rows(views[m], ub.to(torch.int32), deg_ptr, out[m], self.I)
+                h0, n = self._latent_h0(xT=starts, B=x0.shape[0])
+                ub32 = ub.to(torch.int32)
+                for r0 in range(0, n, self.view_rows):
+                    r1 = min(n, r0 + self.view_rows)
+                    views = self._latent_views(h0, r0, r1, range(self.M))
+                    for m in range(self.M):
+                        ops.topk_rows(views[m], ub32[r0:r1], deg_ptr, out[m], self.I)
                 continue
+            if self.lean:
+                raise ValueError("DiffusionEngine: the stepwise reverse chain needs full [chain_rows, I] buffers (this engine keeps lean ones: latent chain only)")
             if precision == 1 and sampling_step == 0:
                 views = self.generate_views_bf16(x0)
                 for m in range(self.M):

@@ -990,6 +990,23 @@ def test_latent_chain_matches_stepwise_chain(dev):
         assert float((one - lat[m]).abs().max()) < 2e-3 * scale, f"modality {m}: single-modality latent chain"
     ptr32 = dd.deg_ptr32
     e_lat = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1, csr=(dd.ptr, dd.col32, 0))
+    # lean chain buffers (what a large item count switches on by itself): the [rows, I] views are formed 256 rows at a time and consumed by the
+    # top-k at once, the bf16 item-sized buffers keep B_max rows -- the same chain, the same GEMM per row: bit-identical edges; the dense start
+    # (rows re-chunked to B_max) likewise; the stepwise chain is refused
+    El = DiffusionEngine(I, D, H, 10, M, T_, dict(hp, chain_view_bytes=M * 256 * E.Kp * 4), dev, 128, chain_rows=B)
+    assert El.lean and El.view_rows == 256 and El.dense_rows_max == 128 and El.cxa[0].shape[0] == 256 and El.cxa16[0].shape[0] == 128
+    for m in range(M):
+        El.P[m].data.copy_(E.P[m].data)
+    e_lean = El.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1, csr=(dd.ptr, dd.col32, 0))
+    e_dense, e_ldense = (X.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1) for X in (E, El))
+    for m in range(M):  # (a GEMM over fewer rows may run on another tile shape: the same products in another summation order -- near-tie flips only)
+        s_csr, s_dense = float((e_lean[m] == e_lat[m]).float().mean()), float((e_dense[m] == e_ldense[m]).float().mean())
+        print(f"modality {m}: lean vs full chain buffers: {s_csr:.4f} (CSR start), {s_dense:.4f} (dense start in B_max-row chunks) of the edges equal")
+        assert s_csr > 0.995 and s_dense > 0.995
+    El.check_chain_error()
+    with pytest.raises(ValueError):
+        El.generate_views_latent(rows=dd.csr_rows(users))
+    del El
     E.hp["chain_mode"] = "stepwise"
     assert not E._latent_mode()
     e_step = E.rebuild_edges(dd.rows, [users], ptr32, int(dd.ptr[-1]), precision=1, csr=(dd.ptr, dd.col32, 0))
