@@ -70,9 +70,10 @@ class Coach:
         self.diffusion_model = GaussianDiffusion(cfg)
         in_dims, out_dims = denoise_dims(cfg)
         own_users = lay.nu if lay is not None else int(cfg.data.user_num)
+        self.item_shard = self._denoise_item_shard(int(in_dims[1]), [int(x) for x in out_dims[:-1]])
         self.diff_engine = DiffusionEngine(int(cfg.data.item_num), int(cfg.base.latdim), int(in_dims[1]), int(cfg.base.d_emb_size), M,
                                            int(cfg.hyper.steps), hyper_dict(cfg), self.device, int(cfg.train.batch),
-                                           chain_rows=min(max(own_users, 1), 16384), hidden=[int(x) for x in out_dims[:-1]])
+                                           chain_rows=min(max(own_users, 1), 16384), hidden=[int(x) for x in out_dims[:-1]], item_shard=self.item_shard)
         dens = [Denoise(in_dims, out_dims, cfg, _engine=self.diff_engine, _slot=m, precision=self.precision) for m in range(M)]
         self.image_denoise_model, self.text_denoise_model = dens[0], dens[1]
         if M == 3:
@@ -83,15 +84,37 @@ class Coach:
         if lay is not None:
             from .sharded import make_sharded_adjacency
             DE, dd = self.diff_engine, h.diffusionData
-            DE.shard_world, DE.shard_rank, DE.shard_group = self.world, self.rank, self.group
-            DE.hp["seed"] = int(DE.hp.get("seed", 1818)) + 7919 * self.rank  # the replicas' rows draw from different Philox streams
+            DE.hp["seed"] = int(DE.hp.get("seed", 1818)) + 7919 * self.rank  # the replicas' rows / item slices draw from different Philox streams
             DE.t_gen = torch.Generator(device=self.device)
-            DE.t_gen.manual_seed(int(cfg.base.seed) + 101 * (self.rank + 1))
+            if self.item_shard is None:  # row split: every replica trains the Denoise on the minibatch rows of its own users
+                DE.shard_world, DE.shard_rank, DE.shard_group = self.world, self.rank, self.group
+                DE.t_gen.manual_seed(int(cfg.base.seed) + 101 * (self.rank + 1))
+            else:  # item split: every replica sees all rows of the minibatch (over its item slice), so the rows' timesteps must agree everywhere
+                DE.t_gen.manual_seed(int(cfg.base.seed) + 101)
             vec = graph.spmm_operand_vec(lay.n_local, int(cfg.base.latdim))  # by the size of the replica's own operand [own users ; items]
             self.base_adj = make_sharded_adjacency(lay, h.graph.trn_rows, h.graph.trn_cols, int(cfg.base.latdim), self.device,
                                                    task_len=graph.spmm_task_len(vec), vec=vec)
             self.local_ptr = (dd.ptr[lay.u0:lay.u1 + 1] - dd.ptr[lay.u0]).contiguous()  # CSR of the own users' train items
             self.local_ptr32 = self.local_ptr.to(torch.int32)
+
+    def _denoise_item_shard(self, H: int, hidden: List[int]):
+        """How the Denoise MLPs are split over the replicas of a user-sharded run.  "rows": weights replicated, every replica trains on
+        the minibatch rows of its own users, gradients all-reduced (2 I H fp32 per modality and step).  "items" (SURVEY 8e): replica g holds the W1
+        columns / W2 rows of its item slice -- weights, gradients and Adam state are 1 / world each and the step exchanges [B, H]-sized partial
+        activations instead of weight gradients.  DMM_DENOISE_SHARD = rows | items | auto (default: items once a modality's weight gradient
+        reaches 256 MiB -- I >= 32768 at H = 1024 -- and the step's kernels cover the shape)."""
+        from .engine import ItemShard
+        if self.world <= 1:
+            return None
+        cfg = self.config
+        mode = os.environ.get("DMM_DENOISE_SHARD", "auto")
+        I, D = int(cfg.data.item_num), int(cfg.base.latdim)
+        fits = len(hidden) == 1 and D in (64, 128, 256) and self.precision == 1 and int(cfg.hyper.sampling_step) == 0 and (self.world - 1) * -(-I // self.world) < I
+        if mode == "items" and not fits:
+            raise ValueError("DMM_DENOISE_SHARD=items needs one hidden width, d in 64 / 128 / 256, bf16 mode, sampling_step = 0 and a non-empty item slice per replica")
+        if mode == "items" or (mode == "auto" and fits and 2 * I * H * 4 >= (256 << 20)):
+            return ItemShard(self.rank, self.world, I, group=self.group)
+        return None
 
     def _set_lr(self) -> None:
         """CosineAnnealingLR(T_max=train.epoch, eta_min=1e-4), stepped once per epoch (Main.py:59-65,93,101,105,110)."""
@@ -204,13 +227,14 @@ class Coach:
         t_start = time.perf_counter()
         # ---- phase 1: diffusion training (Main.py:145-192) ----
         J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
-        feats = [J.feat[m] for m in range(M)]
+        ish = self.item_shard
+        feats = [J.feat[m] if ish is None else J.feat[m][ish.i0:ish.i1] for m in range(M)]
         reg_term = DE.reg_term(J.i_embs)  # i_embs does not move in this phase either
         dl = [0.0] * M
         step_means = []
         diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
         for idx in diff_batches:
-            own = idx if lay is None else idx[(idx >= lay.u0) & (idx < lay.u1)]
+            own = idx if (lay is None or ish is not None) else idx[(idx >= lay.u0) & (idx < lay.u1)]  # (item split: all rows, own item slice)
             x0 = dd.csr_rows(own)  # x_0 stays CSR: the engine densifies it straight into its operand buffer
             t = noise = None
             if draws is not None:
@@ -284,7 +308,8 @@ class Coach:
         import torch.distributed as dist
         J, DE = self.model.engine, self.diff_engine
         lo = J.nu * J.D
-        parts = [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t for p in DE.P for t in (p.data, p.m, p.v)]
+        nr = DE.n_replicated if self.item_shard is not None else None  # item-sharded Denoise: only the small tensors are replicated
+        parts = [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t[:nr] for p in DE.P for t in (p.data, p.m, p.v)]
         sums = torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in parts])
         mn, mx = sums.clone(), sums.clone()
         dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)

@@ -121,6 +121,8 @@ _SIGS = {
     "dmm_adam_step_prefix": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L]),
     "dmm_qsample_temb": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),
     "dmm_csr_dense_rows": (C.c_int, [_P, _P, _P, _I, _I, _P, _L, _P]),
+    "dmm_csr_dense_rows_slice": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "dmm_bias_tanh_rows": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "dmm_csr_gather_sum_bf16": (C.c_int, [_P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _L, _P]),
     "dmm_csr_gather_sum_latent": (C.c_int, [_P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P, _L, _P]),
     "dmm_csr_add_rows": (C.c_int, [_P, _P, _P, _I, _I, _F, _P, _L, _P, _L, _P]),
@@ -135,6 +137,7 @@ _SIGS = {
     "dmm_diff_loss": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _D, _P, _P, _P, _P, _P]),
     "dmm_diff_loss_bits": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _F, _D, _P, _P]),
     "dmm_csr_row_bits": (C.c_int, [_P, _P, _P, _I, _I, _P, _L, _P]),
+    "dmm_csr_row_bits_slice": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _L, _P]),
     "dmm_qsample_temb_bits": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),
     "dmm_topk_rows": (C.c_int, [_P, _L, _P, _P, _P, _I, _I, _P]),
     "dmm_noised_start": (C.c_int, [_P, _L, _P, _F, _F, _P, _L, _I, _I, _U64, _U64, _P]),

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void qsample_temb_kernel(const float* __restri
 // One workgroup per row; ptr is the CSR of ALL users (int64), col int32.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void csr_dense_rows_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
-                                                             const long long* __restrict__ rows, float* __restrict__ out, long long ld, int I) {
+                                                             const long long* __restrict__ rows, float* __restrict__ out, long long ld, int I, int col_lo) {
   const int b = blockIdx.x;
   float* __restrict__ o = out + (long long)b * ld;
   for (long long j = threadIdx.x * 4; j < ld; j += 1024) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void csr_dense_rows_kernel(const long long* __
   __syncthreads();
   const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
   for (long long e = beg + threadIdx.x; e < end; e += 256) {
-    const int c = col[e];
+    const int c = col[e] - col_lo;  // (col_lo: the first item of the column slice this replica holds; 0 = all items)
     if ((unsigned)c < (unsigned)I) o[c] = 1.0f;
   }
 }
@@ -948,35 +948,46 @@ extern "C" int dmm_qsample_temb_bits(const uint32_t* x0bits, int64_t ldb, const 
 
 // x_0 rows as bit masks: bits[b, w] bit k = 1 iff item 32 w + k is an interaction of user rows[b] (one workgroup per row: clear, then set)
 __global__ __launch_bounds__(256) void csr_row_bits_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
-                                                           const long long* __restrict__ rows, uint32_t* __restrict__ bits, long long ldb, int I) {
+                                                           const long long* __restrict__ rows, uint32_t* __restrict__ bits, long long ldb, int I,
+                                                           int col_lo) {
   extern __shared__ uint32_t wb[];
   const int b = blockIdx.x, W = (I + 31) >> 5;
   for (int w = threadIdx.x; w < W; w += 256) wb[w] = 0u;
   __syncthreads();
   const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
   for (long long e = beg + threadIdx.x; e < end; e += 256) {
-    const int c = col[e];
+    const int c = col[e] - col_lo;
     if ((unsigned)c < (unsigned)I) atomicOr(&wb[c >> 5], 1u << (c & 31));
   }
   __syncthreads();
   for (int w = threadIdx.x; w < ldb; w += 256) bits[(long long)b * ldb + w] = w < W ? wb[w] : 0u;
 }
 
-extern "C" int dmm_csr_row_bits(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, uint32_t* bits, int64_t ldb, void* stream) {
-  DMM_CHECK_ARG(ptr && col && rows && bits && B > 0 && I > 0 && ldb * 32 >= I, "dmm_csr_row_bits: bad arguments (ldb words >= ceil(I / 32))");
+extern "C" int dmm_csr_row_bits_slice(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int col_lo, int I, uint32_t* bits, int64_t ldb,
+                                      void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && bits && B > 0 && I > 0 && col_lo >= 0 && ldb * 32 >= I, "dmm_csr_row_bits: bad arguments (ldb words >= ceil(I / 32))");
   const size_t lds = (size_t)((I + 31) >> 5) * 4;
   DMM_CHECK_ARG(lds <= 60 * 1024, "dmm_csr_row_bits: I=%d too large for the LDS row mask (<= 491520)", I);
   hipLaunchKernelGGL(csr_row_bits_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, bits,
-                     (long long)ldb, I);
+                     (long long)ldb, I, col_lo);
   DMM_LAUNCH_CHECK("dmm_csr_row_bits");
   return 0;
 }
+extern "C" int dmm_csr_row_bits(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, uint32_t* bits, int64_t ldb, void* stream) {
+  return dmm_csr_row_bits_slice(ptr, col, rows, B, 0, I, bits, ldb, stream);
+}
 
-extern "C" int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream) {
-  DMM_CHECK_ARG(ptr && col && rows && out && B > 0 && I > 0 && ldo >= I && ldo % 4 == 0, "dmm_csr_dense_rows: bad arguments (ldo must be a multiple of 4 >= I)");
-  hipLaunchKernelGGL(csr_dense_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, out, (long long)ldo, I);
+extern "C" int dmm_csr_dense_rows_slice(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int col_lo, int I, float* out, int64_t ldo,
+                                        void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && out && B > 0 && I > 0 && col_lo >= 0 && ldo >= I && ldo % 4 == 0,
+                "dmm_csr_dense_rows: bad arguments (ldo must be a multiple of 4 >= I)");
+  hipLaunchKernelGGL(csr_dense_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, out, (long long)ldo, I,
+                     col_lo);
   DMM_LAUNCH_CHECK("dmm_csr_dense_rows");
   return 0;
+}
+extern "C" int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream) {
+  return dmm_csr_dense_rows_slice(ptr, col, rows, B, 0, I, out, ldo, stream);
 }
 static int csr_gather_sum_launch(const char* who, const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw,
                                  const float* bias, int H, int act, void* out16, int64_t ldo, float* z, int64_t ldz, void* stream) {

@@ -293,6 +293,22 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
     dpre[i] = dh[i] * (1.0f - t * t);
   }
 }
+// x = tanh(x + bias[col]) in place (fp32, contiguous [rows, cols]) + a bf16 copy: layer 1's activation once its item-sliced partial products have been
+// summed over the replicas (item-sharded Denoise); 4 columns per thread
+__global__ __launch_bounds__(256) void bias_tanh_rows_kernel(float* __restrict__ x, const float* __restrict__ bias, int cols, int64_t n4,
+                                                              __bf16* __restrict__ out16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const int c = (int)((i * 4) % cols);
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    v.x = tanhf(v.x + b.x); v.y = tanhf(v.y + b.y); v.z = tanhf(v.z + b.z); v.w = tanhf(v.w + b.w);
+    reinterpret_cast<float4*>(x)[i] = v;
+    if (out16) {
+      __bf16 o[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      reinterpret_cast<uint2*>(out16)[i] = *reinterpret_cast<const uint2*>(o);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = fmaf(alpha, x[i], y[i]);
 }
@@ -566,6 +582,14 @@ extern "C" int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_
   DMM_CHECK_ARG(dh && h && dpre && n > 0, "dmm_tanh_bwd: bad arguments");
   hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, dh, h, dpre, n);
   DMM_LAUNCH_CHECK("dmm_tanh_bwd");
+  return 0;
+}
+extern "C" int dmm_bias_tanh_rows(float* x, const float* bias, int rows, int cols, void* out16, void* stream) {
+  DMM_CHECK_ARG(x && bias && rows > 0 && cols > 0 && cols % 4 == 0 && (((uintptr_t)x | (uintptr_t)bias) & 15) == 0 && ((uintptr_t)out16 & 7) == 0,
+                "dmm_bias_tanh_rows: bad arguments (contiguous [rows, cols], cols a multiple of 4, 16-byte aligned)");
+  const int64_t n4 = (int64_t)rows * cols / 4;
+  hipLaunchKernelGGL(bias_tanh_rows_kernel, dim3(grid_for(n4, 1024)), dim3(256), 0, (hipStream_t)stream, x, bias, cols, n4, (__bf16*)out16);
+  DMM_LAUNCH_CHECK("dmm_bias_tanh_rows");
   return 0;
 }
 extern "C" int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n, void* stream) {

@@ -67,6 +67,38 @@ class CsrRows:
         return (int(self.users.shape[0]),)
 
 
+class ItemShard:
+    """Item-sharded Denoise ("sharding the Denoise I dimension -- K-split layer 1 / N-split layer 2 with items partitioned").  Replica
+    `rank` of `world` holds the W1 columns, W2 rows, b2 entries (and their gradients / Adam state) of the items i0 .. i1 - 1, a slice of
+    S = ceil(I / world) items (the last one may be shorter); the small tensors (time-embedding layer, b1, W1's time-embedding columns, gate layer)
+    are replicated.  emulate = True: a single process runs ONE replica's work with the collectives skipped (timing / memory tools only)."""
+
+    def __init__(self, rank: int, world: int, items_global: int, group=None, emulate: bool = False):
+        self.rank, self.world, self.items_global, self.group, self.emulate = int(rank), int(world), int(items_global), group, bool(emulate)
+        self.S = -(-self.items_global // self.world)
+        self.i0, self.i1 = min(self.rank * self.S, self.items_global), min((self.rank + 1) * self.S, self.items_global)
+        if (self.world - 1) * self.S >= self.items_global:
+            raise ValueError(f"ItemShard: {items_global} items leave the last of {world} slices of {self.S} empty")
+
+    @property
+    def items_local(self) -> int:
+        return self.i1 - self.i0
+
+    def all_reduce(self, t: Tensor) -> None:
+        if self.world > 1 and not self.emulate:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
+
+    def all_gather(self, out: Tensor, t: Tensor) -> None:
+        """out [world * n, ...] <- every replica's t [n, ...] in rank order (emulation: the own block only)."""
+        if self.world > 1 and not self.emulate:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        else:
+            n = t.shape[0]
+            out[self.rank * n:(self.rank + 1) * n].copy_(t)
+
+
 class FlatParams:
     """Named fp32 tensors carved out of one flat buffer (+ same-layout grad / Adam m / Adam v buffers)."""
 
@@ -509,7 +541,7 @@ class DiffusionEngine:
     """Denoise MLPs of all modalities + GaussianDiffusion arithmetic."""
 
     def __init__(self, items: int, D: int, H: int, te: int, M: int, T: int, hp: dict, device, B_max: int, chain_rows: Optional[int] = None,
-                 hidden: Optional[Sequence[int]] = None):
+                 hidden: Optional[Sequence[int]] = None, item_shard: Optional[ItemShard] = None):
         """chain_rows: rows the reverse chain processes per launch sequence (>= B_max).  The chain's rows are independent, so the
         rebuild is free to use far larger GEMMs than the training batch: more 128x128 tiles per launch, no ragged tail batch.
         hidden: the reference's `base.denoise_dim` list [H_1, ..., H_k] (Model.py:156-160): in_layers (I+te -> H_k), (H_k -> H_k-1), ...,
@@ -523,18 +555,30 @@ class DiffusionEngine:
         self.L2 = f"out_layers.{k - 1}"  # the layer that maps H -> I
         w_in = hidden[::-1]  # output widths of in_layers.0 .. k-1
         self.mids = [(f"in_layers.{j}", w_in[j - 1], w_in[j]) for j in range(1, k)] + [(f"out_layers.{j}", hidden[j], hidden[j + 1]) for j in range(k - 1)]
+        # item-sharded Denoise: `items` is the global item count; the engine's training-side I is the replica's slice, the rebuild's is global
+        self.ishard = item_shard
+        if item_shard is not None:
+            if item_shard.items_global != items:
+                raise ValueError("DiffusionEngine: item_shard.items_global must equal `items`")
+            if k != 1:
+                raise ValueError("DiffusionEngine: item-sharded Denoise covers the single-hidden-width shape (every shipped config)")
+            items = item_shard.items_local
         self.I, self.D, self.H, self.te, self.M, self.T = items, D, H, te, M, T
+        self.I_chain = item_shard.items_global if item_shard is not None else items  # item count of the rebuilt views
         self.chain_rows = max(int(chain_rows or B_max), B_max)
         self.hp = dict(hp)
         self.dev = torch.device(device)
         self.Kp = (items + te + 63) & ~63  # leading dimension of [x_t | temb | 0-pad]; also of out / dout.  Whole 64-wide K tiles: the
         # 256 x 256 LDS-DMA GEMM tile (csrc/gemm_bf16_8ph.hip) takes no K remainder
-        # flat layout: the small tensors whose gradients are ACCUMULATED (atomics / column sums) first, so that one memset clears them all
-        shapes = [("emb_layer.weight", (te, te)), ("emb_layer.bias", (te,)), ("in_layers.0.bias", (H,)), (self.L2 + ".bias", (items,)),
-                  ("gate_layer.weight", (D, D)), ("gate_layer.bias", (D,)), ("in_layers.0.weight", (H, self.Kp)), (self.L2 + ".weight", (items, H))]
+        self.Kp_chain = self.Kp if item_shard is None else (self.I_chain + 63) & ~63
+        # flat layout: the small tensors whose gradients are ACCUMULATED (atomics / column sums) first, so that one memset clears them all;
+        # of those, the ones every replica of an item-sharded Denoise holds whole come before the output bias (n_replicated)
+        shapes = [("emb_layer.weight", (te, te)), ("emb_layer.bias", (te,)), ("in_layers.0.bias", (H,)), ("gate_layer.weight", (D, D)),
+                  ("gate_layer.bias", (D,)), (self.L2 + ".bias", (items,)), ("in_layers.0.weight", (H, self.Kp)), (self.L2 + ".weight", (items, H))]
         for nm, din, dout in self.mids:
             shapes += [(nm + ".weight", (dout, din)), (nm + ".bias", (dout,))]
         self.P = [FlatParams(shapes, self.dev) for _ in range(M)]
+        self.n_replicated = self.P[0].offsets[self.L2 + ".bias"]
         self.sched = schedule_tables(T, hp["noise_scale"], hp["noise_min"], hp["noise_max"])
         f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(self.dev)
         self.sqrt_ac, self.sqrt_1mac = f32(self.sched["sqrt_alphas_cumprod"]), f32(self.sched["sqrt_one_minus_alphas_cumprod"])
@@ -543,6 +587,8 @@ class DiffusionEngine:
         t = np.arange(T)
         w = self.sched["snr"][np.maximum(t - 1, 0)] - self.sched["snr"][t]
         self.w_table = torch.from_numpy(np.where(t == 0, 1.0, w)).to(self.dev)  # float64 [T]
+        if item_shard is not None:  # a replica's mean over ITS items of (out - x_0)^2 counts I_local / I towards the row's mean over all items
+            self.w_table = self.w_table * (float(items) / float(self.I_chain))
         self.lr = float(hp["lr"])
         self.B_max = B_max
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
@@ -573,11 +619,12 @@ class DiffusionEngine:
         # item-sized buffers keep only the training step's B_max rows.  The stepwise chain (chain_mode = "stepwise", the ~fp32 parity
         # mode) needs the full ping-pong sets and is refused in lean mode.
         budget = int(self.hp.get("chain_view_bytes", os.environ.get("DMM_CHAIN_VIEW_BYTES", 8 << 30)))
-        self.lean = self._latent_mode() and M * R * Kp * 4 > budget
-        self.view_rows = R if not self.lean else min(R, max(256, budget // (M * Kp * 4) // 256 * 256))
+        Kc = self.Kp_chain
+        self.lean = self._latent_mode() and M * R * Kc * 4 > budget
+        self.view_rows = R if not self.lean else min(R, max(256, budget // (M * Kc * 4) // 256 * 256))
         self.dense_rows_max = R if not self.lean else B_max  # rows a dense chain start (sampling_step > 0) may bring per launch sequence
         # ping-pong buffers of the reverse chain, one set per modality (the modalities' chains advance together, batched launches)
-        self.cxa = [z(self.view_rows, Kp) for _ in range(M)]
+        self.cxa = [z(self.view_rows, Kc) for _ in range(M)]
         r16 = self.dense_rows_max
         self.cxa16, self.cxb16, self.ch16 = [zb(r16, Kp) for _ in range(M)], [zb(r16, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
         self.xa, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
@@ -617,9 +664,15 @@ class DiffusionEngine:
     w1T16 = property(lambda self: self._lazy["w1T16"].get())
 
     def load_reference_state(self, m: int, sd: Dict[str, Tensor]):
+        """`sd`: the reference's Denoise.state_dict() (the FULL model; an item-sharded replica keeps its slice of W1's item columns, W2's rows, b2)."""
         t = {k: torch.as_tensor(v).float() for k, v in sd.items()}
+        w1_full = t["in_layers.0.weight"]
+        if self.ishard is not None:
+            i0, i1, Ig = self.ishard.i0, self.ishard.i1, self.ishard.items_global
+            w1_full = torch.cat([w1_full[:, i0:i1], w1_full[:, Ig:Ig + self.te]], dim=1)
+            t[self.L2 + ".weight"], t[self.L2 + ".bias"] = t[self.L2 + ".weight"][i0:i1], t[self.L2 + ".bias"][i0:i1]
         w1 = torch.zeros(self.H, self.Kp)
-        w1[:, : self.I + self.te] = t["in_layers.0.weight"]
+        w1[:, : self.I + self.te] = w1_full
         t["in_layers.0.weight"] = w1
         self.P[m].load(t)
 
@@ -628,12 +681,12 @@ class DiffusionEngine:
         sd["in_layers.0.weight"] = sd["in_layers.0.weight"][:, : self.I + self.te].contiguous()
         return sd
 
-    def _set_x0(self, x0) -> Tensor:
+    def _set_x0(self, x0, col_lo: int = 0) -> Tensor:
         """x_0 into the padded operand buffer: a dense [B, I] tensor is copied, CSR rows are densified straight into it (dmm_csr_dense_rows)."""
         B = x0.shape[0]
         x0p = self.x0p[:B]
         if isinstance(x0, CsrRows):
-            ops.csr_dense_rows(x0.ptr, x0.col, x0.users, self.I, x0p)
+            ops.csr_dense_rows(x0.ptr, x0.col, x0.users, self.I, x0p, col_lo=col_lo)
         else:
             x0p[:, : self.I].copy_(x0)
         return x0p
@@ -735,7 +788,8 @@ class DiffusionEngine:
             self._Gf, self._G16 = z(M, D, H), zb(M, D, H)  # (W1x F)^T: fp32 accumulator (K slices) and the bf16 NT operand
             self._G1 = [self._G16[m] for m in range(M)]
             self._G2f, self._G2_16 = z(M, D, H), zb(M, D, H)  # F^T W2 likewise
-            self._FT32, self._b2F = [z(D, (self.I + 3) & ~3) for _ in range(M)], [z(D) for _ in range(M)]
+            self._b2F_block = z(M, D)
+            self._FT32, self._b2F = [z(D, (self.I + 3) & ~3) for _ in range(M)], [self._b2F_block[m] for m in range(M)]
             self._W1eT = [zb(16, H) for _ in range(M)]  # rows te .. 15 stay zero
             self._dtemb = [z(self.B_max, 16) for _ in range(M)]
 
@@ -833,18 +887,24 @@ class DiffusionEngine:
     def _forward_batched(self, x0p: Tensor, ts, noise, feats, i_embs: Tensor, reg_term: float):
         B, I, M = x0p.shape[0], self.I, self.M
         W = self._workspaces()
+        sh = self.ishard  # item-sharded Denoise: this replica's item slice of every [., I] operand; partial products summed over the replicas
+        first = sh is None or sh.rank == 0  # the replica whose partial sums carry the terms that do not depend on the item slice
         for m in range(M):
             a, P = self.act[m], self.P[m]
             a["t"][:B].copy_(ts[m])
+            # (the time-embedding columns of [x_t | temb] are non-zero on ONE replica only: temb W1e^T enters the summed pre-activation once)
+            w_emb, b_emb = (P.view("emb_layer.weight"), P.view("emb_layer.bias")) if first else self._zero_emb()
             if self._x0_bits is not None:  # x_0 as bit masks: 1/32 of the bytes of the dense 0/1 rows
                 ops.qsample_temb_bits(self._x0_bits[:B], noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac,
-                                      P.view("emb_layer.weight"), P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None,
+                                      w_emb, b_emb, a["xcat"][:B], I, draw_noise=noise is None,
                                       seed=self.hp.get("seed", 1818), offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
             else:
-                ops.qsample_temb(x0p, noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, P.view("emb_layer.weight"),
-                                 P.view("emb_layer.bias"), a["xcat"][:B], I, draw_noise=noise is None, seed=self.hp.get("seed", 1818),
+                ops.qsample_temb(x0p, noise[m] if noise is not None else None, a["t"][:B], self.sqrt_ac, self.sqrt_1mac, w_emb,
+                                 b_emb, a["xcat"][:B], I, draw_noise=noise is None, seed=self.hp.get("seed", 1818),
                                  offset=(self.rng_step * M + m) * self.B_max * ((I + 3) // 4))
             self._project_items(a["xcat"][:B], feats[m], a["proj"][:B], 1)
+            if sh is not None:
+                sh.all_reduce(a["proj"][:B])  # x_t F = sum over the slices of x_t[:, I_g] F[I_g]
         # the modalities' gate layers (d x d, one tile each) in one launch
         ops.gemm_batched([dict(A=self.act[m]["proj"][:B], B=self.P[m].view("gate_layer.weight"), out=self.act[m]["gate"][:B], trans_b=True,
                                bias=self.P[m].view("gate_layer.bias"), act=L.ACT_SIGMOID, precision=1) for m in range(M)])
@@ -862,8 +922,14 @@ class DiffusionEngine:
             self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
             if not self._fused_expand():
                 ops.cast_bf16(a["xcat"][:B], W[m]["xa16"][:B])
-        ops.gemm_bf16_nt_batched([dict(A=W[m]["xa16"][:B], B=self.w1_16[m], out=self.act[m]["h"][:B], out_bf16=W[m]["h16"][:B],
-                                       bias=self.P[m].view("in_layers.0.bias"), act=L.ACT_TANH) for m in range(M)])
+        if sh is None:
+            ops.gemm_bf16_nt_batched([dict(A=W[m]["xa16"][:B], B=self.w1_16[m], out=self.act[m]["h"][:B], out_bf16=W[m]["h16"][:B],
+                                           bias=self.P[m].view("in_layers.0.bias"), act=L.ACT_TANH) for m in range(M)])
+        else:  # K-split layer 1: partial pre-activations over the item slice -> sum over the replicas -> bias + tanh (fp32 h and its bf16 copy)
+            ops.gemm_bf16_nt_batched([dict(A=W[m]["xa16"][:B], B=self.w1_16[m], out=self.act[m]["h"][:B]) for m in range(M)])
+            for m in range(M):
+                sh.all_reduce(self.act[m]["h"][:B])
+                ops.bias_tanh_rows(self.act[m]["h"][:B], self.P[m].view("in_layers.0.bias"), W[m]["h16"][:B])
         if self.mids:
             for m in range(M):
                 ops.cast_bf16(self._mids_fwd(m, self.act[m]["h"][:B], 1), W[m]["h16"][:B])
@@ -883,6 +949,9 @@ class DiffusionEngine:
             else:  # d = 256: 64-row workgroups re-stage the [K, 256] operand too often (1.68 ms against 0.76 ms on the K-split generic GEMM at 100k items)
                 ops.gemm_batched([dict(A=feats[m], B=self.P[m].view(self.L2 + ".weight"), out=self._G2f[m], trans_a=True, precision=1, K=I, split_k=32)
                                   for m in range(M)])
+            if sh is not None:  # F^T W2 and b2 F are sums over the item slices
+                sh.all_reduce(self._G2f)
+                sh.all_reduce(self._b2F_block)
             ops.cast_bf16(self._G2f.view(-1, self.H), self._G2_16.view(-1, self.H))
             ops.gemm_bf16_nt_batched([dict(A=W[m]["h16"][:B], B=self._G2_16[m], out=self.act[m]["um"][:B], bias=self._b2F[m]) for m in range(M)])
         for m in range(M):
@@ -895,7 +964,7 @@ class DiffusionEngine:
                     # x_0 @ i_embs (Model.py:414) for 0/1 CSR rows is a sum of a handful of i_embs rows: a gather instead of a pass over [B, I]
                     # (the same bf16-rounded operands and fp32 sums as dmm_item_project, in another order)
                     if self._ie16 is None:
-                        self._ie16 = torch.zeros(self.I, self.D, dtype=torch.bfloat16, device=self.dev)
+                        self._ie16 = torch.zeros(i_embs.shape[0], self.D, dtype=torch.bfloat16, device=self.dev)  # (all items, also when the Denoise is item-sharded)
                         self._zero_d = torch.zeros(self.D, dtype=torch.float32, device=self.dev)
                         self._ui16 = torch.zeros(self.B_max, self.D, dtype=torch.bfloat16, device=self.dev)
                     ops.cast_bf16(i_embs, self._ie16)
@@ -903,10 +972,13 @@ class DiffusionEngine:
                 else:
                     self._project_items(x0p, i_embs, self.ui[:B], 1)
             a["w"] = self.w_table.index_select(0, a["t"][:B])
+            # (item-sharded: a row's loss is the sum over the replicas of its partial MSE -- w_table carries I_local / I -- plus, once, the terms
+            # that do not depend on the slice)
+            sw, rt = (self.hp["sim_weight"], reg_term) if first else (0.0, 0.0)
             if self._x0_bits is not None:
-                ops.diff_loss_bits(a["out"][:B], self._x0_bits[:B], a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, a["loss"][:B])
+                ops.diff_loss_bits(a["out"][:B], self._x0_bits[:B], a["w"], a["um"][:B], self.ui[:B], I, sw, rt, a["loss"][:B])
             else:
-                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, 0.0, a["loss"][:B], None, None)
+                ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, sw, rt, 0.0, a["loss"][:B], None, None)
 
     def _backward_batched(self, x0p: Tensor, feats, reg_term: float, gscale: float, gs_dev: Optional[Tensor] = None):
         B, I, H, D, Kp, M = x0p.shape[0], self.I, self.H, self.D, self.Kp, self.M
@@ -941,6 +1013,10 @@ class DiffusionEngine:
         ops.gemm_bf16_nt_batched([dict(A=W[m]["doutT16"][:, :Bp], B=W[m]["hT16"][:, :Bp], out=self.P[m].g(self.L2 + ".weight"), N=H, K=Bp)
                                   for m in range(M)])                                               # dW2 = dout^T h
         ops.gemm_bf16_nt_batched([dict(A=W[m]["xb16"][:B], B=W[m]["w2T16"], out=W[m]["dh"][:B], K=Kp) for m in range(M)])  # dh = dout W2
+        sh = self.ishard
+        if sh is not None:  # dh = sum over the item slices of dout[:, I_g] W2[I_g, :]
+            for m in range(M):
+                sh.all_reduce(W[m]["dh"][:B])
         for m in range(M):
             a, P, w = self.act[m], self.P[m], W[m]
             dh = self._mids_bwd(m, a["h"][:B], w["dh"][:B], 1) if self.mids else w["dh"][:B]
@@ -967,6 +1043,8 @@ class DiffusionEngine:
             else:  # (d = 256: see the forward's F^T W2)
                 ops.gemm_batched([dict(A=feats[m], B=self.P[m].view("in_layers.0.weight"), out=self._Gf[m], trans_a=True, trans_b=True, precision=1, K=I,
                                        split_k=32) for m in range(M)])
+            if sh is not None:  # (W1x F)^T is a sum over the item slices
+                sh.all_reduce(self._Gf)
             ops.cast_bf16(self._Gf.view(-1, H), self._G16.view(-1, H))
             ops.gemm_bf16_nt_batched([dict(A=W[m]["dpre16"][:B], B=self._G1[m], out=W[m]["dpg"][:B]) for m in range(M)])
             for m in range(M):
@@ -986,6 +1064,33 @@ class DiffusionEngine:
         # dWg = dgate_pre^T proj: a single d x d output tile with K = B -- split K over 32 workgroups (zeroed above), all modalities in one launch
         ops.gemm_batched([dict(A=W[m]["dgate"][:B], B=self.act[m]["proj"][:B], out=self.P[m].g("gate_layer.weight"), trans_a=True, precision=1, split_k=32)
                           for m in range(M)])
+
+    # -- item-sharded Denoise: the replicated small tensors ---------------------------------------------------------------------------
+    def _zero_emb(self):
+        """Zero stand-ins for the time-embedding layer on the replicas whose operand carries no time embedding."""
+        if getattr(self, "_zero_emb_bufs", None) is None:
+            self._zero_emb_bufs = (torch.zeros(self.te, self.te, device=self.dev), torch.zeros(self.te, device=self.dev))
+        return self._zero_emb_bufs
+
+    def _sync_replicated_grads(self):
+        """The gradients of the tensors every replica of an item-sharded Denoise holds whole -- time-embedding layer, b1, gate layer (the flat
+        buffer's first n_replicated entries) and W1's time-embedding columns -- are taken from replica 0 (the others computed the same values from
+        the same all-reduced inputs, up to the order of their atomics; W1e's gradient is zero elsewhere: only replica 0's operand carries temb):
+        ONE all-reduce in which the other replicas contribute zeros, so the replicated tensors get bit-identical updates everywhere."""
+        sh, n0, te, H, I, M = self.ishard, self.n_replicated, self.te, self.H, self.I, self.M
+        if getattr(self, "_rep_buf", None) is None:
+            self._rep_buf = torch.zeros(M, n0 + H * te, dtype=torch.float32, device=self.dev)
+        buf = self._rep_buf
+        for m, P in enumerate(self.P):
+            if sh.rank == 0:
+                buf[m, :n0].copy_(P.grad[:n0])
+                buf[m, n0:].view(H, te).copy_(P.g("in_layers.0.weight")[:, I:I + te])
+            else:
+                buf[m].zero_()
+        sh.all_reduce(buf)
+        for m, P in enumerate(self.P):
+            P.grad[:n0].copy_(buf[m, :n0])
+            P.g("in_layers.0.weight")[:, I:I + te].copy_(buf[m, n0:].view(H, te))
 
     def reg_term(self, i_embs: Tensor) -> float:
         """l2_reg_loss(reg, [i_embs]) * reg (Model.py:421,425) as a host value.  i_embs does not move during the diffusion phase (only the
@@ -1007,9 +1112,17 @@ class DiffusionEngine:
         scale 1 / (minibatch size x sum of the means) (Main.py:176) then reaches the kernels as a device scalar and the step reads nothing back."""
         B, M = x0.shape[0], self.M
         Bg = int(global_rows) if global_rows is not None else B
+        sh = self.ishard
+        if sh is not None:  # item-sharded Denoise: every replica takes ALL rows of the minibatch over its slice of the items
+            if precision != 1 or not (self._fused_expand() and self._folded_products()) or self.shard_world > 1 or Bg != B or not isinstance(x0, CsrRows):
+                raise ValueError("item-sharded Denoise: bf16 batched step (fused expand, folded products, d in 64 / 128 / 256) on CSR rows, the whole "
+                                 "minibatch on every replica, not combined with the row-split mode")
+            if len(feats) != M or any(f.shape[0] != self.I for f in feats):
+                raise ValueError("item-sharded Denoise: `feats` must be the replica's item slice of the projected features")
         if reg_term is None:
             reg_term = self.reg_term(i_embs)
         sums = torch.zeros(M, dtype=torch.float64, device=self.dev)
+        col_lo = sh.i0 if sh is not None else 0
         if B:
             self._x0_rows = x0 if isinstance(x0, CsrRows) else None
             self._x0_bits = None
@@ -1020,10 +1133,10 @@ class DiffusionEngine:
                 if self._bits_buf is None:
                     self._bits_buf = torch.zeros(self.B_max, (self.I + 31) // 32, dtype=torch.int32, device=self.dev)
                 self._x0_bits = self._bits_buf
-                ops.csr_row_bits(x0.ptr, x0.col, x0.users, self.I, self._x0_bits[:B])
+                ops.csr_row_bits(x0.ptr, x0.col, x0.users, self.I, self._x0_bits[:B], col_lo=col_lo)
                 x0p = self.act[0]["xcat"][:B]  # (a [B, Kp] placeholder: nothing on this path reads x_0 rows; the dense operand stays unallocated)
             else:
-                x0p = self._set_x0(x0)
+                x0p = self._set_x0(x0, col_lo)
             ts = [(t[m] if t is not None else torch.randint(0, self.T, (B,), device=self.dev, dtype=torch.int32, generator=self.t_gen)).to(torch.int32)
                   for m in range(M)]
             if precision == 1:  # the modalities' large GEMMs go out as one batched launch each (enough 256 x 256 tiles to fill the chip)
@@ -1035,6 +1148,8 @@ class DiffusionEngine:
         if self.shard_world > 1:
             import torch.distributed as dist
             dist.all_reduce(sums, group=self.shard_group)
+        if sh is not None:
+            sh.all_reduce(sums)
         if not host_means and precision == 1:
             means = sums / Bg
             if B:  # 1 / (Bg * sum(means)) = 1 / sum(sums)
@@ -1042,6 +1157,8 @@ class DiffusionEngine:
             else:
                 for m in range(M):
                     ops.zero_(self.P[m].grad)
+            if sh is not None and B:
+                self._sync_replicated_grads()
             if update:
                 for m in range(M):
                     self.reduce_and_step(m)
@@ -1058,6 +1175,8 @@ class DiffusionEngine:
         else:
             for m in range(M):
                 ops.zero_(self.P[m].grad)
+        if sh is not None and B:
+            self._sync_replicated_grads()
         if update:
             for m in range(M):
                 self.reduce_and_step(m)
@@ -1097,10 +1216,26 @@ class DiffusionEngine:
                                           dict(A=self.w1_16[m], B=lat["w2Tlo"], out=T3[2])])
                 ops.add_inplace(T3[1], T3[2])
                 ops.add_inplace(T3[0], T3[1])
-                ops.cast_bf16(T3[0], lat["G16"][m])
                 ops.gemv_rows(W1, b2, lat["g"][m], cols=self.I)
-                ops.zero_(lat["b2_last"][m])
-                ops.add_inplace(lat["b2_last"][m], b2, float(self.c1[0]))
+                sh = self.ishard
+                if sh is not None:  # G = sum over the replicas' item slices of W1x[:, I_g] W2[I_g, :] (fp32, before its one rounding); g likewise
+                    sh.all_reduce(T3[0])
+                    sh.all_reduce(lat["g"][m])
+                ops.cast_bf16(T3[0], lat["G16"][m])
+                if sh is None:
+                    ops.zero_(lat["b2_last"][m])
+                    ops.add_inplace(lat["b2_last"][m], b2, float(self.c1[0]))
+                else:  # every replica's slice padded to S rows, gathered in rank order: item i sits in row i of the assembled operands
+                    s16, s32, I = lat["send16"], lat["send32"], self.I
+                    ops.zero_(s32)
+                    ops.add_inplace(s32[:I], b2, float(self.c1[0]))
+                    sh.all_gather(lat["b2_last"][m], s32)
+                    if I < sh.S:
+                        ops.zero_(s16[I:])
+                    s16[:I].copy_(self._w1T_chain[m][:I])
+                    sh.all_gather(lat["w1T_full"][m], s16)
+                    s16[:I].copy_(self.w2_16[m][:I])
+                    sh.all_gather(lat["w2_full"][m], s16)
             self.w16_step[m] = P.step
 
     # -- latent reverse chain ---------------------------------------------------------------------------
@@ -1144,7 +1279,7 @@ class DiffusionEngine:
         z = lambda *s_: torch.zeros(s_, dtype=torch.float32, device=self.dev)
         zb = lambda *s_: torch.zeros(s_, dtype=torch.bfloat16, device=self.dev)
         self._lat = dict(za=[z(R, H) for _ in range(M)], zb=[z(R, H) for _ in range(M)], hb=[zb(R, H) for _ in range(M)], G32=z(3, H, H),
-                         G16=[zb(H, H) for _ in range(M)], g=[z(H) for _ in range(M)], b2_last=[z(I) for _ in range(M)],
+                         G16=[zb(H, H) for _ in range(M)], g=[z(H) for _ in range(M)], b2_last=[z(self._chain_item_rows()) for _ in range(M)],
                          w1lo=zb(H, self.Kp), w2Thi=zb(H, self.Kp), w2Tlo=zb(H, self.Kp),  # (scratch of the once-per-epoch G refresh)
                          flags=torch.zeros(514, dtype=torch.int32, device=self.dev))
         # per-step scalars of the persistent kernel (fp64 on the host, then fp32): coef[2 i] = c1[i], coef[2 i + 1] = c2[i-1] c1[i] / c1[i-1]
@@ -1158,7 +1293,21 @@ class DiffusionEngine:
             self._w1T_chain = [zb(self.Kp, H) for _ in range(M)]
             self._b2_first = [z(I) for _ in range(M)]
             self._csr_users = torch.zeros(R, dtype=torch.int64, device=self.dev)
+        if self.ishard is not None:  # the rebuild runs on the replica's own USERS over ALL items: bf16 W1x^T / W2 assembled from the replicas' slices
+            n = self._chain_item_rows()
+            self._lat["w1T_full"], self._lat["w2_full"] = [zb(n, H) for _ in range(M)], [zb(n, H) for _ in range(M)]
+            self._lat["send16"], self._lat["send32"] = zb(self.ishard.S, H), z(self.ishard.S)
         self.w16_step = [-1] * M
+
+    def _chain_item_rows(self) -> int:
+        """Rows of the chain's item-indexed operands: I, or world x S (every replica's slice padded to S rows) when the Denoise is item-sharded."""
+        return self.I if self.ishard is None else self.ishard.world * self.ishard.S
+
+    def _chain_w1T(self, m: int) -> Tensor:
+        return self._w1T_chain[m] if self.ishard is None else self._lat["w1T_full"][m]
+
+    def _chain_w2(self, m: int) -> Tensor:
+        return self.w2_16[m] if self.ishard is None else self._lat["w2_full"][m]
 
     def generate_views_latent(self, rows: Optional[CsrRows] = None, xT=None, B: Optional[int] = None, mods: Optional[Sequence[int]] = None) -> List[Tensor]:
         """The reverse chain (GaussianDiffusion.p_sample without sampling noise, Model.py:300-322) in the H-dimensional space of layer 1's
@@ -1193,6 +1342,8 @@ class DiffusionEngine:
             self._csr_users[:B].copy_(rows.users)
             key = ("latent-csr", B, rows.ptr.data_ptr(), rows.col.data_ptr(), tuple(mods))
         else:
+            if self.ishard is not None:
+                raise ValueError("item-sharded Denoise: the rebuild starts from CSR rows (sampling_step = 0); a dense x_T would need all item columns")
             if B > self.dense_rows_max:
                 raise ValueError(f"latent chain: a dense start of {B} rows > {self.dense_rows_max} (lean chain buffers keep B_max rows)")
             for m, x in zip(mods, xT):  # fp32 staging; cast to the bf16 operand inside the plan
@@ -1208,7 +1359,7 @@ class DiffusionEngine:
                 if rows is not None:
                     users = self._csr_users[:B]
                     for m in mods:
-                        ops.csr_gather_sum_latent(rows.ptr, rows.col, users, self._w1T_chain[m], self.bias_t[m][T - 1], z[m], h[m])
+                        ops.csr_gather_sum_latent(rows.ptr, rows.col, users, self._chain_w1T(m), self.bias_t[m][T - 1], z[m], h[m])
                 else:
                     for m in mods:
                         ops.cast_bf16(self.cxb[m][:B], self.cxa16[m][:B], cols=I, cols_pad=self.Kp)  # temb / pad columns zero: temb enters through bias_t
@@ -1231,13 +1382,13 @@ class DiffusionEngine:
     def _latent_views(self, h0: Dict[int, Tensor], r0: int, r1: int, mods: Sequence[int]) -> List[Tensor]:
         """Last step of the latent chain for rows r0 .. r1 of h_0: x_0' = c1[0] (h_0 W2^T + b2), the ONE item-sized GEMM of the chain, into the
         first r1 - r0 rows of the view buffers (valid until the next call)."""
-        n, I, lat = r1 - r0, self.I, self._lat
+        n, I, lat = r1 - r0, self.I_chain, self._lat
         assert 0 < n <= self.view_rows
         key = ("latent-view", n, tuple(mods), tuple(int(h0[m].data_ptr()) for m in mods), r0)
         plan = self._view_plans.get(key)
         if plan is None:
             with L.Recorder() as plan:
-                ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h0[m][r0:r1]), B=self.w2_16[m], out=self.cxa[m][:n], bias=lat["b2_last"][m],
+                ops.gemm_bf16_nt_batched([dict(A=self._mids_chain(m, h0[m][r0:r1]), B=self._chain_w2(m), out=self.cxa[m][:n], bias=lat["b2_last"][m],
                                                alpha=float(self.c1[0]), N=I) for m in mods])
             if len(self._view_plans) > 256:
                 self._view_plans.clear()
@@ -1459,7 +1610,7 @@ class DiffusionEngine:
         M = self.M
         if M == 1 or self.dev.type != "cuda":
             for m in range(M):
-                ops.topk_rows(views[m], row_ids, deg_ptr, out[m], self.I)
+                ops.topk_rows(views[m], row_ids, deg_ptr, out[m], self.I_chain)
             return
         if not hasattr(self, "_side_streams"):
             self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
@@ -1470,7 +1621,7 @@ class DiffusionEngine:
             st = self._side_streams[m]
             st.wait_event(self._side_events[M])
             with torch.cuda.stream(st):
-                ops.topk_rows(views[m], row_ids, deg_ptr, out[m], self.I)
+                ops.topk_rows(views[m], row_ids, deg_ptr, out[m], self.I_chain)
                 self._side_events[m].record(st)
             main.wait_event(self._side_events[m])
 
@@ -1513,7 +1664,7 @@ class DiffusionEngine:
                     r1 = min(n, r0 + self.view_rows)
                     views = self._latent_views(h0, r0, r1, range(self.M))
                     for m in range(self.M):
-                        ops.topk_rows(views[m], ub32[r0:r1], deg_ptr, out[m], self.I)
+                        ops.topk_rows(views[m], ub32[r0:r1], deg_ptr, out[m], self.I_chain)
                 continue
             if self.lean:
                 raise ValueError("DiffusionEngine: the stepwise reverse chain needs full [chain_rows, I] buffers (this engine keeps lean ones: latent chain only)")

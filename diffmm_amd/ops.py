@@ -543,12 +543,12 @@ def qsample_temb_bits(x0bits: Tensor, noise: Optional[Tensor], t: Tensor, sqrt_a
            L.ptr(b_emb), te, L.ptr(xcat), xcat.stride(0), B, I, int(draw_noise), seed, offset, L.ptr(eps_out), L.stream())
 
 
-def csr_row_bits(ptr: Tensor, col: Tensor, rows: Tensor, I: int, bits: Tensor) -> None:
-    """bits[b, w] bit k = 1 iff item 32 w + k is an interaction of user rows[b]; bits int32 [B, ld >= ceil(I / 32)], whole rows written."""
+def csr_row_bits(ptr: Tensor, col: Tensor, rows: Tensor, I: int, bits: Tensor, col_lo: int = 0) -> None:
+    """bits[b, w] bit k = 1 iff item col_lo + 32 w + k is an interaction of user rows[b]; bits int32 [B, ld >= ceil(I / 32)], whole rows written."""
     p, c, r, B = _csr_args(ptr, col, rows)
     if bits.dtype != torch.int32 or bits.stride(1) != 1 or bits.shape[0] < B or bits.shape[1] * 32 < I:
         raise ValueError("csr_row_bits: bits must be int32 [B, >= ceil(I / 32)]")
-    L.call("dmm_csr_row_bits", p, c, r, B, I, L.ptr(bits), bits.stride(0), L.stream())
+    L.call("dmm_csr_row_bits_slice", p, c, r, B, int(col_lo), I, L.ptr(bits), bits.stride(0), L.stream())
 
 
 def diff_loss_bits(out: Tensor, x0bits: Tensor, w: Tensor, um: Tensor, ui: Tensor, I: int, sim_weight: float, reg_term: float, loss: Tensor) -> None:
@@ -566,13 +566,13 @@ def _csr_args(ptr: Tensor, col: Tensor, rows: Tensor):
     return L.ptr(ptr), L.ptr(col), L.ptr(rows), int(rows.shape[0])
 
 
-def csr_dense_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, out: Tensor) -> Tensor:
-    """out[b, :] = 0/1 interaction row of user rows[b] (whole leading dimension written: columns >= I are zero)."""
+def csr_dense_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, out: Tensor, col_lo: int = 0) -> Tensor:
+    """out[b, :] = 0/1 interaction row of user rows[b] over the items col_lo .. col_lo + I - 1 (whole leading dimension written: columns >= I are zero)."""
     p, c, r, B = _csr_args(ptr, col, rows)
     if out.dtype != torch.float32 or out.stride(1) != 1 or out.shape[0] < B or out.shape[1] < I or out.stride(0) % 4 or out.shape[1] != out.stride(0):
         raise ValueError("csr_dense_rows: out must be fp32 [>= B, ld] with ld % 4 == 0, written over its whole width")
     if B:
-        L.call("dmm_csr_dense_rows", p, c, r, B, I, L.ptr(out), out.stride(0), L.stream())
+        L.call("dmm_csr_dense_rows_slice", p, c, r, B, int(col_lo), I, L.ptr(out), out.stride(0), L.stream())
     return out
 
 
@@ -634,6 +634,16 @@ def zero_(t: Tensor) -> None:
     if not t.is_contiguous():
         raise ValueError("zero_: contiguous tensors only")
     L.call("dmm_fill_zero", L.ptr(t), t.numel() * t.element_size(), L.stream())
+
+
+def bias_tanh_rows(x: Tensor, bias: Tensor, out16: Optional[Tensor] = None) -> None:
+    """x = tanh(x + bias) in place on a contiguous fp32 [rows, cols]; out16: its bf16 copy (contiguous, same shape)."""
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 2 or bias.numel() != x.shape[1] or x.shape[1] % 4:
+        raise ValueError("bias_tanh_rows: x contiguous fp32 [rows, cols % 4 == 0], bias [cols]")
+    if out16 is not None and (out16.dtype != torch.bfloat16 or not out16.is_contiguous() or out16.shape != x.shape):
+        raise ValueError("bias_tanh_rows: out16 must be contiguous bf16 of x's shape")
+    if x.shape[0]:
+        L.call("dmm_bias_tanh_rows", L.ptr(x), L.ptr(_f32c(bias, "bias")), x.shape[0], x.shape[1], L.ptr(out16) if out16 is not None else None, L.stream())
 
 
 def tanh_bwd(dh: Tensor, h: Tensor, dpre: Tensor) -> None:

@@ -320,10 +320,14 @@ int dmm_qsample_temb(const float* x0, int64_t ldx0, const float* noise, const in
  *   dmm_csr_add_rows         y[b, j] += c (and y16[b, j] = bf16 of it) for j in items(rows[b]): the posterior-mean residual c2 * x_0 of that step
  *                            (Model.py:375) without a dense x_0; y == NULL: the row is kept in bf16 only (y16 read and written). */
 int dmm_csr_dense_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, float* out, int64_t ldo, void* stream);
+/* the same for a slice of the item columns: items col_lo .. col_lo + I - 1 become columns 0 .. I - 1 (item-sharded Denoise: a replica holds the
+ * W1 columns / W2 rows of its item slice and reads x_0 restricted to it) */
+int dmm_csr_dense_rows_slice(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int col_lo, int I, float* out, int64_t ldo, void* stream);
 /* x_0 rows as BIT MASKS: bits[b, w] bit k = 1 iff item 32 w + k is an interaction of user rows[b] (ldb words per row, ldb * 32 >= I; the words'
  * unused bits are zero).  The training step's three readers of the dense 0/1 rows take the masks instead -- 1/32 of the bytes:
  * dmm_qsample_temb_bits, dmm_diff_loss_bits (forward loss), dmm_item_expand_fused mode 1 (X0bits). */
 int dmm_csr_row_bits(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int I, uint32_t* bits, int64_t ldb, void* stream);
+int dmm_csr_row_bits_slice(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, int col_lo, int I, uint32_t* bits, int64_t ldb, void* stream);
 int dmm_qsample_temb_bits(const uint32_t* x0bits, int64_t ldb, const float* noise, const int32_t* t, const float* sqrt_ac, const float* sqrt_1mac,
                           const float* w_emb, const float* b_emb, int te, float* xcat, int64_t ldx, int B, int I, int draw_noise, uint64_t seed,
                           uint64_t offset, float* eps_out, void* stream);
@@ -351,6 +355,9 @@ int dmm_mul_sigmoid_fwd(const float* proj, const float* gate_pre_sig /*sigmoid a
 int dmm_gate_bwd(const float* dout, const float* proj, const float* gate, float* dproj /*out: dout*gate*/,
                  float* dgate_pre /*out: dout*proj*gate*(1-gate)*/, int64_t n, void* stream);
 int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* stream); /* dpre = dh * (1 - h^2) */
+/* x = tanh(x + bias[col]) in place on a contiguous fp32 [rows, cols] (cols % 4 == 0), out16 (optional): its bf16 copy.  Denoise layer 1's activation
+ * (Model.py:212) applied AFTER the item-sliced partial products x_t[:, I_g] W1[:, I_g]^T have been summed over the replicas. */
+int dmm_bias_tanh_rows(float* x, const float* bias, int rows, int cols, void* out16 /*bf16 [rows, cols] or NULL*/, void* stream);
 int dmm_add_inplace(float* y, const float* x, float alpha, int64_t n, void* stream);   /* y += alpha * x */
 int dmm_fill_zero(void* p, int64_t bytes, void* stream);                                /* hipMemsetAsync(p, 0, bytes) */
 int dmm_colsum(const float* x, int64_t ldx, int rows, int cols, float* out /*[cols], overwritten*/, void* stream);

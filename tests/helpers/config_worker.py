@@ -31,6 +31,7 @@ def run_config(conf: str, latdim: int, T: int, batch: int, epochs: int, rank: in
         out["epochs"].append({"train": {k: float(v) for k, v in res.items()}, "test": {k: float(v) for k, v in tst.items()},
                               "modal_nnz": [int(a.nnz) for a in adjs], "phase_s": list(coach.phase_seconds)})
     out["sampling_step"] = int(cfg.hyper.sampling_step)
+    out["denoise_shard"] = "items" if getattr(coach, "item_shard", None) is not None else "rows"
     return out
 
 

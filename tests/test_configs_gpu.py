@@ -33,6 +33,15 @@ def _check(out, epochs):
         assert 0.0 < e["test"]["Recall"] < 1.0 and 0.0 < e["test"]["NDCG"] < 1.0 and 0.0 < e["test"]["Precision"] < 1.0
 
 
+_SPORTS = {}
+
+
+def _single_sports():
+    if "out" not in _SPORTS:  # (one single-GPU epoch serves both parametrisations)
+        _SPORTS["out"] = run_config("sports", 128, 200, 8192, 1)
+    return _SPORTS["out"]
+
+
 def test_baby_shape_two_epochs():
     need_gpu()
     out = run_config("baby", 64, 40, 4096, 2)
@@ -45,21 +54,25 @@ def test_baby_shape_two_epochs():
     assert b["train"]["Loss"] < a["train"]["Loss"] and b["test"]["Recall"] > 0.5 * a["test"]["Recall"]
 
 
-def test_sports_shape_single_and_user_sharded():
+@pytest.mark.parametrize("denoise_shard", ["rows", "items"])
+def test_sports_shape_single_and_user_sharded(denoise_shard):
+    """denoise_shard: how the replicas split the Denoise MLPs (Main.Coach._denoise_item_shard): "rows" -- replicated weights, own users' minibatch rows,
+    gradient all-reduce; "items" -- every replica holds the W1 columns / W2 rows of its item slice and exchanges [B, H] partial activations."""
     need_gpu()
-    single = run_config("sports", 128, 200, 8192, 1)
+    single = _single_sports()
     assert (single["users"], single["items"], single["M"]) == (35598, 18357, 2)
     _check(single, 1)
     N = single["users"] + single["items"]
     assert single["epochs"][0]["modal_nnz"] == [2 * single["E"] + N] * 2
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "out.json")
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_DENOISE_SHARD=denoise_shard)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
                str(29950 + os.getpid() % 40), os.path.join(REPO, "tests", "helpers", "config_worker.py"), "sports", "128", "200", "8192", "1", path]
         p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=1500)
         assert p.returncode == 0, p.stderr[-4000:]
         shard = json.load(open(path))
+    assert shard["denoise_shard"] == denoise_shard
     _check(shard, 1)
     assert shard["modal_nnz_sum_over_replicas"] == [2 * single["E"] + N] * 2, "the replicas' blocks hold every entry of the rebuilt graphs exactly once"
     s, d = single["epochs"][0], shard["epochs"][0]

@@ -125,3 +125,15 @@ def test_two_replicas_reproduce_epilogue_and_row_split_step():
         assert np.allclose(yu, y[u0:u1], rtol=1e-12, atol=1e-12) and np.allclose(ypu, yp[u0:u1], rtol=1e-12, atol=1e-12)
         assert np.allclose(yi, y[U:], rtol=1e-12, atol=1e-12) and np.allclose(ypi, yp[U:], rtol=1e-12, atol=1e-12)
         assert abs(m - mean) <= 1e-12 * mean and np.allclose(gsum, grad, rtol=1e-12, atol=1e-12)
+
+
+def test_item_shard_slices_partition_the_items():
+    """ItemShard (item-sharded Denoise): slices of S = ceil(I / world) items in rank order, the last one shorter, never empty; item i sits in row i
+    of the operands assembled from the replicas' S-row blocks."""
+    from diffmm_amd.engine import ItemShard
+    for I, W in ((6710, 8), (18357, 2), (1000000, 8), (17, 3), (9, 2)):
+        sl = [ItemShard(r, W, I) for r in range(W)]
+        assert sl[0].i0 == 0 and sl[-1].i1 == I and all(a.i1 == b.i0 for a, b in zip(sl, sl[1:]))
+        assert all(0 < s.items_local <= s.S for s in sl) and all(s.i0 == s.rank * s.S for s in sl)
+    with pytest.raises(ValueError):
+        ItemShard(0, 8, 9)  # ceil(9 / 8) = 2 items per slice leave the last replicas without items
