@@ -81,9 +81,17 @@ class TrainData:
         self._cols_d = torch.from_numpy(self.cols).to(self.device)
         self._negs_d = torch.zeros(len(self.rows), dtype=torch.int32, device=self.device)
         self._rows64 = None  # user id * item_num as int64 keys (device), built by the first negSampling()
-        order = np.argsort(self.rows, kind="stable")
-        ptr = np.searchsorted(self.rows[order], np.arange(int(config.data.user_num) + 1))
-        self.user_pos_items: List[np.ndarray] = [self.cols[order[ptr[u]:ptr[u + 1]]] for u in range(int(config.data.user_num))]
+        self._user_pos_items: Optional[List[np.ndarray]] = None
+
+    @property
+    def user_pos_items(self) -> List[np.ndarray]:
+        """Per-user arrays of train items (the reference's attribute, DataHandler.py:152-157); built on first access -- nothing on the training path
+        reads it, and a Python list per user is minutes of host time at 10M users."""
+        if self._user_pos_items is None:
+            order = np.argsort(self.rows, kind="stable")
+            ptr = np.searchsorted(self.rows[order], np.arange(int(self.config.data.user_num) + 1))
+            self._user_pos_items = [self.cols[order[ptr[u]:ptr[u + 1]]] for u in range(int(self.config.data.user_num))]
+        return self._user_pos_items
 
     @property
     def negs(self) -> np.ndarray:
@@ -146,7 +154,7 @@ class TestData:
         r, c = np.asarray(tst_rows)[order], np.asarray(tst_cols)[order]
         self.test_users = np.unique(r)
         ptr = np.searchsorted(r, np.arange(users + 1))
-        self.test_user_its: List[Optional[list]] = [list(c[ptr[u]:ptr[u + 1]]) if ptr[u + 1] > ptr[u] else None for u in range(users)]
+        self._its_src, self._test_user_its = (c, ptr), None
         self._tst_ptr = torch.from_numpy(ptr.astype(np.int64)).to(self.device)
         self._tst_col = torch.from_numpy(c.astype(np.int64)).to(self.device)
         # train interactions as CSR over users, for the score mask
@@ -155,6 +163,14 @@ class TestData:
         self._trn_col = torch.from_numpy(np.asarray(trn_cols)[o2].astype(np.int64)).to(self.device)
         self._users_d = torch.from_numpy(self.test_users.astype(np.int64)).to(self.device)
         self._users_i32 = self._users_d.to(torch.int32)
+
+    @property
+    def test_user_its(self) -> List[Optional[list]]:
+        """Per-user lists of test items (the reference's attribute, DataHandler.py:186-199), built on first access: the evaluation reads the CSR."""
+        if self._test_user_its is None:
+            c, ptr = self._its_src
+            self._test_user_its = [list(c[ptr[u]:ptr[u + 1]]) if ptr[u + 1] > ptr[u] else None for u in range(self.users)]
+        return self._test_user_its
 
     def __len__(self) -> int:
         return len(self.test_users)
@@ -261,7 +277,10 @@ class DataHandler:
             return synth.named(self.config.data.name, seed=int(self.config.base.seed))
         raise ValueError(f"Unknown dataset: {self.config.data.name} (no {self.bundle} and no synthetic shape of that name)")
 
-    def LoadData(self, graph_data: Optional[synth.SynthGraph] = None) -> None:
+    def LoadData(self, graph_data: Optional[synth.SynthGraph] = None, sharded: bool = False) -> None:
+        """sharded = True (one process per GPU, users sharded): the full-graph adjacency is not built -- every replica plans its own local block
+        (Coach.prepareModel) -- and `graph_data` may hold the interactions of the replica's own users only (synth.make_graph(user_lo=, user_hi=):
+        a per-shard load; the minibatch loaders of such a partial load see the own users' interactions)."""
         import scipy.sparse as sp
         g = graph_data if graph_data is not None else self._read()
         cfg, dev = self.config, self.device
@@ -272,8 +291,8 @@ class DataHandler:
         # bf16 gather operands for graphs whose operand outgrows the caches (graph.spmm_operand_vec; the user-sharded engine plans its own
         # local blocks, fp32)
         self.spmm_vec = graph.spmm_operand_vec(U + I, int(cfg.base.latdim))
-        self.torchBiAdj = graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev, vec=self.spmm_vec,
-                                               task_len=graph.spmm_task_len(self.spmm_vec))
+        self.torchBiAdj = None if sharded else graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev, vec=self.spmm_vec,
+                                                                    task_len=graph.spmm_task_len(self.spmm_vec))
         self.trainData = TrainData(g.trn_rows, g.trn_cols, cfg, dev)
         self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 1)
         self.testData = TestData(g.tst_rows, g.tst_cols, g.trn_rows, g.trn_cols, U, I, dev)
@@ -285,7 +304,10 @@ class DataHandler:
             self.audio_feats, cfg.data.audio_feat_dim = f[2], int(f[2].shape[1])
         self.diffusionData = DiffusionData(g.trn_rows, g.trn_cols, U, I, dev)
         self.diffusionLoader = BatchLoader(self.diffusionData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 2)
-        self.user_pos_items = self.trainData.user_pos_items
+
+    @property
+    def user_pos_items(self):
+        return self.trainData.user_pos_items
 
     def getUserDegrees(self) -> np.ndarray:
         if not hasattr(self, "trainMat"):

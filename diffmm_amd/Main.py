@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import graph, ops
+from . import comm, graph, ops
 from .Conf import Config, load_config
 from .DataHandler import DataHandler
 from .Model import Denoise, GaussianDiffusion, Model, denoise_dims, hyper_dict
@@ -34,18 +34,24 @@ def _log(msg: str) -> None:
 
 
 class Coach:
-    def __init__(self, handler: DataHandler, config: Config, precision: int = 1, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, handler: DataHandler, config: Config, precision: int = 1, rank: int = 0, world: int = 1, group=None, layout=None,
+                 emulate_replica: bool = False):
         """precision: 1 = single bf16 MFMA product in the dense GEMMs (fast path), 3 = hi/lo split (~fp32, parity tests).
         world > 1: one process per GPU (torch.distributed initialised by the caller; backend 'nccl' == RCCL); the users are sharded over
-        the replicas (diffmm_amd/sharded.py), every epoch makes exactly the reference's optimiser steps on the reference's minibatches."""
+        the replicas (diffmm_amd/sharded.py), every epoch makes exactly the reference's optimiser steps on the reference's minibatches.
+        layout: a sharded.ShardLayout to use instead of the edge-balanced one computed from the handler's graph (a per-shard load holds only the
+        own users' interactions).  emulate_replica (tools/scale_epoch.py): ONE process runs replica `rank` of `world` with every collective
+        reduced to its local part (no process group is needed) -- the per-GPU work and memory of a job this box has no GPUs for."""
         self.handler, self.config, self.precision = handler, config, precision
         self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
         _log(f"USER: {config.data.user_num}, ITEM: {config.data.item_num}")
         _log(f"NUM OF INTERACTIONS: {len(handler.trainData)}")
         self.epoch_idx = 0
         self.world, self.rank, self.group = int(world), int(rank), group
-        self.layout = None
-        if self.world > 1:
+        self.layout = layout
+        if emulate_replica:
+            self.group = comm.LOCAL
+        if self.world > 1 and layout is None:
             from .sharded import ShardLayout
             self.layout = ShardLayout.make(handler.graph.trn_rows, int(config.data.user_num), int(config.data.item_num), self.world, self.rank)
         self.phase_seconds = [0.0, 0.0, 0.0]
@@ -287,8 +293,7 @@ class Coach:
             acc += J.step(users, pos, neg, noise=noise, precision=prec)
         nT = J.n_terms
         if lay is not None:  # [terms..., bpr, reg over the own users, reg over the items]: only the user part is a partial sum
-            import torch.distributed as dist
-            dist.all_reduce(acc[nT + 1:nT + 2], group=self.group)
+            comm.all_reduce(acc[nT + 1:nT + 2], group=self.group)
             acc = torch.cat([acc[:nT + 1], acc[nT + 1:nT + 2] + acc[nT + 2:nT + 3]])
         a = acc.cpu().numpy()
         if lay is not None:
@@ -305,15 +310,14 @@ class Coach:
         """User-sharded runs: the replicated parameters (item embeddings, projections, modal_weight, every Denoise) and their Adam state
         must be bit-identical on all replicas -- they only ever receive all-reduced gradients (sharded.py).  One pass over them per epoch:
         a 64-bit sum of their bit patterns, MIN and MAX over the replicas must agree.  A mismatch raises on every replica."""
-        import torch.distributed as dist
         J, DE = self.model.engine, self.diff_engine
         lo = J.nu * J.D
         nr = DE.n_replicated if self.item_shard is not None else None  # item-sharded Denoise: only the small tensors are replicated
         parts = [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t[:nr] for p in DE.P for t in (p.data, p.m, p.v)]
         sums = torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in parts])
         mn, mx = sums.clone(), sums.clone()
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        comm.all_reduce(mn, op="MIN", group=self.group)
+        comm.all_reduce(mx, op="MAX", group=self.group)
         if not bool((mn == mx).all()):
             bad = (mn != mx).nonzero().flatten().tolist()
             raise RuntimeError(f"user-sharded run: replicated state differs between the replicas (checksum groups {bad}; 0-2 = joint model data/m/v, "
@@ -351,8 +355,7 @@ class Coach:
             top = ops.eval_topk(sc, u32, td._trn_ptr, td._trn_col, k)
             total += ops.eval_metrics(top, u32, td._tst_ptr, td._tst_col).sum(0)  # calcRes on the device; one host read at the end
         if lay is not None:
-            import torch.distributed as dist
-            dist.all_reduce(total, group=self.group)
+            comm.all_reduce(total, group=self.group)
         rec, ndcg, prec = (total / len(td)).tolist()
         return {"Recall": rec, "NDCG": ndcg, "Precision": prec}
 
@@ -411,7 +414,7 @@ def main(argv=None) -> None:
         dist.init_process_group(os.environ.get("DMM_BACKEND", "nccl"))
     handler = DataHandler(config)
     _log("Load Data")
-    handler.LoadData()
+    handler.LoadData(sharded=world > 1)
     Coach(handler, config, precision=args.precision, rank=rank, world=world).run(resume=args.resume, save=args.save)
 
 

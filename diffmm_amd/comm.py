@@ -1,0 +1,30 @@
+"""Collectives of the user-sharded path (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the tests).
+One indirection so that ONE process can run a single replica of a larger job with every collective reduced to its local part (`LOCAL` as the
+group: tools/scale_epoch.py --emulate-world, the per-GPU work and memory of a job the box has no GPUs for).  Nothing here computes."""
+from __future__ import annotations
+
+import torch
+
+LOCAL = "local"  # stand-in group of an emulated replica
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_reduce(t: torch.Tensor, group=None, op=None, async_op: bool = False):
+    if group is LOCAL:
+        return _Done() if async_op else None
+    import torch.distributed as dist
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else getattr(dist.ReduceOp, op), group=group, async_op=async_op)
+
+
+def all_gather_into(out: torch.Tensor, t: torch.Tensor, rank: int, group=None) -> None:
+    """out [world * n, ...] <- every replica's t [n, ...] in rank order (LOCAL: the own block only)."""
+    if group is LOCAL:
+        n = t.shape[0]
+        out[rank * n:(rank + 1) * n].copy_(t)
+        return
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(out, t, group=group)

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import ops
+from . import comm, ops
 from .graph import Adjacency
 
 Tensor = torch.Tensor
@@ -71,10 +71,10 @@ class ItemShard:
     """Item-sharded Denoise ("sharding the Denoise I dimension -- K-split layer 1 / N-split layer 2 with items partitioned").  Replica
     `rank` of `world` holds the W1 columns, W2 rows, b2 entries (and their gradients / Adam state) of the items i0 .. i1 - 1, a slice of
     S = ceil(I / world) items (the last one may be shorter); the small tensors (time-embedding layer, b1, W1's time-embedding columns, gate layer)
-    are replicated.  emulate = True: a single process runs ONE replica's work with the collectives skipped (timing / memory tools only)."""
+    are replicated.  group = comm.LOCAL: a single process runs ONE replica's work with the collectives skipped (timing / memory tools only)."""
 
-    def __init__(self, rank: int, world: int, items_global: int, group=None, emulate: bool = False):
-        self.rank, self.world, self.items_global, self.group, self.emulate = int(rank), int(world), int(items_global), group, bool(emulate)
+    def __init__(self, rank: int, world: int, items_global: int, group=None):
+        self.rank, self.world, self.items_global, self.group = int(rank), int(world), int(items_global), group
         self.S = -(-self.items_global // self.world)
         self.i0, self.i1 = min(self.rank * self.S, self.items_global), min((self.rank + 1) * self.S, self.items_global)
         if (self.world - 1) * self.S >= self.items_global:
@@ -85,18 +85,12 @@ class ItemShard:
         return self.i1 - self.i0
 
     def all_reduce(self, t: Tensor) -> None:
-        if self.world > 1 and not self.emulate:
-            import torch.distributed as dist
-            dist.all_reduce(t, group=self.group)
+        if self.world > 1:
+            comm.all_reduce(t, group=self.group)
 
     def all_gather(self, out: Tensor, t: Tensor) -> None:
-        """out [world * n, ...] <- every replica's t [n, ...] in rank order (emulation: the own block only)."""
-        if self.world > 1 and not self.emulate:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(out, t, group=self.group)
-        else:
-            n = t.shape[0]
-            out[self.rank * n:(self.rank + 1) * n].copy_(t)
+        """out [world * n, ...] <- every replica's t [n, ...] in rank order."""
+        comm.all_gather_into(out, t, self.rank, group=self.group if self.world > 1 else comm.LOCAL)
 
 
 class FlatParams:
@@ -1146,8 +1140,7 @@ class DiffusionEngine:
                     self.loss_forward(m, x0p, ts[m], noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
             sums = self._loss_block[:, :B].sum(1)
         if self.shard_world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=self.shard_group)
+            comm.all_reduce(sums, group=self.shard_group)
         if sh is not None:
             sh.all_reduce(sums)
         if not host_means and precision == 1:
@@ -1186,8 +1179,7 @@ class DiffusionEngine:
     def reduce_and_step(self, m: int):
         P = self.P[m]
         if self.shard_world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(P.grad, group=self.shard_group)  # sum: every replica's rows carry the 1 / (global batch) scale already
+            comm.all_reduce(P.grad, group=self.shard_group)  # sum: every replica's rows carry the 1 / (global batch) scale already
         P.step += 1
         ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step)
 

@@ -55,7 +55,28 @@ class Plan:
     fix: "np.ndarray"
 
 
-def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False, full: bool = False):
+def hub_keys(rowptr: np.ndarray, col: np.ndarray) -> np.ndarray:
+    """Locality key of every row: the id of its highest-degree neighbour (its "hub"; the self loop does not count, rows without neighbours keep
+    their own id).  Rows that share a hub -- users around one popular item, items around one heavy user -- gather overlapping sets of X rows;
+    plan_tasks(row_key=...) schedules them next to each other so that those rows are still in the XCD's L2."""
+    rp = np.asarray(rowptr, dtype=np.int64)
+    n = rp.shape[0] - 1
+    c = np.asarray(col, dtype=np.int64)
+    deg = rp[1:] - rp[:-1]
+    nzrow = np.repeat(np.arange(n, dtype=np.int64), deg)
+    w = deg[c].copy()
+    w[c == nzrow] = -1
+    idx = np.lexsort((c, w, nzrow))  # per row: ascending neighbour degree (ties: larger id last)
+    last = rp[1:] - 1
+    key = np.arange(n, dtype=np.int64)
+    has = deg > 0
+    key[has] = c[idx[last[has]]]
+    lone = has & (w[idx[np.maximum(last, 0)]] < 0)  # only the self loop
+    key[lone] = np.flatnonzero(lone)
+    return key
+
+
+def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False, full: bool = False, row_key: Optional[np.ndarray] = None):
     """Work list for dmm_spmm_csr_f32.
 
     A workgroup of the kernel holds G = 1024 / D task groups.  Rows with at most `task_len` non-zeros are one task.  Longer
@@ -63,6 +84,8 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
     through LDS in task order): k is rounded up to a power of two and runs are placed largest first, so every run is aligned to
     its own size and never straddles a workgroup.  Still longer ("giant") rows are cut into segments of 2 G task_len non-zeros,
     one full workgroup each; the segment partials are added in order by a second pass.  Padding tasks have row = -1.
+    row_key (optional, one integer per row): rows are scheduled in ascending key order (ties: row order) instead of row order -- any order
+    is valid, a task names its row; see hub_keys.
     """
     G = 1024 // D
     if G * D != 1024 or D % 4:
@@ -107,7 +130,7 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
         fix = np.stack([giant, first, nseg, np.zeros_like(giant)], axis=1).astype(np.int32)
     if multi.size:
         kp = 1 << np.ceil(np.log2(k[multi])).astype(np.int64)  # slots reserved per run (power of two <= G)
-        order = np.argsort(-kp, kind="stable")
+        order = np.argsort(-kp, kind="stable") if row_key is None else np.lexsort((np.asarray(row_key)[multi], -kp))
         multi, kp = multi[order], kp[order]
         km = np.minimum(kp, G)
         start = np.concatenate([[0], np.cumsum(km)[:-1]])
@@ -132,6 +155,8 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
         parts.append(t)
     head = int(sum(p.shape[0] for p in parts))  # segments + split rows come first
     if single.size:
+        if row_key is not None:
+            single = single[np.argsort(np.asarray(row_key)[single], kind="stable")]
         t = np.stack([single, rp[single], rp[single + 1], np.ones_like(single)], axis=1)
         pad = (-t.shape[0]) % G
         if pad:
@@ -232,18 +257,20 @@ def spmm_task_len(vec: int) -> int:
 
 
 def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
-                   keep_host: bool = False, vec: int = 4) -> Adjacency:
+                   keep_host: bool = False, vec: int = 4, hub_order: bool = False) -> Adjacency:
+    """hub_order: schedule the rows by their hub (hub_keys) instead of by row id."""
     rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)
-    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host, vec)
+    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host, vec, row_key=hub_keys(rowptr, col) if hub_order else None)
 
 
-def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = TASK_LEN, keep_host: bool = False, vec: int = 4) -> Adjacency:
+def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = TASK_LEN, keep_host: bool = False, vec: int = 4,
+                       row_key: Optional[np.ndarray] = None) -> Adjacency:
     """vec = 8 plans the work list for bf16 operands: a lane owns 8 columns, so a workgroup holds 2048 / D task groups -- the plan of
-    width D / 2."""
+    width D / 2.  row_key: schedule the rows in key order (plan_tasks)."""
     if vec not in (4, 8):
         raise ValueError("vec must be 4 (fp32 operands) or 8 (bf16 operands)")
     Dp = D * 4 // vec
-    plan = plan_tasks(rowptr, Dp, task_len, full=True)
+    plan = plan_tasks(rowptr, Dp, task_len, full=True, row_key=row_key)
     tasks, head = plan.tasks, plan.head
     check_plan(rowptr, tasks, Dp)
     assert col.size == 0 or (col.min() >= 0 and col.max() < rowptr.shape[0] - 1), "column id out of range"
@@ -389,8 +416,8 @@ class ShardedGraphBuilder:
                 raise ValueError("ShardedGraphBuilder.build_all: item_idx must be a contiguous int32 tensor with one entry per local edge")
             L.call("dmm_count_items", L.ptr(item_idx), self.E, self.I, L.ptr(counts[i]), L.stream())
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(counts, group=self.group)
+            from . import comm
+            comm.all_reduce(counts, group=self.group)
         metas = torch.zeros((M, 8), dtype=torch.int32, device=dev)
         outs = []
         for i, item_idx in enumerate(item_lists):

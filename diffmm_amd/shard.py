@@ -96,6 +96,6 @@ def sharded_spmm(shard: UserShard, x_users: torch.Tensor, x_items: torch.Tensor,
         raise ValueError("sharded_spmm: operand rows do not match the shard")
     ops.spmm_batched([ops.SpmmOp(shard.adj, x_users, y=y, x_hi=x_items, split=nu)])
     if reduce and shard.world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(y[nu:], group=group)
+        from . import comm
+        comm.all_reduce(y[nu:], group=group)
     return y

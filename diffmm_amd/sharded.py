@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import graph, ops, shard
+from . import comm, graph, ops, shard
 from .engine import FlatParams, JointEngine, modality_names
 
 Tensor = torch.Tensor
@@ -99,8 +99,7 @@ def sort_batch_by_owner(layout: ShardLayout, users: Tensor, pos: Tensor, neg: Te
 
 
 def _all_reduce(t: Tensor, group=None) -> None:
-    import torch.distributed as dist
-    dist.all_reduce(t, group=group)
+    comm.all_reduce(t, group=group)
 
 
 # ======================================================================================================
@@ -237,13 +236,12 @@ class ShardedJointEngine:
             L.call_py(self._exchange_end_now)
 
     def _exchange_begin_now(self, slot0: int, k: int):
-        import torch.distributed as dist
         if not hasattr(self, "_comm_stream"):
             self._comm_stream, self._comm_event = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
         self._comm_event.record(torch.cuda.current_stream())
         self._comm_stream.wait_event(self._comm_event)
         with torch.cuda.stream(self._comm_stream):
-            self._work = dist.all_reduce(self.xraw[slot0:slot0 + k], group=self.group, async_op=True)
+            self._work = comm.all_reduce(self.xraw[slot0:slot0 + k], group=self.group, async_op=True)
 
     def _exchange_end_now(self):
         self._work.wait()

@@ -10,9 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffmm_amd import graph, ops, synth, _lib as L
 
 
-def measure(g, D, dev, variant, reps=10, task_len=graph.TASK_LEN):
+def measure(g, D, dev, variant, reps=10, task_len=graph.TASK_LEN, order="row"):
     vec = 8 if variant.startswith("bf16") else 4
-    adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev, vec=vec, task_len=task_len)
+    adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev, vec=vec, task_len=task_len, hub_order=order == "hub")
     X = torch.randn(adj.n, D, device=dev)
     Y = torch.empty_like(X)
     if variant == "f32":
@@ -31,7 +31,7 @@ def measure(g, D, dev, variant, reps=10, task_len=graph.TASK_LEN):
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / reps * 1e-3
     alg = adj.nnz * 8 + (adj.n + 1) * 4 + adj.n * D * (s_x + s_y)
-    return dict(variant=variant, task_len=task_len, users=g.users, items=g.items, nnz=adj.nnz, d=D, tasks=adj.n_tasks, giant_rows=0 if adj.fix is None else int(adj.fix.shape[0]),
+    return dict(variant=variant, order=order, task_len=task_len, users=g.users, items=g.items, nnz=adj.nnz, d=D, tasks=adj.n_tasks, giant_rows=0 if adj.fix is None else int(adj.fix.shape[0]),
                 us_per_launch=t * 1e6, algorithmic_bytes=alg, algorithmic_GBps=alg / t / 1e9, frac_of_8TBps=alg / t / 8e12,
                 gather_bytes=adj.nnz * D * s_x, gather_GBps=adj.nnz * D * s_x / t / 1e9)
 
@@ -39,7 +39,7 @@ def measure(g, D, dev, variant, reps=10, task_len=graph.TASK_LEN):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--users", type=int, default=1_000_000); ap.add_argument("--items", type=int, default=500_000)
-    ap.add_argument("--dims", default="64"); ap.add_argument("--variants", default="f32,bf16_x,bf16_xy"); ap.add_argument("--task-lens", default=str(graph.TASK_LEN))
+    ap.add_argument("--dims", default="64"); ap.add_argument("--variants", default="f32,bf16_x,bf16_xy"); ap.add_argument("--task-lens", default=str(graph.TASK_LEN)); ap.add_argument("--orders", default="row")
     a = ap.parse_args()
     t0 = time.time()
     g = synth.make_graph(a.users, a.items, feats=(), seed=1818, heavy_p=0.011, heavy=(300, 520))
@@ -48,5 +48,6 @@ if __name__ == "__main__":
     for D in [int(x) for x in a.dims.split(",")]:
         for v in a.variants.split(","):
             for tl in [int(x) for x in a.task_lens.split(",")]:
-                print(json.dumps(measure(g, D, dev, v, task_len=tl)), flush=True)
-                torch.cuda.empty_cache()
+                for od in a.orders.split(","):  # row: tasks in row order; hub: rows sharing a highest-degree neighbour scheduled together (graph.hub_keys)
+                    print(json.dumps(measure(g, D, dev, v, task_len=tl, order=od)), flush=True)
+                    torch.cuda.empty_cache()
