@@ -9,8 +9,8 @@ as ONE local CSR over `n_local = users_g + items` nodes ([own users ; all items]
   item rows  Y_i      = D_i X_i + sum_g A_iu[:, U_g] X_u[U_g]            one all-reduce of an [items, d] partial per SpMM
 (the item self loops are kept by exactly one replica each, so the reduced sum is the exact row).  The backward is the same
 pattern (A is symmetric).  This module is the building block -- partition, local blocks, the SpMM + exchange -- with its
-own tests (tests/test_shard.py: the blocks reassemble the full matrix; sharded == unsharded SpMM on the GPU); round 1's training
-engines still replicate the graph (diffmm_amd/dist.py), which is the faster layout while it fits.
+own tests (tests/test_shard.py: the blocks reassemble the full matrix; sharded == unsharded SpMM on the GPU); the training
+engine on this layout is diffmm_amd/sharded.py.
 """
 from __future__ import annotations
 
