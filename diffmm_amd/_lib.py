@@ -102,8 +102,8 @@ _SIGS = {
     "dmm_gcn_mix_bwd_counted": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _I, _F, _P, _L, _L, _L, _L, _P]),
     "dmm_gcn_mix_fwd_x16": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _P, _L, _P]),
     "dmm_gcn_mix_bwd_x16": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _I, _F, _P, _L, _L, _L, _L, _P, C.POINTER(_P), _I, _P]),
-    "dmm_zero_batch_rows": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P, _I, _I, _P]),
-    "dmm_cast_batch_rows_bf16": (C.c_int, [C.POINTER(_P), C.POINTER(_P), _I, _I, _P, _P, _P, _I, _I, _P]),
+    "dmm_zero_batch_rows": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _P, _P, _P, _I, _I, _P, _P]),
+    "dmm_cast_batch_rows_bf16": (C.c_int, [C.POINTER(_P), C.POINTER(_P), _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "dmm_infonce_pack_bytes": (C.c_int64, [_I, _I, _I]),
     "dmm_gather_normalize": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_infonce_fwd": (C.c_int, [_P, _P, _I, _I, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P]),

@@ -309,6 +309,7 @@ struct TopkStreamShared {
   int hist[TOPK_BINS];
   uint32_t cand[TOPK_CAND];
   int wsum[4], sm4[4], wave_off[5];
+  int cscan[2][4];  // the compaction's per-wave (above | ties << 16) totals, double-buffered
   uint32_t sel_prefix;
   int sel_k, sel_cnt, n_cand;
 };
@@ -351,14 +352,27 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   const float* __restrict__ r = x + (long long)blockIdx.x * ldx;
   const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) & 15) == 0;
   const int c4 = vec ? cols / 4 : 0;  // columns [0, 4 c4) by 16-byte loads, the rest one by one
-  // ---- read 1: the top 11 bits ----
+  // ---- read 1: the top 11 bits (four 16-byte loads in flight per thread: a 4 MB row is latency, not bandwidth, to one workgroup) ----
   for (int i = threadIdx.x; i < TOPK_BINS; i += 256) S.hist[i] = 0;
   if (threadIdx.x == 0) S.n_cand = 0;
   __syncthreads();
-  for (int j = threadIdx.x; j < c4; j += 256) {
-    const float4 v = reinterpret_cast<const float4*>(r)[j];
-    atomicAdd(&S.hist[fkey(v.x) >> 21], 1); atomicAdd(&S.hist[fkey(v.y) >> 21], 1);
-    atomicAdd(&S.hist[fkey(v.z) >> 21], 1); atomicAdd(&S.hist[fkey(v.w) >> 21], 1);
+  {
+    int j = threadIdx.x;
+    for (; j + 768 < c4; j += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const float4*>(r)[j + 256 * q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        atomicAdd(&S.hist[fkey(v[q].x) >> 21], 1); atomicAdd(&S.hist[fkey(v[q].y) >> 21], 1);
+        atomicAdd(&S.hist[fkey(v[q].z) >> 21], 1); atomicAdd(&S.hist[fkey(v[q].w) >> 21], 1);
+      }
+    }
+    for (; j < c4; j += 256) {
+      const float4 v = reinterpret_cast<const float4*>(r)[j];
+      atomicAdd(&S.hist[fkey(v.x) >> 21], 1); atomicAdd(&S.hist[fkey(v.y) >> 21], 1);
+      atomicAdd(&S.hist[fkey(v.z) >> 21], 1); atomicAdd(&S.hist[fkey(v.w) >> 21], 1);
+    }
   }
   for (int j = 4 * c4 + threadIdx.x; j < cols; j += 256) atomicAdd(&S.hist[fkey(r[j]) >> 21], 1);
   __syncthreads();
@@ -369,7 +383,20 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   const bool in_lds = S.sel_cnt <= TOPK_CAND;  // uniform
   // ---- read 2: the bucket's keys into LDS ----
   if (in_lds) {
-    for (int j = threadIdx.x; j < c4; j += 256) {
+    int j = threadIdx.x;
+    for (; j + 768 < c4; j += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const float4*>(r)[j + 256 * q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t ky[4] = {fkey(v[q].x), fkey(v[q].y), fkey(v[q].z), fkey(v[q].w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((ky[e] >> 21) == top11) S.cand[atomicAdd(&S.n_cand, 1)] = ky[e];
+      }
+    }
+    for (; j < c4; j += 256) {
       const float4 v = reinterpret_cast<const float4*>(r)[j];
       const uint32_t ky[4] = {fkey(v.x), fkey(v.y), fkey(v.z), fkey(v.w)};
 #pragma unroll
@@ -408,36 +435,57 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
   const uint32_t T = prefix;  // the k-th largest key
   int need_ties = kk;         // its rank among the keys equal to T (>= 1): k - need_ties keys are larger -- no counting pass over the row
-  int* sm4 = S.sm4;
-  int* wave_off = S.wave_off;
-  int written = 0;           // uniform running output position
+  int written = 0;            // uniform running output position
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j0 = 0; j0 < cols; j0 += 256) {
-    const int j = j0 + threadIdx.x;
-    const uint32_t key = j < cols ? fkey(r[j]) : 0u;
-    const bool gt = j < cols && key > T, tie = j < cols && key == T;
-    // ordered ranks of this thread among the chunk's gt / tie elements
-    const unsigned long long mg = __ballot(gt), mt = __ballot(tie);
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // ---- read 3: the ordered compaction, 2048 columns per iteration: a thread owns 8 consecutive columns (two 16-byte loads), the (above, tie) counts
+  // of the threads are scanned inside the waves and across them through a double-buffered LDS record -- ONE barrier per 2048 columns (the first
+  // version took 256 columns and two barriers per iteration: 3906 iterations of a 1M-column row, ~4 ms per row whatever the bandwidth) ----
+  int buf = 0;
+  for (int j0 = 0; j0 < cols; j0 += 2048, buf ^= 1) {
+    const int base = j0 + (int)threadIdx.x * 8;
+    uint32_t key[8];
+    if (vec && base + 8 <= cols) {
+      const float4 a = *reinterpret_cast<const float4*>(r + base), b = *reinterpret_cast<const float4*>(r + base + 4);
+      key[0] = fkey(a.x); key[1] = fkey(a.y); key[2] = fkey(a.z); key[3] = fkey(a.w);
+      key[4] = fkey(b.x); key[5] = fkey(b.y); key[6] = fkey(b.z); key[7] = fkey(b.w);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) key[e] = base + e < cols ? fkey(r[base + e]) : 0u;
+    }
+    unsigned gm = 0u, tm = 0u;  // this thread's columns above the threshold / equal to it
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = base + e < cols;
+      gm |= (in && key[e] > T) ? (1u << e) : 0u;
+      tm |= (in && key[e] == T) ? (1u << e) : 0u;
+    }
+    const int mine = __popc(gm) | (__popc(tm) << 16);  // both counts in one scan (at most 2048 each)
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int nb = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += nb;
+    }
+    if (lane == 63) S.cscan[buf][wave] = inc;
     __syncthreads();
-    if (lane == 0) { sm4[wave] = __popcll(mg); wave_off[wave] = __popcll(mt); }
-    __syncthreads();
-    int gbase = 0, tbase = 0, gtot = 0, ttot = 0;
+    int before = inc - mine, total = 0;
+#pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) {
-      if (w2 < wave) { gbase += sm4[w2]; tbase += wave_off[w2]; }
-      gtot += sm4[w2]; ttot += wave_off[w2];
+      const int tw = S.cscan[buf][w2];
+      if (w2 < wave) before += tw;
+      total += tw;
     }
-    const int tie_rank = tbase + __popcll(mt & below);
+    const int gbase = before & 0xffff, tbase = before >> 16, gtot = total & 0xffff, ttot = total >> 16;
+    // output order inside the chunk: ascending column => rank of an element = (# above before it) + (# TAKEN ties before it); ties are taken in column
+    // order while the budget lasts
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned lower = (1u << e) - 1u;
+      const int ties_before = tbase + __popc(tm & lower);
+      const bool g = (gm >> e) & 1u, tk = ((tm >> e) & 1u) && ties_before < need_ties;
+      if (g || tk) out_idx[beg + written + gbase + __popc(gm & lower) + min(ties_before, need_ties)] = base + e;
+    }
     const int ties_taken_chunk = min(ttot, need_ties);
-    const bool take_tie = tie && tie_rank < need_ties;
-    // output order inside the chunk: ascending column => merge gt and taken ties by column id
-    // rank of this element = (# gt before it) + (# taken ties before it)
-    if (gt || take_tie) {
-      const int gt_before = gbase + __popcll(mg & below);
-      // taken ties before this column: ties with rank < need_ties and smaller column
-      const int ties_before = min(tbase + __popcll(mt & below), need_ties);
-      out_idx[beg + written + gt_before + ties_before] = j;
-    }
     written += gtot + ties_taken_chunk;
     need_ties -= ties_taken_chunk;
   }

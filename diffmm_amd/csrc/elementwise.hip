@@ -464,13 +464,15 @@ extern "C" int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const floa
 // casting just these rows and clearing them again after use, instead of a pass over all N rows.)
 struct BatchRowsP { const float* src[4]; __bf16* dst[4]; };
 __global__ __launch_bounds__(256) void cast_batch_rows_kernel(BatchRowsP P, int D, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
-                                                              const int32_t* __restrict__ neg, int B, int U) {
+                                                              const int32_t* __restrict__ neg, int B, int U, const int32_t* __restrict__ seg) {
   const int lanes = D / 8, per = 256 / lanes;
   const int l = threadIdx.x % lanes;
   const float* __restrict__ src = P.src[blockIdx.y];
   __bf16* __restrict__ dst = P.dst[blockIdx.y];
+  const int s0 = seg ? seg[0] : 0, s1 = seg ? seg[1] : B;  // user-sharded replica: users[b] is a row of this replica only for b in [seg[0], seg[1])
   for (int r = blockIdx.x * per + threadIdx.x / lanes; r < 3 * B; r += gridDim.x * per) {
     const int which = r / B, b = r - which * B;
+    if (which == 0 && (b < s0 || b >= s1)) continue;
     const int64_t row = which == 0 ? users[b] : (int64_t)U + (which == 1 ? pos[b] : neg[b]);
     typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
     bf16x8v o;
@@ -486,18 +488,20 @@ __global__ __launch_bounds__(256) void cast_batch_rows_kernel(BatchRowsP P, int 
 // The same rows of up to 8 tensors of any element size cleared: row_bytes[t] bytes per row (a multiple of 16)
 struct BatchRowsZeroP { char* dst[8]; int row_bytes[8]; };
 __global__ __launch_bounds__(256) void zero_batch_rows_kernel(BatchRowsZeroP P, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
-                                                              const int32_t* __restrict__ neg, int B, int U) {
+                                                              const int32_t* __restrict__ neg, int B, int U, const int32_t* __restrict__ seg) {
   char* __restrict__ dst = P.dst[blockIdx.y];
   const int rb = P.row_bytes[blockIdx.y], lanes = rb / 16;  // 16-byte pieces per row
+  const int s0 = seg ? seg[0] : 0, s1 = seg ? seg[1] : B;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)3 * B * lanes; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / lanes), l = (int)(e % lanes);
     const int which = r / B, b = r - which * B;
+    if (which == 0 && (b < s0 || b >= s1)) continue;
     const int64_t row = which == 0 ? users[b] : (int64_t)U + (which == 1 ? pos[b] : neg[b]);
     *reinterpret_cast<uint4*>(dst + row * rb + (int64_t)l * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 extern "C" int dmm_zero_batch_rows(void* const* dst, const int32_t* row_bytes, int n_t, const int32_t* users, const int32_t* pos, const int32_t* neg, int B,
-                                   int U, void* stream) {
+                                   int U, const int32_t* seg, void* stream) {
   DMM_CHECK_ARG(dst && row_bytes && n_t >= 1 && n_t <= 8 && users && pos && neg && B > 0 && U >= 0, "dmm_zero_batch_rows: bad arguments");
   BatchRowsZeroP P = {};
   int max_lanes = 0;
@@ -508,12 +512,12 @@ extern "C" int dmm_zero_batch_rows(void* const* dst, const int32_t* row_bytes, i
     max_lanes = std::max(max_lanes, row_bytes[t] / 16);
   }
   const int64_t work = (int64_t)3 * B * max_lanes;
-  hipLaunchKernelGGL(zero_batch_rows_kernel, dim3((unsigned)std::min<int64_t>(4096, (work + 255) / 256), n_t), dim3(256), 0, (hipStream_t)stream, P, users, pos, neg, B, U);
+  hipLaunchKernelGGL(zero_batch_rows_kernel, dim3((unsigned)std::min<int64_t>(4096, (work + 255) / 256), n_t), dim3(256), 0, (hipStream_t)stream, P, users, pos, neg, B, U, seg);
   DMM_LAUNCH_CHECK("dmm_zero_batch_rows");
   return 0;
 }
 extern "C" int dmm_cast_batch_rows_bf16(const float* const* src, void* const* dst, int n_t, int D, const int32_t* users, const int32_t* pos, const int32_t* neg,
-                                        int B, int U, void* stream) {
+                                        int B, int U, const int32_t* seg, void* stream) {
   DMM_CHECK_ARG(dst && n_t >= 1 && n_t <= 4 && users && pos && neg && B > 0 && U >= 0, "dmm_cast_batch_rows_bf16: bad arguments");
   DMM_CHECK_ARG(D >= 8 && D <= 2048 && D % 8 == 0 && 256 % (D / 8) == 0, "dmm_cast_batch_rows_bf16: D=%d unsupported (a multiple of 8 with 256 %% (D / 8) == 0)", D);
   BatchRowsP P = {};
@@ -523,7 +527,7 @@ extern "C" int dmm_cast_batch_rows_bf16(const float* const* src, void* const* ds
     P.dst[t] = (__bf16*)dst[t];
   }
   const int per = 256 / (D / 8);
-  hipLaunchKernelGGL(cast_batch_rows_kernel, dim3(std::min(2048, (3 * B + per - 1) / per), n_t), dim3(256), 0, (hipStream_t)stream, P, D, users, pos, neg, B, U);
+  hipLaunchKernelGGL(cast_batch_rows_kernel, dim3(std::min(2048, (3 * B + per - 1) / per), n_t), dim3(256), 0, (hipStream_t)stream, P, D, users, pos, neg, B, U, seg);
   DMM_LAUNCH_CHECK("dmm_cast_batch_rows_bf16");
   return 0;
 }

@@ -126,6 +126,7 @@ template <int D, bool SCATTER>
 __global__ __launch_bounds__(256) void rows_move_kernel(SlotTable S, int B, const int32_t* __restrict__ seg, float* __restrict__ buf) {
   constexpr int LANES = D / 4, G = 256 / LANES;
   const int s = blockIdx.y, l = threadIdx.x % LANES;
+  if (SCATTER && !S.grad[s]) return;  // a slot without a gradient table is skipped (its rows of `buf` are scattered by another launch)
   const int b0 = seg ? max(0, seg[0]) : 0, b1 = seg ? min(B, seg[1]) : B;
   const int32_t* __restrict__ idx = S.idx[s];
   for (int b = b0 + blockIdx.x * G + threadIdx.x / LANES; b < b1; b += gridDim.x * G) {
@@ -1079,7 +1080,6 @@ static int rows_move(bool scatter, const dmm_gather_desc* slots, int n_slots, in
   SlotTable S;
   if (int e = fill_slots(slots, n_slots, S)) return e;
   DMM_CHECK_ARG(buf && B > 0 && d_ok(D), "dmm_gather_rows / dmm_scatter_add_rows: bad arguments (B=%d D=%d)", B, D);
-  for (int i = 0; i < n_slots; ++i) DMM_CHECK_ARG(!scatter || S.grad[i], "dmm_scatter_add_rows: slot %d has no grad table", i);
   const int G = 1024 / D;
   dim3 grid(cdiv(B, G) > 1024 ? 1024 : cdiv(B, G), n_slots);
   if (scatter) {

@@ -366,8 +366,9 @@ def gcn_mix_fwd(bx: Tensor, z: Sequence[Tensor], w_logits: Tensor, maw: float, m
     return mx
 
 
-def zero_batch_rows(dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int) -> None:
-    """Rows users[b], U + pos[b], U + neg[b] of up to 8 contiguous [N, D] tensors (fp32 and / or bf16) cleared in one launch."""
+def zero_batch_rows(dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int, seg: Optional[Tensor] = None) -> None:
+    """Rows users[b], U + pos[b], U + neg[b] of up to 8 contiguous [N, D] tensors (fp32 and / or bf16) cleared in one launch.  seg (device int32 [2]):
+    users[b] counts only for b in [seg[0], seg[1]) -- a user-sharded replica's own segment of the minibatch."""
     rb = []
     for t in dst:
         if not t.is_contiguous() or t.dim() != 2 or (t.shape[1] * t.element_size()) % 16:
@@ -376,11 +377,14 @@ def zero_batch_rows(dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tens
     for i_ in (users, pos, neg):
         if i_.dtype != torch.int32 or not i_.is_contiguous() or i_.numel() != users.numel():
             raise ValueError("zero_batch_rows: index lists must be contiguous int32 of one length")
-    L.call("dmm_zero_batch_rows", _ptr_array_any(dst), (C.c_int32 * len(rb))(*rb), len(dst), L.ptr(users), L.ptr(pos), L.ptr(neg), users.numel(), U, L.stream())
+    L.call("dmm_zero_batch_rows", _ptr_array_any(dst), (C.c_int32 * len(rb))(*rb), len(dst), L.ptr(users), L.ptr(pos), L.ptr(neg), users.numel(), U,
+           L.ptr(_i32c(seg, "seg")) if seg is not None else None, L.stream())
 
 
-def cast_batch_rows_bf16(src: Optional[Sequence[Tensor]], dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int) -> None:
-    """Rows users[b], U + pos[b], U + neg[b] of up to 4 [N, D] tensors: dst[t] row = bf16(src[t] row); src = None writes zero rows."""
+def cast_batch_rows_bf16(src: Optional[Sequence[Tensor]], dst: Sequence[Tensor], users: Tensor, pos: Tensor, neg: Tensor, U: int,
+                         seg: Optional[Tensor] = None) -> None:
+    """Rows users[b], U + pos[b], U + neg[b] of up to 4 [N, D] tensors: dst[t] row = bf16(src[t] row); src = None writes zero rows.  seg: as in
+    zero_batch_rows."""
     D = dst[0].shape[1]
     for t in dst:
         if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 2 or t.shape != dst[0].shape:
@@ -392,7 +396,7 @@ def cast_batch_rows_bf16(src: Optional[Sequence[Tensor]], dst: Sequence[Tensor],
         if i_.dtype != torch.int32 or not i_.is_contiguous() or i_.numel() != users.numel():
             raise ValueError("cast_batch_rows_bf16: index lists must be contiguous int32 of one length")
     L.call("dmm_cast_batch_rows_bf16", _ptr_array(src) if src is not None else None, _ptr_array_any(dst), len(dst), D, L.ptr(users), L.ptr(pos), L.ptr(neg),
-           users.numel(), U, L.stream())
+           users.numel(), U, L.ptr(_i32c(seg, "seg")) if seg is not None else None, L.stream())
 
 
 def gcn_mix_bwd(dmx: Tensor, bx: Tensor, z: Sequence[Tensor], dz: Sequence[Tensor], dbx_extra: Optional[Tensor], w_logits: Tensor, maw: float,

@@ -379,7 +379,13 @@ class ShardedJointEngine:
         ub, dub = cview(self.ub, nU, D), cview(self.dub, nU, D)
         lse, row_loss = cview(self.lse, nT), cview(self.row_loss, nT + 1)
         users, pos, neg, ar = self.users_s[:B], self.pos_s[:B], self.neg_s[:B], self.arange[:B]
-        ops.zero_(self.gblock)
+        x16 = self._x16()
+        if x16 is None:
+            ops.zero_(self.gblock)
+        # (bf16 gather operands, i.e. blocks beyond the caches: the (M + 3) n d scatter targets are NOT cleared by a pass over all rows -- 13.8 GB per
+        # step on a replica of the 10M-user configuration.  dFin / dCl1 / dCl2 are zero outside the minibatch's rows and get those rows cleared again
+        # once they are consumed; the dZ_m are written, not accumulated into, by the mixing backward, the CL gradients of the modality views are
+        # scattered on top afterwards -- JointEngine.step does the same on one GPU)
         ops.zero_(dzhat)
         ops.zero_(ub)
         ops.zero_(dub)
@@ -405,24 +411,37 @@ class ShardedJointEngine:
             ops.zero_(self.loss_parts[nT + 1:nT + 2])
         ops.sumsq(emb[nu:], hp["reg"], self.loss_parts[nT + 2:], self.sumsq_scratch)
         # ---- backward ----
-        ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
-        ops.scatter_add_rows(ops.Slots([(v[0], users, v[1]) for v in views]), B, D, self.seg_s, dub)
         A = self.adj
         s = 1.0 + hp["residual_weight"]
-        x16 = self._x16()
+        modal_v = range(1, 1 + M)  # the modality views (their gradients go into the dZ_m, i.e. behind the mixing backward in bf16-operand mode)
         if x16 is None:
+            ops.scatter_normalize_bwd(slots, B, D, zhat, znorm, dzhat)
+            ops.scatter_add_rows(ops.Slots([(v[0], users, v[1]) for v in views]), B, D, self.seg_s, dub)
             gFin, gCl1, gX2p, gBx, gZ, o16, mo = self.dFin, self.dCl1, self.dX2p, self.dBx, self.dZ, {}, {}
-        else:  # bf16 gather operands: the scatter-added gradient rows are cast, the mixing backward writes the copies of its outputs itself
+        else:
+            # the user-side slots scatter into the batch table dub (all of them now); the item-side slots of the modality views wait
+            ops.scatter_normalize_bwd(ops.Slots([(e_[0], e_[1], None if (i_ % 2 == 1 and i_ // 2 in modal_v) else e_[2]) for i_, e_ in enumerate(slots.entries)]),
+                                      B, D, zhat, znorm, dzhat)
+            ops.scatter_add_rows(ops.Slots([(v[0], users, None if j in modal_v else v[1]) for j, v in enumerate(views)]), B, D, self.seg_s, dub)
+            # dFin and dCl1 are zero outside the minibatch's rows (own users of the segment, U + pos[b], U + neg[b]): their bf16 gather copies get
+            # just those rows; the mixing backward writes the copies of its dense outputs itself
             g16 = x16["g"]
-            ops.cast_bf16(self.gblock[:2].view(-1, D), g16[:2].view(-1, D))
+            ops.cast_batch_rows_bf16([self.gblock[0], self.gblock[1]], [g16[0], g16[1]], users, pos, neg, nu, seg=self.seg_s)
             gFin, gCl1, gX2p, gBx, gZ = g16[0], g16[1], x16["dX2p"], x16["dBx"], [g16[3 + m] for m in range(M)]
-            o16, mo = dict(y16=x16["dX2p"]), dict(dbx16=x16["dBx"], dz16=gZ)
+            o16, mo = dict(y16=x16["dX2p"]), dict(dbx16=x16["dBx"], dz16=gZ, dz_overwrite=True)
         self._spmm([dict(adj=A, x_lo=gFin, y=self.dMx, alpha=s, c1=self.dFin, beta=s),
                     dict(adj=A, x_lo=gCl1, y=self.dX2p, alpha=1.0 / 3.0, c1=self.dCl1, beta=1.0 / 3.0, **o16)])
         self._spmm([dict(adj=A, x_lo=gX2p, y=self.dX1p, alpha=1.0, c1=self.dCl1, beta=1.0 / 3.0, c2=self.dCl2, gamma=1.0)])
         i0, i1 = self.layout.item_slice()
+        if x16 is not None:  # dFin, dCl1, dCl2 and the two bf16 copies are consumed: their minibatch rows are cleared (they stay zero for the next step)
+            ops.zero_batch_rows([self.gblock[0], self.gblock[1], self.gblock[2], x16["g"][0], x16["g"][1]], users, pos, neg, nu, seg=self.seg_s)
         ops.gcn_mix_bwd(self.dMx, self.Bx, self.Z, self.dZ, self.dX1p, self.P.view("modal_weight"), hp["modal_adj_weight"], dbx=self.dBx,
                         dw=self.P.g("modal_weight"), partials=self.mix_partials, count=(nu * D, (nu + i0) * D, (nu + i1) * D), **mo)
+        if x16 is not None:  # the CL gradients of the modality views on top of the written dZ_m, then the bf16 copies of the rows they touched
+            ops.scatter_normalize_bwd(ops.Slots([(e_[0], e_[1], e_[2] if (i_ % 2 == 1 and i_ // 2 in modal_v) else None) for i_, e_ in enumerate(slots.entries)]),
+                                      B, D, zhat, znorm, dzhat)
+            ops.scatter_add_rows(ops.Slots([(v[0], users, v[1] if j in modal_v else None) for j, v in enumerate(views)]), B, D, self.seg_s, dub)
+            ops.cast_batch_rows_bf16(self.dZ, gZ, users, pos, neg, nu, seg=self.seg_s)
         # last backward SpMMs.  Gradient exchange overlapped with the remaining backward work: the modal graphs' item partials (they feed
         # the projection gradients) travel under the base graph's SpMM; the base graph's item partials (= d i_embs) travel under the
         # projection backward.

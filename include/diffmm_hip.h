@@ -225,10 +225,12 @@ int dmm_gcn_mix_bwd_x16(const float* dmx, const float* bx, const float* const* z
  * outputs indexed by ancs / poss / negs, Main.py:318-352) get their bf16 copies by casting just those rows of up to 4 [N, D] tensors; src == NULL or
  * src[t] == NULL writes zeros (clearing the rows again after use keeps the copy zero elsewhere).  D % 8 == 0, 256 % (D / 8) == 0. */
 /* the same rows of up to 8 tensors cleared, row_bytes[t] bytes per row (multiples of 16): fp32 and bf16 tensors in one launch */
+/* seg (device, int32[2], or NULL = all): a user-sharded replica's users[] holds LOCAL row ids that are valid only for b in [seg[0], seg[1]) -- the
+ * minibatch entries whose user it owns; the item rows U + pos[b], U + neg[b] (U = its own user count) are touched for every b. */
 int dmm_zero_batch_rows(void* const* dst /*host*/, const int32_t* row_bytes /*host*/, int n_t, const int32_t* users, const int32_t* pos, const int32_t* neg,
-                        int B, int U, void* stream);
+                        int B, int U, const int32_t* seg, void* stream);
 int dmm_cast_batch_rows_bf16(const float* const* src /*host array or NULL*/, void* const* dst /*host array of n_t bf16 [N, D]*/, int n_t, int D,
-                             const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int U, void* stream);
+                             const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int U, const int32_t* seg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Contrastive + ranking losses.  Utils/Utils.py:57-75 (InfoNCE), :78-98 (bpr_loss), :45-54 (l2_reg_loss).
@@ -280,7 +282,8 @@ int dmm_bpr_fwd_bwd_tables(const float* fin_u, const float* fin_i, const int32_t
  * is the same every step; NULL = all of [0, B)).
  *   dmm_gather_rows       out[s][b] = slots[s].src[slots[s].idx[b]]   for b in the segment; other rows of out [n_slots, B, D] untouched
  *                         (zero them first: a sum all-reduce over the replicas then assembles every replica's copy of the table)
- *   dmm_scatter_add_rows  slots[s].grad[slots[s].idx[b]] += in[s][b]  for b in the segment (fp32 atomics; repeated users are legal) */
+ *   dmm_scatter_add_rows  slots[s].grad[slots[s].idx[b]] += in[s][b]  for b in the segment (fp32 atomics; repeated users are legal; a slot whose
+ *                         grad is NULL is skipped) */
 int dmm_gather_rows(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const int32_t* seg, float* out, void* stream);
 int dmm_scatter_add_rows(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, const int32_t* seg, const float* in, void* stream);
 /* out[s] = scale * sum(in[s*len .. (s+1)*len)) in a fixed order (deterministic loss reduction). */
