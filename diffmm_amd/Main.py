@@ -202,6 +202,7 @@ class Coach:
             self.his_max = [float(v) for v in sd["his_max"]]
         DE.w16_step = [-1] * DE.M  # bf16 weight copies of the reverse chain are stale
         J._plans.clear()
+        J._emb16_step = -1  # ... and so is the embedding table's bf16 gather copy
         h.trainLoader.gen.set_state(sd["gen"]["train_loader"].cpu()); h.diffusionLoader.gen.set_state(sd["gen"]["diffusion_loader"].cpu())
         h.trainData.gen.set_state(sd["gen"]["neg_sampler"].cpu())
         torch.set_rng_state(sd["gen"]["torch_cpu"].cpu()); torch.cuda.set_rng_state(sd["gen"]["torch_device"].cpu(), self.device)

@@ -94,6 +94,7 @@ _SIGS = {
     "dmm_gemv_rows": (C.c_int, [_P, _L, _P, _P, _I, _I, _P]),
     "dmm_temb_bias_table": (C.c_int, [_P, _P, _I, _P, _L, _I, _P, _I, _I, _P, _P]),
     "dmm_rownorm_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "dmm_rownorm_fwd_x16": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "dmm_rownorm_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "dmm_rownorm_bwd_batched": (C.c_int, [C.POINTER(RownormBwdProblem), _I, _I, _P]),
     "dmm_gcn_mix_fwd": (C.c_int, [_P, C.POINTER(_P), _P, _I, _F, _P, _L, _P]),
@@ -119,6 +120,7 @@ _SIGS = {
     "dmm_sumsq": (C.c_int, [_P, _L, _F, _P, _P, _P]),
     "dmm_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P]),
     "dmm_adam_step_prefix": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L]),
+    "dmm_adam_step_x16": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L, _P, _L]),
     "dmm_qsample_temb": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),
     "dmm_csr_dense_rows": (C.c_int, [_P, _P, _P, _I, _I, _P, _L, _P]),
     "dmm_csr_dense_rows_slice": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _L, _P]),
@@ -199,6 +201,14 @@ def call(name: str, *args) -> None:
     rc = fn(*args)
     if rc:
         check(rc, name)
+
+
+ADAM_CALLS = ("dmm_adam_step", "dmm_adam_step_prefix", "dmm_adam_step_x16")  # (lr, step) sit at argument positions 9 and 13 in all of them
+
+
+def is_recording() -> bool:
+    """True inside a `Recorder` block (calls are being recorded into a launch plan, not launched)."""
+    return _recording is not None
 
 
 class Recorder:

@@ -33,7 +33,7 @@ namespace dmm {
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                           float* __restrict__ norm, int rows) {
+                                                           float* __restrict__ norm, int rows, __bf16* __restrict__ y16) {
   constexpr int LANES = D / 4, G = 256 / LANES;
   const int l = threadIdx.x % LANES;
   for (int r = blockIdx.x * G + threadIdx.x / LANES; r < rows; r += gridDim.x * G) {  // group-uniform trip count
@@ -41,7 +41,12 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restric
     float ss = group_sum<LANES>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
     const float nrm = sqrtf(ss);
     const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-    *reinterpret_cast<float4*>(y + (size_t)r * D + 4 * l) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    const float4 o = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    *reinterpret_cast<float4*>(y + (size_t)r * D + 4 * l) = o;
+    if (y16) {  // the bf16 gather copy of the normalised rows, written by their producer
+      __bf16 h[4] = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+      *reinterpret_cast<uint2*>(y16 + (size_t)r * D + 4 * l) = *reinterpret_cast<const uint2*>(h);
+    }
     if (l == 0 && norm) norm[r] = nrm;
   }
 }
@@ -256,7 +261,8 @@ struct AdamExtra {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, AdamExtra ex, float l2c, float step_size,
-                                                    float b1, float b2, float inv_sqrt_c2, float eps, int64_t l2_n) {
+                                                    float b1, float b2, float inv_sqrt_c2, float eps, int64_t l2_n, __bf16* __restrict__ p16,
+                                                    int64_t p16_n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float pv = p[i];
     float gr = g[i];
@@ -267,7 +273,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
     m[i] = mm;
     v[i] = vv;
-    p[i] = pv - step_size * mm / (sqrtf(vv) * inv_sqrt_c2 + eps);
+    const float pn = pv - step_size * mm / (sqrtf(vv) * inv_sqrt_c2 + eps);
+    p[i] = pn;
+    if (i < p16_n) p16[i] = (__bf16)pn;  // the bf16 gather copy of a prefix (the embedding table), written by the step that changes it
   }
 }
 
@@ -329,24 +337,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 template <int D>
-static int rownorm_launch(bool fwd, const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out, int rows, hipStream_t s) {
+static int rownorm_launch(bool fwd, const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out, int rows, hipStream_t s, void* out16) {
   constexpr int G = 1024 / D;
   const unsigned grid = grid_for(rows, G);
   if (fwd)
-    hipLaunchKernelGGL(rownorm_fwd_kernel<D>, dim3(grid), dim3(256), 0, s, a, out, nrm_out, rows);
+    hipLaunchKernelGGL(rownorm_fwd_kernel<D>, dim3(grid), dim3(256), 0, s, a, out, nrm_out, rows, (__bf16*)out16);
   else
     hipLaunchKernelGGL(rownorm_bwd_kernel<D>, dim3(grid), dim3(256), 0, s, a, b, nrm_in, out, rows);
   DMM_LAUNCH_CHECK("dmm_rownorm");
   return 0;
 }
-static int rownorm_dispatch(bool fwd, const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out, int rows, int D, hipStream_t s) {
+static int rownorm_dispatch(bool fwd, const float* a, const float* b, const float* nrm_in, float* out, float* nrm_out, int rows, int D, hipStream_t s,
+                            void* out16 = nullptr) {
   switch (D) {
-    case 8: return rownorm_launch<8>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
-    case 16: return rownorm_launch<16>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
-    case 32: return rownorm_launch<32>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
-    case 64: return rownorm_launch<64>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
-    case 128: return rownorm_launch<128>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
-    case 256: return rownorm_launch<256>(fwd, a, b, nrm_in, out, nrm_out, rows, s);
+    case 8: return rownorm_launch<8>(fwd, a, b, nrm_in, out, nrm_out, rows, s, out16);
+    case 16: return rownorm_launch<16>(fwd, a, b, nrm_in, out, nrm_out, rows, s, out16);
+    case 32: return rownorm_launch<32>(fwd, a, b, nrm_in, out, nrm_out, rows, s, out16);
+    case 64: return rownorm_launch<64>(fwd, a, b, nrm_in, out, nrm_out, rows, s, out16);
+    case 128: return rownorm_launch<128>(fwd, a, b, nrm_in, out, nrm_out, rows, s, out16);
+    case 256: return rownorm_launch<256>(fwd, a, b, nrm_in, out, nrm_out, rows, s, out16);
   }
   set_error("dmm_rownorm: D=%d unsupported (8,16,32,64,128,256)", D);
   return DMM_ERR_INVALID_ARG;
@@ -388,6 +397,11 @@ extern "C" int dmm_rownorm_fwd(const float* x, float* y, float* norm, int rows, 
   DMM_CHECK_ARG(x && y && rows >= 0, "dmm_rownorm_fwd: null operand");
   if (rows == 0) return 0;
   return rownorm_dispatch(true, x, nullptr, nullptr, y, norm, rows, D, (hipStream_t)stream);
+}
+extern "C" int dmm_rownorm_fwd_x16(const float* x, float* y, void* y16, float* norm, int rows, int D, void* stream) {
+  DMM_CHECK_ARG(x && y && y16 && rows >= 0 && ((uintptr_t)y16 & 7) == 0, "dmm_rownorm_fwd_x16: null or misaligned operand");
+  if (rows == 0) return 0;
+  return rownorm_dispatch(true, x, nullptr, nullptr, y, norm, rows, D, (hipStream_t)stream, y16);
 }
 extern "C" int dmm_rownorm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream) {
   DMM_CHECK_ARG(dy && y && norm && dx && rows >= 0, "dmm_rownorm_bwd: null operand");
@@ -556,7 +570,14 @@ extern "C" int dmm_adam_step(float* p, const float* g, float* m, float* v, int64
 
 extern "C" int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
                                     int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n) {
+  return dmm_adam_step_x16(p, g, m, v, n, extra, extra_n, n_extra, l2_coef, lr, beta1, beta2, eps, step, stream, l2_n, nullptr, 0);
+}
+
+extern "C" int dmm_adam_step_x16(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
+                                 int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n,
+                                 void* p16, int64_t p16_n) {
   DMM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && n_extra >= 0 && n_extra <= 4 && l2_n >= 0, "dmm_adam_step: bad arguments");
+  DMM_CHECK_ARG(p16_n >= 0 && p16_n <= n && (p16_n == 0 || p16), "dmm_adam_step_x16: p16 must cover p16_n <= n elements");
   AdamExtra ex = {};
   ex.cnt = n_extra;
   for (int k = 0; k < n_extra; ++k) {
@@ -565,7 +586,7 @@ extern "C" int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v
   }
   const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ex, l2_coef,
-                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps, l2_n);
+                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps, l2_n, (__bf16*)p16, p16_n);
   DMM_LAUNCH_CHECK("dmm_adam_step");
   return 0;
 }

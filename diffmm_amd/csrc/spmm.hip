@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256) void spmm_epilogue_rows_kernel(const SpmmBatch
   constexpr int LANES = D / 4, G = 256 / LANES;
   const dmm_spmm_problem& P = batch.p[blockIdx.y];
   if (!P.raw) return;
+  // a plain problem (y = A x, nothing else) whose raw rows were parked in y's own rows and summed there: nothing is left to do
+  if (P.y && P.raw == P.y + (size_t)P.raw_from * D && P.alpha == 1.0f && !P.c1 && !P.c2 && !P.y16 && !P.y_pert && !P.y_pert16 && !P.y_mean) return;
   const int l = threadIdx.x % LANES;
   for (int row = P.raw_from + blockIdx.x * G + threadIdx.x / LANES; row < P.n_rows; row += gridDim.x * G) {
     const Acc<4> acc = load_f32<4>(P.raw + (size_t)(row - P.raw_from) * D + 4 * l);

@@ -153,6 +153,7 @@ class JointEngine:
         # E_m^T [F_m, round_up(I, 32)] (constant): the weight gradient dW_m = dfeat_m^T E_m runs as E_m^T x dfeat_m on the item-space kernel
         self._featsT = None
         self._x16_bufs = None
+        self._emb16_step = -1  # Adam step at which the embedding table's bf16 gather copy was last made (bf16 gather operands only)
         self._nf_block, self._fnorm_block = z(M, items, D), z(M, items)  # blocks: the modalities' row normalisation is one launch
         self.nf = [self._nf_block[m] for m in range(M)]
         self.fnorm = [self._fnorm_block[m] for m in range(M)]
@@ -201,6 +202,7 @@ class JointEngine:
         t = {k: torch.as_tensor(v) for k, v in sd.items()}
         t["emb"] = torch.cat([t.pop("u_embs"), t.pop("i_embs")], dim=0)
         self.P.load(t)
+        self._emb16_step = -1
 
     def state_dict(self) -> Dict[str, Tensor]:
         sd = self.P.state_dict()
@@ -251,7 +253,16 @@ class JointEngine:
         else:  # Linear_m(E_m) of every modality in ONE launch of the generic GEMM
             ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{n}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{n}_layer.bias"),
                                    precision=precision) for m, n in enumerate(names)])
-        ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1))  # all modalities' rows
+        x16 = self._x16()  # (bf16 gather operands: the normalised rows' copy comes out of the same launch)
+        ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1),
+                        y16=x16["nf"].view(-1, self.D) if x16 is not None else None)  # all modalities' rows
+
+    def _emb16_refresh(self, x16: Dict[str, Tensor]):
+        """The embedding table's bf16 gather copy.  Adam writes it with the table (dmm_adam_step_x16), so a recorded step never casts it; the
+        eager paths (parity steps, evaluation) and the first planned step after the table was loaded from outside cast it here."""
+        if not L.is_recording():
+            ops.cast_bf16(self.P.view("emb"), x16["emb"])
+            self._emb16_step = self.P.step
 
     def _x16(self) -> Optional[Dict[str, Tensor]]:
         """bf16 copies of the SpMMs' gathered operands when the graphs are planned for them (Adjacency.vec == 8, graph.spmm_operand_vec): made by
@@ -307,8 +318,7 @@ class JointEngine:
         seed, base = hp.get("seed", 1818), self.rng_step * 3 * self.N * lanes
         nz = lambda k: dict(noise=noise[k]) if noise is not None else dict(noise=None, seed=seed, offset=base + k * self.N * lanes)
         refs = self._philox_refs
-        ops.cast_bf16(emb, x16["emb"])
-        ops.cast_bf16(self._nf_block.view(-1, self.D), x16["nf"].view(-1, self.D))
+        self._emb16_refresh(x16)
         batch = [ops.SpmmOp(self.modal_adj[m], x16["emb"][:U], y=self.Z[m], x_hi=x16["nf"][m], split=U) for m in range(M)]
         if with_cl:
             batch.append(ops.SpmmOp(A, x16["emb"], y=self.Bx, y_pert=self.X1p, y_pert16=x16["X1p"], noise_degree=nd, **nz(0)))
@@ -458,13 +468,16 @@ class JointEngine:
             try:
                 with L.Recorder() as calls:
                     self.step(self.users_s[:B], self.pos_s[:B], self.neg_s[:B], noise=None, precision=precision, update=True)
-                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in ("dmm_adam_step", "dmm_adam_step_prefix")])
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in L.ADAM_CALLS])
             finally:
                 self._philox_refs = None
             self.rng_step -= 1  # recording ran step()'s bookkeeping once without launching anything
             self.P.step -= 1
             self._plans[key] = plan
         self._set_batch(users, pos, neg)
+        x16 = self._x16()
+        if x16 is not None and self._emb16_step != self.P.step:
+            self._emb16_refresh(x16)
         lanes = self.D // 4
         base = self.rng_step * 3 * self.N * lanes
         for arr, i, k in plan["philox"]:
@@ -473,6 +486,8 @@ class JointEngine:
         for c in plan["adam"]:
             c[1][9], c[1][13] = self.lr, self.P.step
         L.replay(plan["calls"])
+        if x16 is not None:
+            self._emb16_step = self.P.step  # (the plan's Adam launch wrote the copy)
         self.rng_step += 1
         return self.loss_parts
 
@@ -493,7 +508,11 @@ class JointEngine:
         ne = self.N * D
         extra = list(self.T)
         # one launch for the whole flat buffer: the l2 term and the extra gradient rows touch the embedding prefix only
-        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, extra=extra, extra_n=[U * D] * len(extra), l2_coef=2.0 * self.hp["reg"], l2_n=ne)
+        x16 = self._x16()
+        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, extra=extra, extra_n=[U * D] * len(extra), l2_coef=2.0 * self.hp["reg"], l2_n=ne,
+                      p16=x16["emb"].view(-1) if x16 is not None else None)
+        if x16 is not None:
+            self._emb16_step = P.step
 
     def full_grads(self) -> Dict[str, Tensor]:
         """Gradients as autograd would report them (for parity tests): folds the extras / l2 term that Adam absorbs."""

@@ -310,11 +310,15 @@ def temb_bias_table(w_emb: Tensor, b_emb: Tensor, w1: Tensor, I: int, b1: Tensor
 # ------------------------------------------------------------------------------------------------
 # normalisation / mixing
 # ------------------------------------------------------------------------------------------------
-def rownorm_fwd(x: Tensor, y: Optional[Tensor] = None, norm: Optional[Tensor] = None):
+def rownorm_fwd(x: Tensor, y: Optional[Tensor] = None, norm: Optional[Tensor] = None, y16: Optional[Tensor] = None):
+    """y16: also write the bf16 copy of y (a gather operand of dmm_spmm_csr_bf16)."""
     _f32c(x, "x")
     y = torch.empty_like(x) if y is None else _f32c(y, "y")
     norm = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if norm is None else norm
-    L.call("dmm_rownorm_fwd", L.ptr(x), L.ptr(y), L.ptr(norm), x.shape[0], x.shape[1], L.stream())
+    if y16 is not None:
+        L.call("dmm_rownorm_fwd_x16", L.ptr(x), L.ptr(y), L.ptr(_bf16_like(y16, x, "y16")), L.ptr(norm), x.shape[0], x.shape[1], L.stream())
+    else:
+        L.call("dmm_rownorm_fwd", L.ptr(x), L.ptr(y), L.ptr(norm), x.shape[0], x.shape[1], L.stream())
     return y, norm
 
 
@@ -512,14 +516,21 @@ def sumsq(x: Tensor, scale: float, out: Tensor, scratch: Optional[Tensor] = None
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, extra: Sequence[Tensor] = (), extra_n: Sequence[int] = (),
-              l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, l2_n: Optional[int] = None) -> None:
-    """l2_n: the l2 term (l2_coef * p added to the gradient) covers the first l2_n elements only (default: all)."""
+              l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, l2_n: Optional[int] = None,
+              p16: Optional[Tensor] = None) -> None:
+    """l2_n: the l2 term (l2_coef * p added to the gradient) covers the first l2_n elements only (default: all).  p16 (contiguous bf16): receives the
+    bf16 copy of the first p16.numel() updated parameters."""
     n = p.numel()
     if not (g.numel() == n and m.numel() == n and v.numel() == n):
         raise ValueError("adam: size mismatch")
     ex = (C.c_void_p * max(1, len(extra)))(*[L.ptr(t) for t in extra]) if extra else (C.c_void_p * 1)()
     en = (C.c_int64 * max(1, len(extra)))(*extra_n) if extra else (C.c_int64 * 1)()
-    if l2_n is None:
+    if p16 is not None:  # (argument positions of lr and step as in dmm_adam_step: the recorded plans patch them in place)
+        if p16.dtype != torch.bfloat16 or not p16.is_contiguous() or p16.numel() > n:
+            raise ValueError("adam: p16 must be a contiguous bfloat16 tensor of at most p.numel() elements")
+        L.call("dmm_adam_step_x16", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream(),
+               int(n if l2_n is None else l2_n), L.ptr(p16), p16.numel())
+    elif l2_n is None:
         L.call("dmm_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream())
     else:  # (the argument positions of lr and step are those of dmm_adam_step: the recorded plans patch them in place)
         L.call("dmm_adam_step_prefix", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream(), int(l2_n))

@@ -24,6 +24,7 @@ B shuffled interactions, every replica holds the user rows of the triples whose 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -162,6 +163,7 @@ class ShardedJointEngine:
         self._plans: Dict[tuple, dict] = {}
         self._philox_refs: Optional[list] = None
         self._x16_bufs: Optional[Dict[str, Tensor]] = None
+        self._emb16_step = -1
 
     # -- parameters ------------------------------------------------------------------------------------
     @property
@@ -178,6 +180,7 @@ class ShardedJointEngine:
         u = t.pop("u_embs")[self.layout.u0:self.layout.u1]
         t["emb"] = torch.cat([u, t.pop("i_embs")], dim=0)
         self.P.load(t)
+        self._emb16_step = -1
 
     def state_dict(self) -> Dict[str, Tensor]:
         """Local view: u_embs are the replica's OWN rows (users u0..u1)."""
@@ -211,40 +214,71 @@ class ShardedJointEngine:
         if self.world > 1:
             L.call_py(_all_reduce, t, self.group)
 
+    _PLAIN = frozenset(("adj", "x_lo", "x_hi", "split", "y"))
+
+    def _in_place(self) -> bool:
+        """Large blocks (those planned for bf16 gather operands; DMM_SHARD_INPLACE=0/1 forces it): a PLAIN problem (y = A x and nothing else: the
+        modal graphs' forward and backward, the base graph's last backward -- 7 of a step's 14) parks its raw item partials in y's own item rows,
+        they are all-reduced there and need no epilogue pass: no [I, d] scratch round trip (2 GB of traffic per problem at 1M items, d = 256).
+        Small blocks keep ONE scratch buffer per launch: one collective instead of one per problem."""
+        env = os.environ.get("DMM_SHARD_INPLACE")
+        return (env == "1") if env in ("0", "1") else (self.adj is not None and self.adj.vec == 8)
+
     def _spmm(self, batch: List[dict]):
         """batch: SpmmOp keyword dicts (with adj, x_lo).  Local launch -> all-reduce of the raw item partials -> item-row epilogue."""
-        k = len(batch)
-        arr = self._spmm_local(batch, 0)
-        self._ar(self.xraw[:k])
-        ops.spmm_epilogue_rows(arr, k, self.D)
+        arr, bufs, epi = self._spmm_local(batch, 0)
+        for t in bufs:
+            self._ar(t)
+        if epi:
+            ops.spmm_epilogue_rows(arr, len(batch), self.D)
         return arr
 
     def _spmm_local(self, batch: List[dict], slot0: int):
-        """The local launch alone: own user rows finished, raw item partials parked in xraw[slot0 : slot0 + len(batch)]."""
-        return ops.spmm_batched([ops.SpmmOp(raw=self.xraw[slot0 + i], raw_from=self.nu, **b) for i, b in enumerate(batch)])
+        """The local launch alone: own user rows finished, raw item partials parked in xraw[slot0 : slot0 + len(batch)] -- or, for plain problems in
+        in-place mode, in the item rows of their own output.  Returns (argument block, the buffers to all-reduce, whether any problem needs
+        dmm_spmm_epilogue_rows afterwards)."""
+        nu, ops_, bufs, run = self.nu, [], [], None
+        inplace = self._in_place()
+        for i, b in enumerate(batch):
+            if inplace and set(b) <= self._PLAIN:
+                raw = b["y"][nu:]
+                bufs.append(raw)
+                run = None
+            else:
+                raw = self.xraw[slot0 + i]
+                if run is not None and run[1] == slot0 + i:  # consecutive scratch slots travel as one collective
+                    run[1] += 1
+                else:
+                    run = [slot0 + i, slot0 + i + 1]
+                    bufs.append(run)
+            ops_.append(ops.SpmmOp(raw=raw, raw_from=nu, **b))
+        epi = any(isinstance(t, list) for t in bufs)
+        bufs = [self.xraw[t[0]:t[1]] if isinstance(t, list) else t for t in bufs]
+        return ops.spmm_batched(ops_), bufs, epi
 
     # The exchange of one launch's partials can run on a side stream UNDER the next launch (RCCL uses its own stream anyway; the side
     # stream only orders it behind the producing launch without blocking the main stream): the gradient all-reduces of the backward --
     # the item rows of the modal SpMMs that feed the projection gradients, then the item rows of the base SpMM = d(i_embs) -- overlap
     # with the remaining backward SpMM and with the projection backward.
-    def _exchange_begin(self, slot0: int, k: int):
+    def _exchange_begin(self, bufs: List[Tensor]):
         if self.world > 1:
-            L.call_py(self._exchange_begin_now, slot0, k)
+            L.call_py(self._exchange_begin_now, bufs)
 
     def _exchange_end(self):
         if self.world > 1:
             L.call_py(self._exchange_end_now)
 
-    def _exchange_begin_now(self, slot0: int, k: int):
+    def _exchange_begin_now(self, bufs: List[Tensor]):
         if not hasattr(self, "_comm_stream"):
             self._comm_stream, self._comm_event = torch.cuda.Stream(device=self.dev), torch.cuda.Event()
         self._comm_event.record(torch.cuda.current_stream())
         self._comm_stream.wait_event(self._comm_event)
         with torch.cuda.stream(self._comm_stream):
-            self._work = comm.all_reduce(self.xraw[slot0:slot0 + k], group=self.group, async_op=True)
+            self._work = [comm.all_reduce(t, group=self.group, async_op=True) for t in bufs]
 
     def _exchange_end_now(self):
-        self._work.wait()
+        for w in self._work:
+            w.wait()
         torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._work = None
 
@@ -265,9 +299,12 @@ class ShardedJointEngine:
         else:
             ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{nm}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{nm}_layer.bias"),
                                    precision=precision) for m, nm in enumerate(modality_names(self.M))])
-        ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1))  # all modalities' rows
+        x16 = self._x16()
+        ops.rownorm_fwd(self._feat_block.view(-1, self.D), self._nf_block.view(-1, self.D), self._fnorm_block.view(-1),
+                        y16=x16["nf"].view(-1, self.D) if x16 is not None else None)  # all modalities' rows (+ their bf16 gather copy)
 
     _feat_kernels = JointEngine._feat_kernels
+    _emb16_refresh = JointEngine._emb16_refresh
 
     def _features_T_slice(self) -> List[Tensor]:
         """E_m^T restricted to this replica's item slice, [F_m, round_up(i1 - i0, 32)] (constant)."""
@@ -292,19 +329,20 @@ class ShardedJointEngine:
         if x16 is None:
             xe, xu, xnf, xMx, xX1, xX2, o1, o2, mo = emb, self.u_embs, self.nf, self.Mx, self.X1p, self.X2p, {}, {}, {}
         else:  # bf16 gather operands (JointEngine._forward_x16): casts of the embedding table and the normalised features, producer-made copies behind them
-            ops.cast_bf16(emb, x16["emb"])
-            ops.cast_bf16(self._nf_block.view(-1, self.D), x16["nf"].view(-1, self.D))
+            self._emb16_refresh(x16)  # (a recorded step relies on Adam's copy: dmm_adam_step_x16)
             xe, xu, xnf, xMx, xX1, xX2 = x16["emb"], x16["emb"][: self.nu], [x16["nf"][m] for m in range(M)], x16["Mx"], x16["X1p"], x16["X2p"]
             o1, o2, mo = dict(y_pert16=x16["X1p"]), dict(y_pert16=x16["X2p"]), dict(mx16=x16["Mx"])
         modal = [dict(adj=self.modal_adj[m], x_lo=xu, y=self.Z[m], x_hi=xnf[m], split=self.nu) for m in range(M)]
         base = dict(adj=A, x_lo=xe, y=self.Bx, y_pert=self.X1p, noise_degree=nd, **o1, **self._rng(0, noise)) if with_cl else dict(adj=A, x_lo=xe, y=self.Bx)
         # the modal graphs' partials are exchanged under the base graph's launch
-        arr_m = self._spmm_local(modal, 0)
-        self._exchange_begin(0, M)
-        arr = self._spmm_local([base], M)
+        arr_m, bufs_m, epi_m = self._spmm_local(modal, 0)
+        self._exchange_begin(bufs_m)
+        arr, bufs_b, _ = self._spmm_local([base], M)
         self._exchange_end()
-        ops.spmm_epilogue_rows(arr_m, M, self.D)
-        self._ar(self.xraw[M:M + 1])
+        if epi_m:
+            ops.spmm_epilogue_rows(arr_m, M, self.D)
+        for t in bufs_b:
+            self._ar(t)
         ops.spmm_epilogue_rows(arr, 1, self.D)
         if refs is not None and with_cl:
             refs.append((arr, 0, 0))
@@ -445,12 +483,13 @@ class ShardedJointEngine:
         # last backward SpMMs.  Gradient exchange overlapped with the remaining backward work: the modal graphs' item partials (they feed
         # the projection gradients) travel under the base graph's SpMM; the base graph's item partials (= d i_embs) travel under the
         # projection backward.
-        arr_m = self._spmm_local([dict(adj=self.modal_adj[m], x_lo=gZ[m], y=self.T[m]) for m in range(M)], 0)
-        self._exchange_begin(0, M)
-        arr_b = self._spmm_local([dict(adj=A, x_lo=gBx, y=self.P.g("emb"))], M)
+        arr_m, bufs_m, epi_m = self._spmm_local([dict(adj=self.modal_adj[m], x_lo=gZ[m], y=self.T[m]) for m in range(M)], 0)
+        self._exchange_begin(bufs_m)
+        arr_b, bufs_b, epi_b = self._spmm_local([dict(adj=A, x_lo=gBx, y=self.P.g("emb"))], M)
         self._exchange_end()
-        ops.spmm_epilogue_rows(arr_m, M, D)
-        self._exchange_begin(M, 1)
+        if epi_m:
+            ops.spmm_epilogue_rows(arr_m, M, D)
+        self._exchange_begin(bufs_b)
         ne = self.n * D
         names = modality_names(M)
         mw = self.P.offsets["modal_weight"]
@@ -466,7 +505,8 @@ class ShardedJointEngine:
                 ops.gemm_batched([dict(A=self.dfeat[m][i0:i1], B=self.feats[m][i0:i1], out=self.P.g(f"{nm}_layer.weight"), trans_a=True, precision=precision,
                                        split_k=128) for m, nm in enumerate(names)])
         self._exchange_end()
-        ops.spmm_epilogue_rows(arr_b, 1, D)
+        if epi_b:
+            ops.spmm_epilogue_rows(arr_b, 1, D)
         self._ar(self.P.grad[ne:])  # projections + modal_weight: partial sums over disjoint node sets
         if update:
             self.apply_adam()
@@ -485,12 +525,15 @@ class ShardedJointEngine:
             try:
                 with L.Recorder() as calls:
                     self._step_body(B, None, precision, True)
-                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in ("dmm_adam_step", "dmm_adam_step_prefix")])
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in L.ADAM_CALLS])
             finally:
                 self._philox_refs = None
             self.rng_step -= 1  # recording ran the bookkeeping once without launching anything
             self.P.step -= 1
             self._plans[key] = plan
+        x16 = self._x16()
+        if x16 is not None and self._emb16_step != self.P.step:
+            self._emb16_refresh(x16)
         lanes = self.D // 4
         base = self.rng_step * 3 * self.N * lanes
         for arr, i, k in plan["philox"]:
@@ -499,6 +542,8 @@ class ShardedJointEngine:
         for c in plan["adam"]:
             c[1][9], c[1][13] = self.lr, self.P.step
         L.replay(plan["calls"])
+        if x16 is not None:
+            self._emb16_step = self.P.step
         self.rng_step += 1
         return self.loss_parts
 
@@ -506,7 +551,11 @@ class ShardedJointEngine:
         P, nu, D = self.P, self.nu, self.D
         P.step += 1
         ne = self.n * D
-        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, extra=list(self.T), extra_n=[nu * D] * self.M, l2_coef=2.0 * self.hp["reg"], l2_n=ne)
+        x16 = self._x16()
+        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, extra=list(self.T), extra_n=[nu * D] * self.M, l2_coef=2.0 * self.hp["reg"], l2_n=ne,
+                      p16=x16["emb"].view(-1) if x16 is not None else None)
+        if x16 is not None:
+            self._emb16_step = P.step
 
     def full_grads(self) -> Dict[str, Tensor]:
         """Gradients as autograd reports them on the unsharded model (parity tests): u_embs = the replica's OWN rows."""

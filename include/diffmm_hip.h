@@ -186,6 +186,7 @@ int dmm_temb_bias_table(const float* w_emb, const float* b_emb, int te, const fl
  * Row L2 normalisation, F.normalize(x, p=2, dim=1, eps=1e-12): Model.py:89,92,104; Utils.py:72.
  * fwd writes y = x / max(||x||, eps) and norm = ||x||.  bwd: dx = (dy - y (y.dy)) / ||x||  (dy / eps below eps). */
 int dmm_rownorm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream);
+int dmm_rownorm_fwd_x16(const float* x, float* y, void* y16 /*bf16 copy of y*/, float* norm, int rows, int D, void* stream);
 int dmm_rownorm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream);
 /* dmm_rownorm_bwd for up to 4 tensors in one launch; csum (optional, [D], pre-zeroed) receives the column sums of dx -- the bias gradient of the
  * Linear layer in front of the normalisation (Model.py:84-89): the joint step's three rownorm_bwd + three colsum launches in one */
@@ -303,6 +304,11 @@ int dmm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
 /* the same step with the l2 term applied to the first l2_n elements only (one launch for a flat buffer = [embedding rows | other weights]) */
 int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/, const int64_t* extra_n,
                          int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n);
+/* ... and with a bf16 copy of the first p16_n updated parameters written to p16 (the embedding table's gather copy for dmm_spmm_csr_bf16: made by the
+ * step that changes the table instead of a cast pass over it per training step) */
+int dmm_adam_step_x16(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/, const int64_t* extra_n,
+                      int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n, void* p16,
+                      int64_t p16_n);
 
 /* ---------------------------------------------------------------------------------------------------
  * Diffusion path.
