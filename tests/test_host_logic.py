@@ -190,3 +190,36 @@ def test_bundle_round_trip_and_reference_feature_files(tmp_path):
     if os.path.exists(ref):
         f = bundle.load_feature_npy(ref)
         assert f.dtype == np.float32 and f.shape == (6710, 128) and np.isfinite(f).all()
+
+
+def test_hub_ordered_plan_is_a_permutation_of_the_row_ordered_plan():
+    """graph.hub_keys (a row's highest-degree neighbour) and plan_tasks(row_key=): the same tasks in another order -- every plan the checker accepts
+    is valid for the kernel, which reads its row from the task."""
+    from diffmm_amd import graph, synth
+    g = synth.named("mid")
+    rp, col, _ = graph.normalized_bipartite_csr(g.trn_rows, g.trn_cols, g.users, g.items)
+    key = graph.hub_keys(rp, col)
+    deg = np.diff(rp)
+    for r in range(0, len(deg), 5):
+        cs = col[rp[r]:rp[r + 1]]
+        cs = cs[cs != r]
+        want = r if cs.size == 0 else int(cs[deg[cs] == deg[cs].max()].max())
+        assert key[r] == want
+    for D, tl in ((64, 16), (32, 8)):
+        p0, p1 = graph.plan_tasks(rp, D, tl, full=True), graph.plan_tasks(rp, D, tl, full=True, row_key=key)
+        graph.check_plan(rp, p1.tasks, D)
+        live = lambda p: sorted(map(tuple, p.tasks[p.tasks[:, 0] >= 0].tolist()))
+        assert live(p0) == live(p1) and p0.head == p1.head and p0.n_partial_blocks == p1.n_partial_blocks
+
+
+def test_local_comm_keeps_the_own_part():
+    """comm.LOCAL (one process running a single replica of a larger job): reductions are the identity, a gather fills the replica's own block."""
+    import torch
+    from diffmm_amd import comm
+    t = torch.arange(6.0)
+    comm.all_reduce(t, group=comm.LOCAL)
+    comm.all_reduce(t, group=comm.LOCAL, op="MAX")
+    assert torch.equal(t, torch.arange(6.0)) and comm.all_reduce(t, group=comm.LOCAL, async_op=True).wait()
+    out = torch.zeros(6, 2)
+    comm.all_gather_into(out, torch.ones(2, 2), rank=1, group=comm.LOCAL)
+    assert torch.equal(out, torch.tensor([[0, 0], [0, 0], [1, 1], [1, 1], [0, 0], [0, 0]], dtype=torch.float32))
