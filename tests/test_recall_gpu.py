@@ -91,12 +91,15 @@ def test_plateau_losses_match_the_reference(hip_runs):
         assert rows[-1]["Loss"] < rows[5]["Loss"] < rows[0]["Loss"], "the loss keeps decreasing like the reference's"
 
 
-def test_user_sharded_replicas_reach_the_same_plateau():
+@pytest.mark.parametrize("denoise_shard", ["rows", "items"])
+def test_user_sharded_replicas_reach_the_same_plateau(denoise_shard):
+    """denoise_shard: the Denoise MLPs split over the replicas by minibatch rows (replicated weights, gradient all-reduce) or by items (each replica
+    holds the W1 columns / W2 rows of its item slice; Main.Coach._denoise_item_shard) -- the same 30-epoch plateau either way."""
     need_gpu()
     seed = SEEDS[0]
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "curve.csv")
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_DENOISE_SHARD=denoise_shard)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
                str(29850 + os.getpid() % 100), os.path.join(REPO, "tests", "helpers", "curve_worker.py"), str(seed), str(EPOCHS), out]
         p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=1500)
@@ -106,7 +109,7 @@ def test_user_sharded_replicas_reach_the_same_plateau():
     for key, tol in (("Recall", 0.002), ("NDCG", 0.002)):
         spread, _ = _spread(key)
         h, r = _plateau(rows, key), _plateau(ref, key)
-        print(f"user-shard2 {key}@20 plateau {h:.4f} vs reference {r:.4f}")
+        print(f"user-shard2 (Denoise by {denoise_shard}) {key}@20 plateau {h:.4f} vs reference {r:.4f}")
         assert abs(h - r) <= max(tol, spread), f"user-sharded {key}: {h:.4f} vs reference {r:.4f}"
     for key, tol in (("Loss", 0.01), ("BPR Loss", 0.01), ("CL loss", 0.01), ("reg loss", 0.02)):
         r, h = _plateau(ref, key), _plateau(rows, key)
