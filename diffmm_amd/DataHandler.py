@@ -279,8 +279,10 @@ class DataHandler:
 
     def LoadData(self, graph_data: Optional[synth.SynthGraph] = None, sharded: bool = False) -> None:
         """sharded = True (one process per GPU, users sharded): the full-graph adjacency is not built -- every replica plans its own local block
-        (Coach.prepareModel) -- and `graph_data` may hold the interactions of the replica's own users only (synth.make_graph(user_lo=, user_hi=):
-        a per-shard load; the minibatch loaders of such a partial load see the own users' interactions)."""
+        (Coach.prepareModel).  The interaction LIST stays replicated in a real run: every replica draws the same global shuffle of it (the
+        reference's minibatches, Main.py:292-296), and a replica of an item-sharded Denoise reads every minibatch user's row over its item slice
+        (768 MB at 10M users).  Only the single-process replica emulation (tools/scale_epoch.py --emulate-world) passes a `graph_data` that holds
+        the own users' interactions alone (synth.make_graph(user_lo=, user_hi=)): the rows of the other users are then empty."""
         import scipy.sparse as sp
         g = graph_data if graph_data is not None else self._read()
         cfg, dev = self.config, self.device

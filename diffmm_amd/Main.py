@@ -39,7 +39,7 @@ class Coach:
         """precision: 1 = single bf16 MFMA product in the dense GEMMs (fast path), 3 = hi/lo split (~fp32, parity tests).
         world > 1: one process per GPU (torch.distributed initialised by the caller; backend 'nccl' == RCCL); the users are sharded over
         the replicas (diffmm_amd/sharded.py), every epoch makes exactly the reference's optimiser steps on the reference's minibatches.
-        layout: a sharded.ShardLayout to use instead of the edge-balanced one computed from the handler's graph (a per-shard load holds only the
+        layout: a sharded.ShardLayout to use instead of the edge-balanced one computed from the handler's graph (the replica emulation's graph holds only the
         own users' interactions).  emulate_replica (tools/scale_epoch.py): ONE process runs replica `rank` of `world` with every collective
         reduced to its local part (no process group is needed) -- the per-GPU work and memory of a job this box has no GPUs for."""
         self.handler, self.config, self.precision = handler, config, precision

@@ -6,7 +6,7 @@ phase times, the peak HBM allocation and the first epoch's losses.
     python tools/scale_epoch.py [--users 1000000 --items 100000 --latdim 256 --T 40 --batch 8192 --joint-iters 0]
 --joint-iters N > 0 stops the joint phase after N minibatches (its cost is E / batch full-graph iterations) and extrapolates; --diff-iters likewise.
 --emulate-world W [--emulate-rank r]: ONE process runs replica r of a W-replica user-sharded job on --users x --items (BASELINE config 5 is
---users 10000000 --items 1000000 --latdim 256 --T 1000 --emulate-world 8): the graph rows of the replica's own users only (a per-shard load), its
+--users 10000000 --items 1000000 --latdim 256 --T 1000 --emulate-world 8): the graph rows of the replica's own users only, its
 local adjacency blocks, its item slice of the Denoise MLPs, its share of the rebuild and of the evaluation -- with every collective reduced to
 its local part (diffmm_amd/comm.py: LOCAL).  What one GPU of that job computes and holds; the exchanges themselves are not in the timing."""
 import argparse, json, os, sys, time
