@@ -31,7 +31,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
-PMC_CHAIN_JSON = "r2f_pmc_chain_gemm.json"  # committed PMC summary of tools/roofline_target.py (tools/final_profile.sh)
+PMC_CHAIN_JSON = "r3_pmc_chain_gemm.json"  # committed PMC summary of tools/roofline_target.py (tools/final_profile.sh)
 
 
 def make_coach(args, rank: int, world: int):
