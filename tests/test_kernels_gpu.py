@@ -755,7 +755,7 @@ def test_item_project_and_expand(dev, B, I, D):
     assert torch.equal(Rc[:, I:], R[:, I:])
 
 
-@pytest.mark.parametrize("D,B,I", [(64, 300, 1000), (128, 130, 517), (256, 200, 777)])
+@pytest.mark.parametrize("D,B,I", [(64, 300, 1000), (128, 130, 517), (256, 200, 777), (256, 600, 1100)])  # (d = 256: the [256 rows, 64 items] tile)
 def test_item_expand_fused_equals_the_separate_passes(dev, D, B, I):
     """dmm_item_expand_fused against the passes it replaces, bit for bit where the arithmetic is the same: forward (item_expand -> cast_bf16,
     transpose_cast_bf16, incl. the time-embedding / pad columns and the zero batch-row padding of the transposed copy) and loss gradient

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""dmm_item_expand_fused alone at the diffusion step's shape (B = 4096, I = 6710, d = 64): forward mode and loss-gradient mode, HIP-event time."""
+"""dmm_item_expand_fused alone at the diffusion step's shape (default B = 4096, I = 6710, d = 64; argv: B I d): forward mode and loss-gradient
+modes, HIP-event time.  DMM_EXPAND_WIDE=0 / 1 / 2 picks the workgroup tile (csrc/itemspace.hip): [64 rows, 256 items] everywhere / the
+[256 rows, 64 items] tile with F staged in LDS at d = 256 (default) / at every d."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffmm_amd import ops
 dev = torch.device("cuda:0")
-B, I, D, Kp = 4096, 6710, 64, 6720
+B, I, D = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 6710, 64)
+Kp = (I + 10 + 63) // 64 * 64
 P, F = torch.randn(B, D, device=dev), torch.randn(I, D, device=dev)
 R = torch.randn(B, Kp, device=dev)
 y16, yT = torch.zeros(B, Kp, device=dev, dtype=torch.bfloat16), torch.zeros(Kp, B, device=dev, dtype=torch.bfloat16)
@@ -20,6 +23,7 @@ def t(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+print(f"B={B} I={I} d={D} DMM_EXPAND_WIDE={os.environ.get('DMM_EXPAND_WIDE', '1')}")
 print("forward      %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT, I, Kp, Kp)))
 print("loss, bits   %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0bits=bits)))
 print("loss, dense  %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0=x0)))
