@@ -42,6 +42,7 @@ class SynthGraph:
     tst_rows: np.ndarray  # int32, disjoint from train
     tst_cols: np.ndarray  # int32
     feats: List[np.ndarray]  # per modality, float32 [items, F_m]
+    clusters: Optional[Tuple[np.ndarray, np.ndarray]] = None  # (user_cluster [user_hi - user_lo], item_cluster [items]) of the generator: tools only
 
     @property
     def nnz(self) -> int:
@@ -120,7 +121,7 @@ def make_graph(users: int, items: int, feats: Tuple[int, ...] = (128, 768, 128),
     tr, tc = _dedup(rows_g[is_trn], item_k[is_trn], items)
     sr, sc = _dedup(rows_g[is_tst], item_k[is_tst], items)
     keep = np.ones(sr.shape[0], dtype=bool)
-    return SynthGraph(users, items, tr, tc, sr[keep], sc[keep], feat_list)
+    return SynthGraph(users, items, tr, tc, sr[keep], sc[keep], feat_list, clusters=(user_cluster, item_cluster))
 
 
 def named(name: str, seed: int = 1818, **over) -> SynthGraph:

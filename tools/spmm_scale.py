@@ -12,7 +12,12 @@ from diffmm_amd import graph, ops, synth, _lib as L
 
 def measure(g, D, dev, variant, reps=10, task_len=graph.TASK_LEN, order="row"):
     vec = 8 if variant.startswith("bf16") else 4
-    adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev, vec=vec, task_len=task_len, hub_order=order == "hub")
+    if order == "cluster":  # the generator's own communities as the schedule key: the ceiling of what any locality ordering could give
+        rowptr, col, val = graph.normalized_bipartite_csr(g.trn_rows, g.trn_cols, g.users, g.items)
+        key = np.concatenate([g.clusters[0].astype(np.int64), g.clusters[1].astype(np.int64) + 1000])
+        adj = graph.adjacency_from_csr(rowptr, col, val, D, dev, task_len, vec=vec, row_key=key)
+    else:
+        adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev, vec=vec, task_len=task_len, hub_order=order == "hub")
     X = torch.randn(adj.n, D, device=dev)
     Y = torch.empty_like(X)
     if variant == "f32":
@@ -48,6 +53,6 @@ if __name__ == "__main__":
     for D in [int(x) for x in a.dims.split(",")]:
         for v in a.variants.split(","):
             for tl in [int(x) for x in a.task_lens.split(",")]:
-                for od in a.orders.split(","):  # row: tasks in row order; hub: rows sharing a highest-degree neighbour scheduled together (graph.hub_keys)
+                for od in a.orders.split(","):  # row: tasks in row order; hub: rows sharing a highest-degree neighbour scheduled together (graph.hub_keys); cluster: by the generator's communities
                     print(json.dumps(measure(g, D, dev, v, task_len=tl, order=od)), flush=True)
                     torch.cuda.empty_cache()
