@@ -55,7 +55,7 @@ class ExpandFusedArgs(C.Structure):
     _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("F", C.c_void_p), ("ldf", C.c_int64), ("R", C.c_void_p), ("ldr", C.c_int64), ("X0", C.c_void_p),
                 ("ldx0", C.c_int64), ("w", C.c_void_p), ("gscale", C.c_double), ("Y16", C.c_void_p), ("ldy", C.c_int64), ("YT", C.c_void_p), ("ldt", C.c_int64),
                 ("csum", C.c_void_p), ("B", C.c_int32), ("I", C.c_int32), ("Kc", C.c_int32), ("Kt", C.c_int32), ("X0bits", C.c_void_p), ("ldbits", C.c_int64),
-                ("gscale_dev", C.c_void_p)]
+                ("gscale_dev", C.c_void_p), ("F16", C.c_void_p), ("ldf16", C.c_int64)]
 
 
 class RownormBwdProblem(C.Structure):

@@ -309,6 +309,7 @@ struct ExpandFusedP {
   __bf16* YT; long long ldt;        // [Kt, >= Bp]
   float* csum;                      // MODE 1: [I]
   int B, I, Kc, Kt;
+  const __bf16* F16; long long ldf16;  // optional bf16 copy of F (strip kernel: staged instead of F, half the bytes)
 };
 
 template <int D, int MODE>
@@ -466,36 +467,30 @@ __global__ __launch_bounds__(256, (D > 128 ? 3 : 1)) void item_expand_fused_kern
   }
 }
 
-// ---- the same, on a [256 rows, 64 items] workgroup tile (d = 256) -------------------------------------------------------------------------------
-// The tile above gives every wave its own 64 item columns, so a workgroup loads [256 items, d] of F (fp32) for 64 rows of the residual: at d = 256
-// the F traffic is four times the residual's and the kernel ran at a third of its byte floor (3.8 / 4.9 ms against 1.7 at 8192 x 100k).  Here the four
-// waves take 64 ROWS each and share the same 64 item columns: their [64, d] slice of F is staged ONCE per workgroup in LDS as bf16 (row stride d + 8:
-// the 16 rows of a fragment read hit distinct banks) and every wave reads its MFMA fragments from there -- F traffic = the residual's, a quarter of
-// before; the P fragments of a wave's own rows come from global memory, half of d at a time.  The products are accumulated in the same k order, so
-// the results are bit-identical to item_expand_fused_kernel's.  The transposed copy leaves as 512-byte row segments (four 128-byte pieces per item).
+// ---- the same with the P fragments resident over a strip of item tiles (the default) ---------------------------------------------------------------
+// The tile above is bound by its operand fragments, not by the [B, I] passes it fuses: every [64 rows, 256 items] tile loads [256 items, d] of F (fp32,
+// each wave its own 64 columns) and, four times over, the [64 rows, d] fragments of P -- at d = 256 that is 16 + 16 bytes of fragment loads from L2 per
+// output element against 4 of residual and 4 of output (3.8 / 4.6 ms against a byte floor of 1.7 at 8192 x 100k).  Here a wave keeps the P fragments of
+// its 32 rows ([32, d]: 64 registers at d = 256) for the whole kernel and the workgroup (4 waves = 128 rows) walks `tiles` consecutive 64-item tiles:
+// per tile it stages the [64, d] slice of F ONCE in LDS as bf16 (row stride d + 8: the 16 rows of a fragment read hit distinct banks), forms the
+// products column tile by column tile (8 live accumulators), writes the row-major bf16 result and passes the transposed copy through LDS as
+// 256-byte row segments.  Same k order as the tile above: bit-identical results.  (An intermediate form -- [256 rows, 64 items] per workgroup, F in
+// LDS, P fragments still per tile -- gained 25-30 % at d = 128 and 10 % at d = 256; this one 35-40 % / 22-37 %.)
 template <int D, int MODE>
-__global__ __launch_bounds__(256, 2) void item_expand_fused_wide_kernel(const ExpandFusedP A) {
-  constexpr int KS = D / 32, LDF = D + 8, TLD = 256 + 8;
-  constexpr int KH = KS > 4 ? 2 : KS;  // k steps whose P fragments are held at a time (d = 256: two -- with four the loss-gradient modes spill)
+__global__ __launch_bounds__(256, 2) void item_expand_fused_strip_kernel(const ExpandFusedP A, int tiles) {
+  constexpr int KS = D / 32, LDF = D + 8, TLD = 128 + 8;
   __shared__ __attribute__((aligned(16))) __bf16 fl[64 * LDF];
   __shared__ __attribute__((aligned(16))) __bf16 tt[64 * TLD];
+  __shared__ float csl[4][64];  // loss modes: the waves' column sums of the current tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, kg = lane >> 4;
-  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 256, rowW = row0 + wave * 64;
+  const int row0 = blockIdx.y * 128, rowW = row0 + wave * 32;
   const int B = A.B, I = A.I, Kc = A.Kc;
   constexpr bool LOSS = MODE != 0;
-  // F slice -> LDS (bf16): 64 items x D, consecutive threads on consecutive 16-byte pieces of a row (clamped rows: masked where used)
-  for (int idx = threadIdx.x; idx < 64 * (D / 4); idx += 256) {
-    const int it = idx / (D / 4), c4 = idx % (D / 4);
-    const float4 v = *reinterpret_cast<const float4*>(A.F + (long long)min(col0 + it, I - 1) * A.ldf + c4 * 4);
-    __bf16 h[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    *reinterpret_cast<uint2*>(fl + it * LDF + c4 * 4) = *reinterpret_cast<const uint2*>(h);
-  }
-  float4 rr[4][4];
-  float gc[4];
-  long long rofs[4];
+  float gc[2];
+  long long rofs[2];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < 2; ++rt) {
     const int row = rowW + rt * 16 + fr, rc = min(row, B - 1);
     rofs[rt] = (long long)rc;
     gc[rt] = 0.f;
@@ -504,124 +499,123 @@ __global__ __launch_bounds__(256, 2) void item_expand_fused_wide_kernel(const Ex
       gc[rt] = row < B ? g : 0.f;
     }
   }
+  bf16x8 fp[2][KS];  // this wave's rows of P, for every tile of the strip
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int cc = min(col0 + ct * 16 + kg * 4, Kc - 4);
-      rr[ct][rt] = *reinterpret_cast<const float4*>(A.R + rofs[rt] * A.ldr + cc);
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* p = A.P + rofs[rt] * A.ldp + ks * 32 + kg * 8;
+      fp[rt][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
     }
-  if (MODE == 2) {
-    uint32_t wd[4][4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const int cc = min(col0 + ct * 16 + kg * 4, ((I + 31) & ~31) - 4);
-        wd[ct][rt] = A.X0b[rofs[rt] * A.ldb + (cc >> 5)] >> (cc & 31);
-      }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        float4& r = rr[ct][rt];
-        const uint32_t w_ = wd[ct][rt];
-        r = make_float4(__fmul_rn(gc[rt], r.x - (float)(w_ & 1u)), __fmul_rn(gc[rt], r.y - (float)((w_ >> 1) & 1u)),
-                        __fmul_rn(gc[rt], r.z - (float)((w_ >> 2) & 1u)), __fmul_rn(gc[rt], r.w - (float)((w_ >> 3) & 1u)));
-      }
-  } else if (MODE == 1) {
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      float4 xx[4];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const int cc = min(col0 + ct * 16 + kg * 4, Kc - 4);
-        xx[rt] = *reinterpret_cast<const float4*>(A.X0 + rofs[rt] * A.ldx0 + cc);
-      }
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        float4& r = rr[ct][rt];
-        r = make_float4(__fmul_rn(gc[rt], r.x - xx[rt].x), __fmul_rn(gc[rt], r.y - xx[rt].y), __fmul_rn(gc[rt], r.z - xx[rt].z),
-                        __fmul_rn(gc[rt], r.w - xx[rt].w));
-      }
-    }
-  }
-  __syncthreads();  // F slice staged
-  f32x4 accs[4][4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) accs[ct][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ch = 0; ch < KS / KH; ++ch) {
-    bf16x8 fp[4][KH];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-        const float* p = A.P + rofs[rt] * A.ldp + (ch * KH + ks) * 32 + kg * 8;
-        fp[rt][ks] = is_cvt8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
-      }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      bf16x8 ff[KH];
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) ff[ks] = *reinterpret_cast<const bf16x8*>(fl + (ct * 16 + fr) * LDF + (ch * KH + ks) * 32 + kg * 8);
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        f32x4 a = accs[ct][rt];
-#pragma unroll
-        for (int ks = 0; ks < KH; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ks], fp[rt][ks], a, 0, 0, 0);
-        accs[ct][rt] = a;
-      }
-    }
-  }
-  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const f32x4 acc = accs[ct][rt];
-      // acc[r] = (item column col0 + ct*16 + kg*4 + r, row rowW + rt*16 + fr)
-      const int row = rowW + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
-      const float4 r4 = rr[ct][rt];
-      float v[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (LOSS) {
-          v[j] = col + j < I ? v[j] + acc[j] : 0.f;
-        } else {
-          if (col + j < I) v[j] += acc[j];
-        }
-        if (row >= B || col >= Kc) v[j] = 0.f;
-        cs[j] += v[j];
-      }
-      const bf16x4v b4 = bf16x4v{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-      if (row < B && col < Kc) *reinterpret_cast<bf16x4v*>(A.Y16 + (long long)row * A.ldy + col) = b4;
-      const int cl = ct * 16 + kg * 4, rl = wave * 64 + rt * 16 + fr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tt[(cl + j) * TLD + rl] = b4[j];
-    }
-    if (LOSS) {  // column sums over the wave's 64 rows: reduce over fr, then one atomic per column and wave
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float c = cs[j];
-        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
-        const int col = col0 + ct * 16 + kg * 4 + j;
-        if (fr == 0 && col < I) atomicAdd(A.csum + col, c);
-      }
-    }
-  }
-  __syncthreads();
-  // transposed copy: thread t owns 64 consecutive batch rows (128 bytes) of tile column t / 4
-  const int c = col0 + (int)(threadIdx.x >> 2), q = threadIdx.x & 3;
   const int Bp = (B + 63) & ~63;
-  if (c < A.Kt && row0 + q * 64 < Bp) {
-    const uint4* src = reinterpret_cast<const uint4*>(tt + (threadIdx.x >> 2) * TLD + q * 64);
-    uint4* dst = reinterpret_cast<uint4*>(A.YT + (long long)c * A.ldt + row0 + q * 64);
+  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+  for (int t = 0; t < tiles; ++t) {
+    const int col0 = (blockIdx.x * tiles + t) * 64;
+    if (col0 >= Kc) break;  // (uniform)
+    __syncthreads();        // the previous tile's readers of fl / tt are done
+    if (A.F16) {  // (uniform) the caller's bf16 copy of F: the same values, half the bytes
+      for (int idx = threadIdx.x; idx < 64 * (D / 8); idx += 256) {
+        const int it = idx / (D / 8), c8 = idx % (D / 8);
+        *reinterpret_cast<uint4*>(fl + it * LDF + c8 * 8) = *reinterpret_cast<const uint4*>(A.F16 + (long long)min(col0 + it, I - 1) * A.ldf16 + c8 * 8);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < 64 * (D / 4); idx += 256) {
+        const int it = idx / (D / 4), c4 = idx % (D / 4);
+        const float4 v = *reinterpret_cast<const float4*>(A.F + (long long)min(col0 + it, I - 1) * A.ldf + c4 * 4);
+        __bf16 h[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<uint2*>(fl + it * LDF + c4 * 4) = *reinterpret_cast<const uint2*>(h);
+      }
+    }
+    float4 rr[4][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = src[i];
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int cc = min(col0 + ct * 16 + kg * 4, Kc - 4);
+        rr[ct][rt] = *reinterpret_cast<const float4*>(A.R + rofs[rt] * A.ldr + cc);
+      }
+    if (MODE == 2) {
+      uint32_t wd[4][2];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int cc = min(col0 + ct * 16 + kg * 4, ((I + 31) & ~31) - 4);
+          wd[ct][rt] = A.X0b[rofs[rt] * A.ldb + (cc >> 5)] >> (cc & 31);
+        }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          float4& r = rr[ct][rt];
+          const uint32_t w_ = wd[ct][rt];
+          r = make_float4(__fmul_rn(gc[rt], r.x - (float)(w_ & 1u)), __fmul_rn(gc[rt], r.y - (float)((w_ >> 1) & 1u)),
+                          __fmul_rn(gc[rt], r.z - (float)((w_ >> 2) & 1u)), __fmul_rn(gc[rt], r.w - (float)((w_ >> 3) & 1u)));
+        }
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int cc = min(col0 + ct * 16 + kg * 4, Kc - 4);
+          const float4 xx = *reinterpret_cast<const float4*>(A.X0 + rofs[rt] * A.ldx0 + cc);
+          float4& r = rr[ct][rt];
+          r = make_float4(__fmul_rn(gc[rt], r.x - xx.x), __fmul_rn(gc[rt], r.y - xx.y), __fmul_rn(gc[rt], r.z - xx.z), __fmul_rn(gc[rt], r.w - xx.w));
+        }
+    }
+    __syncthreads();  // F slice staged
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      bf16x8 ff[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) ff[ks] = *reinterpret_cast<const bf16x8*>(fl + (ct * 16 + fr) * LDF + ks * 32 + kg * 8);
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff[ks], fp[rt][ks], acc, 0, 0, 0);
+        // acc[r] = (item column col0 + ct*16 + kg*4 + r, row rowW + rt*16 + fr)
+        const int row = rowW + rt * 16 + fr, col = col0 + ct * 16 + kg * 4;
+        const float4 r4 = rr[ct][rt];
+        float v[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (LOSS) {
+            v[j] = col + j < I ? v[j] + acc[j] : 0.f;
+          } else {
+            if (col + j < I) v[j] += acc[j];
+          }
+          if (row >= B || col >= Kc) v[j] = 0.f;
+          cs[j] += v[j];
+        }
+        const bf16x4v b4 = bf16x4v{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        if (row < B && col < Kc) *reinterpret_cast<bf16x4v*>(A.Y16 + (long long)row * A.ldy + col) = b4;
+        const int cl = ct * 16 + kg * 4, rl = wave * 32 + rt * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tt[(cl + j) * TLD + rl] = b4[j];
+      }
+      if (LOSS) {  // column sums over the wave's 32 rows -> LDS; the workgroup adds its 128 rows' sums with ONE atomic instruction per tile, below
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float c = cs[j];
+          c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+          if (fr == 0) csl[wave][ct * 16 + kg * 4 + j] = c;
+        }
+      }
+    }
+    __syncthreads();
+    // (64 lanes on 64 consecutive columns: one contiguous 256-byte atomic instruction per workgroup and tile -- per wave and column group it was 64
+    // instructions of 4 scattered dwords each, which at 8192 x 100k cost more than the tile's memory traffic: 3.6 ms against 2.4 without the sums)
+    if (LOSS && wave == 0 && col0 + lane < I) atomicAdd(A.csum + col0 + lane, (csl[0][lane] + csl[1][lane]) + (csl[2][lane] + csl[3][lane]));
+    // transposed copy: thread t owns 32 consecutive batch rows (64 bytes) of tile column t / 4
+    const int c = col0 + (int)(threadIdx.x >> 2), q = threadIdx.x & 3;
+    if (c < A.Kt && row0 + q * 32 < Bp) {
+      const uint4* src = reinterpret_cast<const uint4*>(tt + (threadIdx.x >> 2) * TLD + q * 32);
+      uint4* dst = reinterpret_cast<uint4*>(A.YT + (long long)c * A.ldt + row0 + q * 32);
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) dst[i2] = src[i2];
+    }
   }
 }
 
@@ -728,21 +722,27 @@ extern "C" int dmm_item_expand_fused(const dmm_expand_fused_args* a, int mode, i
   ExpandFusedP p;
   p.P = a->P; p.ldp = a->ldp; p.F = a->F; p.ldf = a->ldf; p.R = a->R; p.ldr = a->ldr; p.X0 = a->X0; p.ldx0 = a->ldx0; p.X0b = a->X0bits; p.ldb = a->ldbits; p.w = a->w; p.gscale = a->gscale; p.gs_dev = a->gscale_dev;
   p.Y16 = (__bf16*)a->Y16; p.ldy = a->ldy; p.YT = (__bf16*)a->YT; p.ldt = a->ldt; p.csum = a->csum; p.B = a->B; p.I = a->I; p.Kc = a->Kc; p.Kt = a->Kt;
+  p.F16 = (const __bf16*)a->F16; p.ldf16 = a->ldf16;
+  DMM_CHECK_ARG(!a->F16 || (a->ldf16 % 8 == 0 && a->ldf16 >= D && ((uintptr_t)a->F16 & 15) == 0), "dmm_item_expand_fused: F16 rows must be 16-byte aligned bf16 [I, >= D]");
   hipStream_t s = (hipStream_t)stream;
   const int km = mode == 0 ? 0 : (a->X0 ? 1 : 2);
-  static const int wide = [] { const char* e = getenv("DMM_EXPAND_WIDE"); return e ? atoi(e) : 1; }();  // 0: never, 1: d >= 128, 2: every d (read once)
-  if (wide == 2 || (wide == 1 && D >= 128)) {
-    dim3 gw((a->Kc + 63) / 64, (Bp + 255) / 256);
-#define DMM_EXPAND_WIDE_LAUNCH(DD)                                                                                     \
-    do {                                                                                                                 \
-      if (km == 0) hipLaunchKernelGGL((item_expand_fused_wide_kernel<DD, 0>), gw, dim3(256), 0, s, p);                 \
-      else if (km == 1) hipLaunchKernelGGL((item_expand_fused_wide_kernel<DD, 1>), gw, dim3(256), 0, s, p);            \
-      else hipLaunchKernelGGL((item_expand_fused_wide_kernel<DD, 2>), gw, dim3(256), 0, s, p);                         \
+  // tile choice (DMM_EXPAND_WIDE, read once): 1 (default) = the strip kernel, 0 = the [64 rows, 256 items] tile
+  static const int strip = [] { const char* e = getenv("DMM_EXPAND_WIDE"); return e ? atoi(e) : 1; }();
+  if (strip) {
+    const int ntile = (a->Kc + 63) / 64, yb = (Bp + 127) / 128;
+    int nt = 16;
+    while (nt > 1 && (long long)((ntile + nt - 1) / nt) * yb < 1024) nt /= 2;  // enough workgroups to fill the chip four times over
+    dim3 gs((ntile + nt - 1) / nt, yb);
+#define DMM_EXPAND_STRIP_LAUNCH(DD)                                                                                         \
+    do {                                                                                                                      \
+      if (km == 0) hipLaunchKernelGGL((item_expand_fused_strip_kernel<DD, 0>), gs, dim3(256), 0, s, p, nt);                 \
+      else if (km == 1) hipLaunchKernelGGL((item_expand_fused_strip_kernel<DD, 1>), gs, dim3(256), 0, s, p, nt);            \
+      else hipLaunchKernelGGL((item_expand_fused_strip_kernel<DD, 2>), gs, dim3(256), 0, s, p, nt);                         \
     } while (0)
-    if (D == 64) DMM_EXPAND_WIDE_LAUNCH(64);
-    else if (D == 128) DMM_EXPAND_WIDE_LAUNCH(128);
-    else DMM_EXPAND_WIDE_LAUNCH(256);
-#undef DMM_EXPAND_WIDE_LAUNCH
+    if (D == 64) DMM_EXPAND_STRIP_LAUNCH(64);
+    else if (D == 128) DMM_EXPAND_STRIP_LAUNCH(128);
+    else DMM_EXPAND_STRIP_LAUNCH(256);
+#undef DMM_EXPAND_STRIP_LAUNCH
     DMM_LAUNCH_CHECK("dmm_item_expand_fused");
     return 0;
   }

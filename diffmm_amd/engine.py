@@ -656,6 +656,7 @@ class DiffusionEngine:
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
         self._x0_rows, self._ie16 = None, None  # the current training batch as CSR rows (if it came as such); bf16 i_embs for its gather
         self._FT16 = None  # F^T operands of the folded products (_folded_prepare)
+        self._feat16 = None  # bf16 copies of the modality features for the fused expand kernels (made per training step)
         self._x0_bits, self._bits_buf = None, None  # the current batch's x_0 rows as bit masks (batched bf16 step fed with CSR rows)
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
@@ -925,7 +926,10 @@ class DiffusionEngine:
             a, P = self.act[m], self.P[m]
             ops.mul(a["proj"][:B], a["gate"][:B], a["pg"][:B])
             if self._fused_expand():  # x_t += (proj * gate) F^T written only as layer 1's bf16 operand and its transposed copy (the backward's)
-                ops.item_expand_fused(a["pg"][:B], feats[m], a["xcat"][:B], W[m]["xa16"][:B], W[m]["xcatT16"], I, self.Kp, self.Kp)
+                if self._feat16 is None:  # bf16 copies of the modality features: what the expand kernels stage (both directions of this step)
+                    self._feat16 = [torch.zeros(I, self.D, dtype=torch.bfloat16, device=self.dev) for _ in range(M)]
+                ops.cast_bf16(feats[m], self._feat16[m])
+                ops.item_expand_fused(a["pg"][:B], feats[m], a["xcat"][:B], W[m]["xa16"][:B], W[m]["xcatT16"], I, self.Kp, self.Kp, F16=self._feat16[m])
             elif self._item_kernels(1):
                 ops.item_expand(a["pg"][:B], feats[m], a["xcat"][:B], a["xcat"][:B], I)  # x_t += (proj * gate) F^T
             else:
@@ -1009,7 +1013,8 @@ class DiffusionEngine:
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, None, None, w["dum"][:B],
                               gscale_dev=gs_dev)
                 ops.item_expand_fused(w["dum"][:B], feats[m], a["out"][:B], w["xb16"][:B], w["doutT16"], I, self.Kp, I, w=a["w"], gscale=gscale,
-                                      gscale_dev=gs_dev, csum=P.g(self.L2 + ".bias"), **(dict(x0bits=self._x0_bits[:B]) if self._x0_bits is not None else dict(x0=x0p)))
+                                      gscale_dev=gs_dev, csum=P.g(self.L2 + ".bias"), F16=self._feat16[m] if self._feat16 is not None else None,
+                                      **(dict(x0bits=self._x0_bits[:B]) if self._x0_bits is not None else dict(x0=x0p)))
             else:
                 ops.diff_loss(a["out"][:B], x0p, a["w"], a["um"][:B], self.ui[:B], I, self.hp["sim_weight"], reg_term, gscale, a["loss"][:B], w["dout"][:B],
                               w["dum"][:B], gscale_dev=gs_dev)

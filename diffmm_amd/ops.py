@@ -777,9 +777,10 @@ def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:
 
 def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, I: int, Kc: int, Kt: int, x0: Optional[Tensor] = None,
                       w: Optional[Tensor] = None, gscale: float = 0.0, csum: Optional[Tensor] = None, x0bits: Optional[Tensor] = None,
-                      gscale_dev: Optional[Tensor] = None) -> None:
+                      gscale_dev: Optional[Tensor] = None, F16: Optional[Tensor] = None) -> None:
     """item_expand whose result goes straight into the bf16 operands of the next GEMMs (Y16 [B, Kc] row-major, YT [Kt, round_up(B, 64)]
-    transposed).  x0 / w / csum given: the loss-gradient form v = gscale w[b] 2/I (R - x0) + P F^T with its column sums added to csum."""
+    transposed).  x0 / w / csum given: the loss-gradient form v = gscale w[b] 2/I (R - x0) + P F^T with its column sums added to csum.
+    F16: a bf16 copy of F (cast_bf16) for the kernel to stage instead of F."""
     B, D = P.shape[0], P.shape[1]
     mode = 0 if (x0 is None and x0bits is None) else 1
     for t in (P, F, R) + ((x0,) if x0 is not None else ()):
@@ -792,6 +793,10 @@ def item_expand_fused(P: Tensor, F: Tensor, R: Tensor, Y16: Tensor, YT: Tensor, 
     a = L.ExpandFusedArgs()
     a.P, a.ldp, a.F, a.ldf, a.R, a.ldr = L.ptr(P), P.stride(0), L.ptr(F), F.stride(0), L.ptr(R), R.stride(0)
     a.Y16, a.ldy, a.YT, a.ldt, a.B, a.I, a.Kc, a.Kt = L.ptr(Y16), Y16.stride(0), L.ptr(YT), YT.stride(0), B, I, Kc, Kt
+    if F16 is not None:
+        if F16.dtype != torch.bfloat16 or F16.stride(1) != 1 or F16.shape[0] < I or F16.shape[1] != D:
+            raise ValueError("item_expand_fused: F16 must be the bfloat16 copy of F")
+        a.F16, a.ldf16 = L.ptr(F16), F16.stride(0)
     if mode:
         if w.dtype != torch.float64 or csum is None or csum.numel() < I:
             raise ValueError("item_expand_fused: w is float64 [B], csum fp32 [I]")

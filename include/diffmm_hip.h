@@ -421,6 +421,7 @@ typedef struct dmm_expand_fused_args {
   int32_t B, I, Kc, Kt;
   const uint32_t* X0bits; int64_t ldbits; /* mode 1, X0 == NULL: x_0 as bit masks (dmm_csr_row_bits), ldbits words per row */
   const double* gscale_dev;               /* mode 1: NULL, or a device scalar multiplied into gscale (see dmm_diff_loss) */
+  const void* F16; int64_t ldf16;         /* optional: bf16 copy of F [I, >= D] (dmm_cast_bf16 of it): staged instead of F -- same values, half the bytes */
 } dmm_expand_fused_args;
 int dmm_item_expand_fused(const dmm_expand_fused_args* a /*host*/, int mode, int D, void* stream);
 /* The same product for up to 4 problems in one launch, 64 rows per workgroup (many short rows), with the layouts of the joint step's

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dmm_item_expand_fused alone at the diffusion step's shape (default B = 4096, I = 6710, d = 64; argv: B I d): forward mode and loss-gradient
-modes, HIP-event time.  DMM_EXPAND_WIDE=0 / 1 / 2 picks the workgroup tile (csrc/itemspace.hip): [64 rows, 256 items] everywhere / the
-[256 rows, 64 items] tile with F staged in LDS at d = 256 (default) / at every d."""
+modes, HIP-event time.  DMM_EXPAND_WIDE=1 (default): the strip kernel (P fragments resident over a strip of item tiles, F staged per tile in LDS); 0: the
+[64 rows, 256 items] tile.  EXPAND_F16=0: without the bf16 copy of F."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffmm_amd import ops
@@ -24,6 +24,7 @@ def t(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 print(f"B={B} I={I} d={D} DMM_EXPAND_WIDE={os.environ.get('DMM_EXPAND_WIDE', '1')}")
-print("forward      %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT, I, Kp, Kp)))
-print("loss, bits   %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0bits=bits)))
-print("loss, dense  %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0=x0)))
+F16 = F.bfloat16() if os.environ.get("EXPAND_F16", "1") == "1" else None  # (EXPAND_F16=0: the kernel stages the fp32 F)
+print("forward      %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT, I, Kp, Kp, F16=F16)))
+print("loss, bits   %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0bits=bits, F16=F16)))
+print("loss, dense  %.1f us" % t(lambda: ops.item_expand_fused(P, F, R, y16, yT[:I], I, Kp, I, w=w, gscale=1e-3, csum=cs, x0=x0, F16=F16)))
