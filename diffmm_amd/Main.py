@@ -201,6 +201,7 @@ class Coach:
             self.best = {k: (int(v) if k == "epoch" else float(v)) for k, v in sd["best"].items()}
             self.his_max = [float(v) for v in sd["his_max"]]
         DE.w16_step = [-1] * DE.M  # bf16 weight copies of the reverse chain are stale
+        DE.w16_train_step = [-1] * DE.M  # ... and the training step's
         J._plans.clear()
         J._emb16_step = -1  # ... and so is the embedding table's bf16 gather copy
         h.trainLoader.gen.set_state(sd["gen"]["train_loader"].cpu()); h.diffusionLoader.gen.set_state(sd["gen"]["diffusion_loader"].cpu())

@@ -120,7 +120,7 @@ _SIGS = {
     "dmm_sumsq": (C.c_int, [_P, _L, _F, _P, _P, _P]),
     "dmm_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P]),
     "dmm_adam_step_prefix": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L]),
-    "dmm_adam_step_x16": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L, _P, _L]),
+    "dmm_adam_step_x16": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L, _P, _L, _L]),
     "dmm_qsample_temb": (C.c_int, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _U64, _U64, _P, _P]),
     "dmm_csr_dense_rows": (C.c_int, [_P, _P, _P, _I, _I, _P, _L, _P]),
     "dmm_csr_dense_rows_slice": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _L, _P]),

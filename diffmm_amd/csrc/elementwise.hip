@@ -262,7 +262,7 @@ struct AdamExtra {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, AdamExtra ex, float l2c, float step_size,
                                                     float b1, float b2, float inv_sqrt_c2, float eps, int64_t l2_n, __bf16* __restrict__ p16,
-                                                    int64_t p16_n) {
+                                                    int64_t p16_n, int64_t p16_lo) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float pv = p[i];
     float gr = g[i];
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     v[i] = vv;
     const float pn = pv - step_size * mm / (sqrtf(vv) * inv_sqrt_c2 + eps);
     p[i] = pn;
-    if (i < p16_n) p16[i] = (__bf16)pn;  // the bf16 gather copy of a prefix (the embedding table), written by the step that changes it
+    // the bf16 copy of a window of the parameters (the embedding table's gather copy; a Denoise's W1 | W2 GEMM operands), written by the step that
+    // changes them
+    if (i >= p16_lo && i < p16_lo + p16_n) p16[i - p16_lo] = (__bf16)pn;
   }
 }
 
@@ -570,14 +572,14 @@ extern "C" int dmm_adam_step(float* p, const float* g, float* m, float* v, int64
 
 extern "C" int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
                                     int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n) {
-  return dmm_adam_step_x16(p, g, m, v, n, extra, extra_n, n_extra, l2_coef, lr, beta1, beta2, eps, step, stream, l2_n, nullptr, 0);
+  return dmm_adam_step_x16(p, g, m, v, n, extra, extra_n, n_extra, l2_coef, lr, beta1, beta2, eps, step, stream, l2_n, nullptr, 0, 0);
 }
 
 extern "C" int dmm_adam_step_x16(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra, const int64_t* extra_n,
                                  int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n,
-                                 void* p16, int64_t p16_n) {
+                                 void* p16, int64_t p16_n, int64_t p16_lo) {
   DMM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && n_extra >= 0 && n_extra <= 4 && l2_n >= 0, "dmm_adam_step: bad arguments");
-  DMM_CHECK_ARG(p16_n >= 0 && p16_n <= n && (p16_n == 0 || p16), "dmm_adam_step_x16: p16 must cover p16_n <= n elements");
+  DMM_CHECK_ARG(p16_n >= 0 && p16_lo >= 0 && p16_lo + p16_n <= n && (p16_n == 0 || p16), "dmm_adam_step_x16: p16 must cover the window [p16_lo, p16_lo + p16_n) of the n parameters");
   AdamExtra ex = {};
   ex.cnt = n_extra;
   for (int k = 0; k < n_extra; ++k) {
@@ -586,7 +588,7 @@ extern "C" int dmm_adam_step_x16(float* p, const float* g, float* m, float* v, i
   }
   const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ex, l2_coef,
-                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps, l2_n, (__bf16*)p16, p16_n);
+                     (float)((double)lr / c1), beta1, beta2, (float)(1.0 / sqrt(c2)), eps, l2_n, (__bf16*)p16, p16_n, p16_lo);
   DMM_LAUNCH_CHECK("dmm_adam_step");
   return 0;
 }

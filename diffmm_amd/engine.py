@@ -641,7 +641,13 @@ class DiffusionEngine:
         r16 = self.dense_rows_max
         self.cxa16, self.cxb16, self.ch16 = [zb(r16, Kp) for _ in range(M)], [zb(r16, Kp) for _ in range(M)], [zb(R, H) for _ in range(M)]
         self.xa, self.xa16, self.xb16, self.h16 = self.cxa[0], self.cxa16[0], self.cxb16[0], self.ch16[0]
-        self.w1_16, self.w2_16 = [zb(H, Kp) for _ in range(M)], [zb(items, H) for _ in range(M)]
+        # bf16 copies of W1 | W2 (the GEMM operands): one buffer per modality laid out like the two tensors in the flat parameter buffer, so that Adam
+        # writes them with the weights (dmm_adam_step_x16) and a training step casts them only when they were changed from outside (w16_train_step)
+        if self.P[0].offsets[self.L2 + ".weight"] != self.P[0].offsets["in_layers.0.weight"] + H * Kp:
+            raise AssertionError("DiffusionEngine: W1 and W2 must be adjacent in the flat parameter buffer")
+        self._w16 = [zb(H * Kp + items * H) for _ in range(M)]
+        self.w1_16, self.w2_16 = [w[: H * Kp].view(H, Kp) for w in self._w16], [w[H * Kp:].view(items, H) for w in self._w16]
+        self.w16_train_step = [-1] * M  # Adam step at which w1_16 / w2_16 were last made equal to bf16(W1), bf16(W2)
         if any(w % 8 for w in hidden):
             raise ValueError("DiffusionEngine: hidden widths must be multiples of 8 (bf16 operand rows are 16-byte pieces)")
         self.wmid16 = [[zb(dout, din) for _, din, dout in self.mids] for _ in range(M)]
@@ -689,6 +695,7 @@ class DiffusionEngine:
         w1[:, : self.I + self.te] = w1_full
         t["in_layers.0.weight"] = w1
         self.P[m].load(t)
+        self.w16_train_step[m] = -1
 
     def state_dict(self, m: int) -> Dict[str, Tensor]:
         sd = self.P[m].state_dict()
@@ -743,9 +750,7 @@ class DiffusionEngine:
     def _mlp_train_bf16(self, m: int, xcat: Tensor, h: Tensor, out: Tensor):
         """Training-time Denoise MLP on the bf16 NT kernel: operands are cast once, h is also kept in bf16 for the backward."""
         P, B = self.P[m], xcat.shape[0]
-        ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
-        ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
-        self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
+        self._train_weights_bf16(m)
         ops.cast_bf16(xcat, self.xa16[:B])
         ops.gemm_bf16_nt(self.xa16[:B], self.w1_16[m], out=h, out_bf16=self.h16[:B], bias=P.view("in_layers.0.bias"), act=L.ACT_TANH)
         if self.mids:
@@ -934,9 +939,7 @@ class DiffusionEngine:
                 ops.item_expand(a["pg"][:B], feats[m], a["xcat"][:B], a["xcat"][:B], I)  # x_t += (proj * gate) F^T
             else:
                 ops.gemm(a["pg"][:B], feats[m], out=a["xcat"][:B], trans_b=True, residual=a["xcat"][:B], e1=1.0, e2=1.0, precision=1, N=I)
-            ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
-            ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
-            self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its copies
+            self._train_weights_bf16(m)
             if not self._fused_expand():
                 ops.cast_bf16(a["xcat"][:B], W[m]["xa16"][:B])
         if sh is None:
@@ -1200,12 +1203,23 @@ class DiffusionEngine:
         self.rng_step += 1
         return means
 
+    def _train_weights_bf16(self, m: int):
+        """bf16 W1 / W2 for the training step's GEMMs: written by the last Adam step (reduce_and_step); cast here only if the weights came from
+        outside since (load_reference_state, a checkpoint, a test poking P.data before its first step)."""
+        P = self.P[m]
+        if self.w16_train_step[m] != P.step:
+            ops.cast_bf16(P.view("in_layers.0.weight"), self.w1_16[m])
+            ops.cast_bf16(P.view(self.L2 + ".weight"), self.w2_16[m])
+            self.w16_train_step[m] = P.step
+        self.w16_step[m] = -1  # weights are about to change: the rebuild must refresh its other copies
+
     def reduce_and_step(self, m: int):
         P = self.P[m]
         if self.shard_world > 1:
             comm.all_reduce(P.grad, group=self.shard_group)  # sum: every replica's rows carry the 1 / (global batch) scale already
         P.step += 1
-        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step)
+        ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, p16=self._w16[m], p16_lo=P.offsets["in_layers.0.weight"])
+        self.w16_train_step[m] = P.step
 
     # -- reverse chain (generate_view, Model.py:300-322) ------------------------------------------------
     def _refresh_bf16_weights(self, m: int):

@@ -517,19 +517,19 @@ def sumsq(x: Tensor, scale: float, out: Tensor, scratch: Optional[Tensor] = None
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, extra: Sequence[Tensor] = (), extra_n: Sequence[int] = (),
               l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, l2_n: Optional[int] = None,
-              p16: Optional[Tensor] = None) -> None:
+              p16: Optional[Tensor] = None, p16_lo: int = 0) -> None:
     """l2_n: the l2 term (l2_coef * p added to the gradient) covers the first l2_n elements only (default: all).  p16 (contiguous bf16): receives the
-    bf16 copy of the first p16.numel() updated parameters."""
+    bf16 copy of the updated parameters p[p16_lo : p16_lo + p16.numel()]."""
     n = p.numel()
     if not (g.numel() == n and m.numel() == n and v.numel() == n):
         raise ValueError("adam: size mismatch")
     ex = (C.c_void_p * max(1, len(extra)))(*[L.ptr(t) for t in extra]) if extra else (C.c_void_p * 1)()
     en = (C.c_int64 * max(1, len(extra)))(*extra_n) if extra else (C.c_int64 * 1)()
     if p16 is not None:  # (argument positions of lr and step as in dmm_adam_step: the recorded plans patch them in place)
-        if p16.dtype != torch.bfloat16 or not p16.is_contiguous() or p16.numel() > n:
-            raise ValueError("adam: p16 must be a contiguous bfloat16 tensor of at most p.numel() elements")
+        if p16.dtype != torch.bfloat16 or not p16.is_contiguous() or p16_lo < 0 or p16_lo + p16.numel() > n:
+            raise ValueError("adam: p16 must be a contiguous bfloat16 tensor covering a window of p")
         L.call("dmm_adam_step_x16", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream(),
-               int(n if l2_n is None else l2_n), L.ptr(p16), p16.numel())
+               int(n if l2_n is None else l2_n), L.ptr(p16), p16.numel(), int(p16_lo))
     elif l2_n is None:
         L.call("dmm_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, ex, en, len(extra), l2_coef, lr, beta1, beta2, eps, step, L.stream())
     else:  # (the argument positions of lr and step are those of dmm_adam_step: the recorded plans patch them in place)

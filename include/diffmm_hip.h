@@ -304,11 +304,11 @@ int dmm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const
 /* the same step with the l2 term applied to the first l2_n elements only (one launch for a flat buffer = [embedding rows | other weights]) */
 int dmm_adam_step_prefix(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/, const int64_t* extra_n,
                          int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n);
-/* ... and with a bf16 copy of the first p16_n updated parameters written to p16 (the embedding table's gather copy for dmm_spmm_csr_bf16: made by the
- * step that changes the table instead of a cast pass over it per training step) */
+/* ... and with a bf16 copy of the updated parameters p[p16_lo .. p16_lo + p16_n) written to p16[0 .. p16_n) (the embedding table's gather copy for
+ * dmm_spmm_csr_bf16; a Denoise's W1 | W2 as the next step's bf16 GEMM operands: made by the step that changes them instead of a cast pass per step) */
 int dmm_adam_step_x16(float* p, const float* g, float* m, float* v, int64_t n, const float* const* extra /*host, <=4*/, const int64_t* extra_n,
                       int n_extra, float l2_coef, float lr, float beta1, float beta2, float eps, int step, void* stream, int64_t l2_n, void* p16,
-                      int64_t p16_n);
+                      int64_t p16_n, int64_t p16_lo);
 
 /* ---------------------------------------------------------------------------------------------------
  * Diffusion path.
