@@ -1,11 +1,17 @@
 """Configuration surface of the reference (Conf.py:9-77): four sections as dataclasses + load_config(path).
 
 Field names and defaults are the reference's; unknown TOML keys raise TypeError exactly like the reference's
-dataclass constructors do.  Parsing uses the stdlib-compatible `tomli` (the reference imports `toml`).
+dataclass constructors do (strict, the default).  load_config(path, strict=False) is the tolerant loader of SURVEY 8f.4:
+keys the dataclasses do not know -- the reference's own conf/baby.toml and conf/test.toml still carry the key names of an
+older code base (trans, keepRate, e_loss, sampling_steps, rebuild_k, norm, sampling_noise) and do not load with its
+Conf.py -- are dropped with ONE logged line naming them; nothing is renamed or guessed (a dropped `sampling_steps` leaves
+`sampling_step` at its default, which is what the reference's code would run if its loader got that far).
+Parsing uses the stdlib-compatible `tomli` (the reference imports `toml`).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+import logging
+from dataclasses import dataclass, field, fields
 
 try:  # Python >= 3.11
     import tomllib as _toml
@@ -72,8 +78,20 @@ class Config:
     train: TrainConfig = field(default_factory=TrainConfig)
 
 
-def load_config(path: str) -> Config:
+def load_config(path: str, strict: bool = True) -> Config:
     with open(path, "rb") as fh:
         raw = _toml.load(fh)
-    return Config(base=BaseConfig(**raw.get("base", {})), data=DataConfig(**raw.get("data", {})),
-                  hyper=HyperConfig(**raw.get("hyper", {})), train=TrainConfig(**raw.get("train", {})))
+    sections = {"base": BaseConfig, "data": DataConfig, "hyper": HyperConfig, "train": TrainConfig}
+    kept, dropped = {}, []
+    for name, cls in sections.items():
+        sec = dict(raw.get(name, {}))
+        if not strict:
+            known = {f.name for f in fields(cls)}
+            dropped += [f"{name}.{k}" for k in sec if k not in known]
+            sec = {k: v for k, v in sec.items() if k in known}
+        kept[name] = cls(**sec)  # strict: an unknown key is a TypeError here, as in the reference (Conf.py:69-77)
+    if not strict:
+        dropped += [f"[{k}]" for k in raw if k not in sections]
+        if dropped:
+            logging.getLogger("diffmm_amd.Conf").warning("%s: ignored keys unknown to Conf.py: %s", path, ", ".join(dropped))
+    return Config(**kept)

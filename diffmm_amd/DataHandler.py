@@ -24,6 +24,22 @@ from . import graph, synth
 from .Conf import Config
 
 
+def _config_device(config) -> torch.device:
+    """The device the reference's classes derive from the config (DataHandler.py:16,216)."""
+    return torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
+
+
+def _is_sparse(x) -> bool:
+    return hasattr(x, "tocoo") and hasattr(x, "shape")
+
+
+def _coo_pairs(mat) -> Tuple[np.ndarray, np.ndarray]:
+    """(row, col) of the stored non-zero entries of a scipy sparse matrix, in COO order (what the reference iterates: DataHandler.py:150-157,190-199)."""
+    m = mat.tocoo()
+    keep = m.data != 0
+    return np.asarray(m.row[keep], dtype=np.int32), np.asarray(m.col[keep], dtype=np.int32)
+
+
 class BatchLoader:
     """Minimal stand-in for torch DataLoader(shuffle=..., num_workers=0): index batches drawn on the device."""
 
@@ -69,8 +85,19 @@ class BatchLoader:
 class TrainData:
     """(user, positive item, sampled negative item) triples -- one per train interaction."""
 
-    def __init__(self, rows: np.ndarray, cols: np.ndarray, config: Config, device="cpu"):
-        self.config, self.device = config, torch.device(device)
+    def __init__(self, rows, cols=None, config: Optional[Config] = None, device=None):
+        """Two positional forms: the reference's `TrainData(coomat, config)` (DataHandler.py:147: a scipy (user x item) COO matrix; the
+        device comes from the config like everywhere in the reference) and `TrainData(rows, cols, config, device)` with index arrays (what
+        LoadData() passes: no scipy object is needed for a synthetic or bundled graph)."""
+        if _is_sparse(rows):
+            coomat, config = rows, (cols if config is None else config)
+            if not isinstance(config, Config):
+                raise TypeError("TrainData(coomat, config): config must be a Conf.Config")
+            rows, cols = _coo_pairs(coomat)
+            device = _config_device(config) if device is None else device
+        elif config is None:
+            raise TypeError("TrainData(rows, cols, config[, device]) or TrainData(coomat, config)")
+        self.config, self.device = config, torch.device("cpu" if device is None else device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(config.base.seed) + 17)
         self.rows, self.cols = np.asarray(rows, dtype=np.int32), np.asarray(cols, dtype=np.int32)
@@ -146,9 +173,23 @@ class TrainData:
 
 
 class TestData:
-    def __init__(self, tst_rows: np.ndarray, tst_cols: np.ndarray, trn_rows: np.ndarray, trn_cols: np.ndarray, users: int, items: int,
-                 device="cpu"):
-        self.device = torch.device(device)
+    def __init__(self, tst_rows, tst_cols, trn_rows=None, trn_cols=None, users: Optional[int] = None, items: Optional[int] = None, device=None):
+        """Two positional forms: the reference's `TestData(testMat, trainMat)` (DataHandler.py:180: scipy (user x item) matrices; the reference's class carries no
+        device -- its index arrays go to the current GPU when there is one, where testEpoch() ranks, unless `device=` says otherwise) and `TestData(tst_rows, tst_cols, trn_rows, trn_cols, U, I, device)`."""
+        if _is_sparse(tst_rows):
+            testMat, trainMat = tst_rows, tst_cols
+            if not _is_sparse(trainMat):
+                raise TypeError("TestData(testMat, trainMat): both must be scipy sparse matrices")
+            if trn_rows is not None and device is None and not isinstance(trn_rows, np.ndarray):
+                device = trn_rows  # TestData(testMat, trainMat, device)
+            users, items = int(testMat.shape[0]), int(testMat.shape[1])
+            tst_rows, tst_cols = _coo_pairs(testMat)
+            trn_rows, trn_cols = _coo_pairs(trainMat)
+            if device is None and torch.cuda.is_available():
+                device = torch.device("cuda", torch.cuda.current_device())
+        elif trn_rows is None or trn_cols is None or users is None or items is None:
+            raise TypeError("TestData(tst_rows, tst_cols, trn_rows, trn_cols, users, items[, device]) or TestData(testMat, trainMat)")
+        self.device = torch.device("cpu" if device is None else device)
         self.users, self.items = users, items
         order = np.argsort(tst_rows, kind="stable")
         r, c = np.asarray(tst_rows)[order], np.asarray(tst_cols)[order]
@@ -210,8 +251,27 @@ def dense_rows(ptr: torch.Tensor, col: torch.Tensor, users: torch.Tensor, items:
 class DiffusionData:
     """User rows of the train interaction matrix (what the Denoise MLP sees)."""
 
-    def __init__(self, trn_rows: np.ndarray, trn_cols: np.ndarray, users: int, items: int, device="cpu"):
-        self.device = torch.device(device)
+    def __init__(self, trn_rows, trn_cols=None, users: Optional[int] = None, items: Optional[int] = None, device=None):
+        """Two positional forms: the reference's `DiffusionData(data, config)` (DataHandler.py:213: `data` the dense (user x item) 0/1 tensor -- a
+        scipy matrix is taken too --, the device from the config) and `DiffusionData(trn_rows, trn_cols, U, I, device)`.  Either way only the
+        CSR of the rows is kept: the dense matrix is consumed, never stored (`.data` rebuilds it on request for code that reads the attribute)."""
+        if isinstance(trn_cols, Config) or (trn_cols is None and (torch.is_tensor(trn_rows) or _is_sparse(trn_rows))):
+            data, config = trn_rows, trn_cols
+            if _is_sparse(data):
+                users, items = int(data.shape[0]), int(data.shape[1])
+                trn_rows, trn_cols = _coo_pairs(data)
+            else:
+                data = torch.as_tensor(data)
+                if data.dim() != 2:
+                    raise ValueError("DiffusionData(data, config): data must be a (user_num, item_num) matrix")
+                users, items = int(data.shape[0]), int(data.shape[1])
+                nz = (data != 0).nonzero()  # row-major order: already sorted by user
+                trn_rows, trn_cols = nz[:, 0].cpu().numpy().astype(np.int32), nz[:, 1].cpu().numpy().astype(np.int32)
+            if device is None:
+                device = _config_device(config) if config is not None else (data.device if torch.is_tensor(data) else "cpu")
+        elif users is None or items is None:
+            raise TypeError("DiffusionData(trn_rows, trn_cols, users, items[, device]) or DiffusionData(data, config)")
+        self.device = torch.device("cpu" if device is None else device)
         self.users, self.items = users, items
         o = np.argsort(trn_rows, kind="stable")
         self.ptr = torch.from_numpy(np.searchsorted(np.asarray(trn_rows)[o], np.arange(users + 1)).astype(np.int64)).to(self.device)
@@ -221,6 +281,11 @@ class DiffusionData:
 
     def __len__(self) -> int:
         return self.users
+
+    @property
+    def data(self) -> torch.Tensor:
+        """The reference's attribute (DataHandler.py:215): the dense (user_num, item_num) matrix, materialised on request only."""
+        return self.rows(torch.arange(self.users, device=self.device))
 
     def rows(self, idx: torch.Tensor) -> torch.Tensor:
         return dense_rows(self.ptr, self.col32 if self.ptr.is_cuda else self.col, idx, self.items)

@@ -115,9 +115,12 @@ class Coach:
         cfg = self.config
         mode = os.environ.get("DMM_DENOISE_SHARD", "auto")
         I, D = int(cfg.data.item_num), int(cfg.base.latdim)
-        fits = len(hidden) == 1 and D in (64, 128, 256) and self.precision == 1 and int(cfg.hyper.sampling_step) == 0 and (self.world - 1) * -(-I // self.world) < I
+        latent = os.environ.get("DMM_CHAIN_MODE", "latent") == "latent"  # (the item-sharded rebuild exists for the latent chain only: engine.rebuild_edges)
+        fits = (len(hidden) == 1 and D in (64, 128, 256) and self.precision == 1 and int(cfg.hyper.sampling_step) == 0 and latent
+                and (self.world - 1) * -(-I // self.world) < I)
         if mode == "items" and not fits:
-            raise ValueError("DMM_DENOISE_SHARD=items needs one hidden width, d in 64 / 128 / 256, bf16 mode, sampling_step = 0 and a non-empty item slice per replica")
+            raise ValueError("DMM_DENOISE_SHARD=items needs one hidden width, d in 64 / 128 / 256, bf16 mode, sampling_step = 0, the latent chain and a "
+                             "non-empty item slice per replica")
         if mode == "items" or (mode == "auto" and fits and 2 * I * H * 4 >= (256 << 20)):
             return ItemShard(self.rank, self.world, I, group=self.group)
         return None
@@ -181,7 +184,9 @@ class Coach:
         if DE.t_gen is not None:
             sd["gen"]["timesteps"] = DE.t_gen.get_state()
         for name, P in self._flat_models():
-            sd[name] = {"data": P.data.clone(), "m": P.m.clone(), "v": P.v.clone(), "step": int(P.step)}
+            sd[name] = {"data": P.data.clone(), "m": P.m.clone(), "v": P.v.clone(), "step": int(P.step), "layout": P.signature()}
+        sd["format"] = {"dmm_version": int(ops.L.lib().dmm_version()), "denoise_shard": "items" if self.item_shard is not None else "rows",
+                        "rank": int(self.rank)}
         torch.save(sd, self._ckpt_path(path))
 
     def load_checkpoint(self, path: str) -> None:
@@ -190,11 +195,13 @@ class Coach:
         sd = torch.load(self._ckpt_path(path), map_location=self.device, weights_only=True)
         if int(sd.get("world", 1)) != self.world:
             raise ValueError(f"checkpoint {path} was written by {sd.get('world', 1)} replica(s), this run has {self.world}")
+        fmt = sd.get("format", {})
+        shard_now = "items" if self.item_shard is not None else "rows"
+        if fmt and (fmt.get("denoise_shard", shard_now) != shard_now or int(fmt.get("rank", self.rank)) != self.rank):
+            raise ValueError(f"checkpoint {path} was written by replica {fmt.get('rank')} with the Denoise split by {fmt.get('denoise_shard')}; "
+                             f"this is replica {self.rank} with the split by {shard_now}")
         for name, P in self._flat_models():
-            t = sd[name]
-            if t["data"].numel() != P.data.numel():
-                raise ValueError(f"checkpoint {path}: {name} has {t['data'].numel()} parameters, this model {P.data.numel()}")
-            P.data.copy_(t["data"]); P.m.copy_(t["m"]); P.v.copy_(t["v"]); P.step = int(t["step"])
+            restore_flat(P, sd[name], f"checkpoint {path}: {name}")
         self.epoch_idx, J.rng_step, DE.rng_step = int(sd["epoch_idx"]), int(sd["rng_step_joint"]), int(sd["rng_step_diffusion"])
         DE._xT_calls = int(sd["xT_calls"])
         if "best" in sd:
@@ -220,7 +227,7 @@ class Coach:
         """One epoch (Main.py:136-388).  `draws` (tests only, single replica) supplies the random draws in the reference's call order."""
         cfg, h, M, dev = self.config, self.handler, self.M, self.device
         J, DE, prec, lay = self.model.engine, self.diff_engine, self.precision, self.layout
-        if draws is not None and lay is not None:
+        if draws is not None and (lay is not None or self.item_shard is not None):
             raise ValueError("recorded draws drive the single-replica path only")
         self._set_lr()
         if draws is None:
@@ -308,22 +315,48 @@ class Coach:
         self.epoch_idx += 1
         return result
 
-    def check_replicas(self) -> None:
-        """User-sharded runs: the replicated parameters (item embeddings, projections, modal_weight, every Denoise) and their Adam state
-        must be bit-identical on all replicas -- they only ever receive all-reduced gradients (sharded.py).  One pass over them per epoch:
-        a 64-bit sum of their bit patterns, MIN and MAX over the replicas must agree.  A mismatch raises on every replica."""
+    def _replicated_parts(self):
         J, DE = self.model.engine, self.diff_engine
         lo = J.nu * J.D
         nr = DE.n_replicated if self.item_shard is not None else None  # item-sharded Denoise: only the small tensors are replicated
-        parts = [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t[:nr] for p in DE.P for t in (p.data, p.m, p.v)]
+        return [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t[:nr] for p in DE.P for t in (p.data, p.m, p.v)]
+
+    def _replica_checksums_differ(self, parts) -> List[int]:
         sums = torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in parts])
         mn, mx = sums.clone(), sums.clone()
         comm.all_reduce(mn, op="MIN", group=self.group)
         comm.all_reduce(mx, op="MAX", group=self.group)
-        if not bool((mn == mx).all()):
-            bad = (mn != mx).nonzero().flatten().tolist()
-            raise RuntimeError(f"user-sharded run: replicated state differs between the replicas (checksum groups {bad}; 0-2 = joint model data/m/v, "
-                               f"then data/m/v per Denoise) at epoch {self.epoch_idx}")
+        return (mn != mx).nonzero().flatten().tolist()  # (the same list on every replica: MIN / MAX are all-reduced)
+
+    def check_replicas(self) -> None:
+        """User-sharded runs: the replicated parameters (item embeddings, projections, modal_weight, every Denoise) and their Adam state
+        must be bit-identical on all replicas -- they only ever receive all-reduced gradients (sharded.py).  One pass over them per epoch:
+        a 64-bit sum of their bit patterns, MIN and MAX over the replicas must agree.  A first mismatch HEALS the run instead of ending it:
+        every replica takes replica 0's copy of the replicated slices and of their Adam state (one broadcast each), the bf16 operand copies
+        derived from them are marked stale, and the event is logged and counted (`replica_heals`); a mismatch at the very next check as well
+        means the replicas diverge systematically -- that raises, on every replica."""
+        parts = self._replicated_parts()
+        bad = self._replica_checksums_differ(parts)
+        if not bad:
+            self._healed_last_check = False
+            return
+        what = (f"replicated state differs between the replicas (checksum groups {bad}; 0-2 = joint model data/m/v, then data/m/v per Denoise) "
+                f"at epoch {self.epoch_idx}")
+        if getattr(self, "_healed_last_check", False):
+            raise RuntimeError(f"user-sharded run: {what} -- again, right after a re-broadcast from replica 0")
+        for t in parts:
+            comm.broadcast(t, src=0, group=self.group)
+        J, DE = self.model.engine, self.diff_engine
+        DE.w16_step = [-1] * DE.M; DE.w16_train_step = [-1] * DE.M  # bf16 copies of the weights are stale on the replicas that were overwritten
+        J._emb16_step = -1
+        self._healed_last_check = True
+        self.replica_heals = getattr(self, "replica_heals", 0) + 1
+        msg = f"user-sharded run: {what}; every replica took replica 0's copy (heal #{self.replica_heals})"
+        _log(msg)
+        if main_log is None and self.rank == 0:
+            print(msg, flush=True)
+        if self._replica_checksums_differ(parts):
+            raise RuntimeError("user-sharded run: replicated state still differs after the re-broadcast from replica 0")
 
     # ---------------------------------------------------------------------------------------------
     def testEpoch(self) -> Dict[str, float]:
@@ -378,6 +411,33 @@ class Coach:
         return rec, ndcg, prec
 
 
+def restore_flat(P, t: dict, what: str) -> None:
+    """Read a checkpointed flat buffer set (data / m / v + the layout it was written in) into P.  The flat layout is an implementation detail
+    that has changed between versions (the Denoise's small tensors moved in front of b2 / W1 / W2): a checkpoint whose ordered (name, shape,
+    offset) list equals this build's is copied as it is; one with the same tensors at other offsets is REMAPPED tensor by tensor; one
+    without a layout record (written before the record existed) or with other names / shapes is refused -- never read positionally."""
+    layout = t.get("layout")
+    if layout is None:
+        raise ValueError(f"{what}: the file carries no layout record (written by a build before the flat parameter layout was versioned); "
+                         "its flat buffers cannot be mapped onto this build's layout safely")
+    layout = [[str(k), [int(x) for x in shp], int(off)] for k, shp, off in layout]
+    mine = P.signature()
+    if layout == mine:
+        if t["data"].numel() != P.data.numel():
+            raise ValueError(f"{what}: {t['data'].numel()} parameters in the file, {P.data.numel()} in this model")
+        P.data.copy_(t["data"]); P.m.copy_(t["m"]); P.v.copy_(t["v"])
+    else:
+        theirs = {k: (shp, off) for k, shp, off in layout}
+        if set(theirs) != set(P.names) or any(tuple(theirs[k][0]) != tuple(P.shapes[k]) for k in P.names):
+            diff = sorted(set(theirs) ^ set(P.names)) or [k for k in P.names if tuple(theirs[k][0]) != tuple(P.shapes[k])]
+            raise ValueError(f"{what}: the file's tensors do not match this model's ({diff[:4]} ...)")
+        for k in P.names:
+            n, off = int(np.prod(P.shapes[k])), theirs[k][1]
+            for dst, src in ((P.data, t["data"]), (P.m, t["m"]), (P.v, t["v"])):
+                P.view(k, dst).copy_(src[off:off + n].view(P.shapes[k]))
+    P.step = int(t["step"])
+
+
 def seed_it(seed: int) -> None:
     random.seed(seed)
     os.environ["PYTHONHASHSEED"] = str(seed)
@@ -394,9 +454,11 @@ def main(argv=None) -> None:
     ap.add_argument("--precision", type=int, default=1, choices=(1, 3), help="1: bf16 MFMA GEMMs, 3: hi/lo split (~fp32)")
     ap.add_argument("--save", default=None, help="write a checkpoint to this path after every epoch")
     ap.add_argument("--resume", default=None, help="continue from a checkpoint written by --save")
+    ap.add_argument("--tolerant", action="store_true", help="drop TOML keys Conf.py does not know (one logged line) instead of failing like the "
+                    "reference does: its own conf/baby.toml and conf/test.toml need this")
     args = ap.parse_args(argv)
     try:
-        config = load_config(args.config)
+        config = load_config(args.config, strict=not args.tolerant)
         print(f"Load configuration ({config.data.name}) file successfully")
     except Exception as e:  # same behaviour as the reference: report and exit 1
         print(f"Error loading configuration file: {e}")

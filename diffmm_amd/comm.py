@@ -28,3 +28,11 @@ def all_gather_into(out: torch.Tensor, t: torch.Tensor, rank: int, group=None) -
         return
     import torch.distributed as dist
     dist.all_gather_into_tensor(out, t, group=group)
+
+
+def broadcast(t: torch.Tensor, src: int = 0, group=None) -> None:
+    """t <- replica `src`'s t (LOCAL: nothing to do)."""
+    if group is LOCAL:
+        return
+    import torch.distributed as dist
+    dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)

@@ -124,6 +124,10 @@ class FlatParams:
     def state_dict(self) -> Dict[str, Tensor]:
         return {k: self.view(k).clone() for k in self.names}
 
+    def signature(self) -> List[List]:
+        """The ordered (name, shape, offset) list: what a checkpoint of the raw flat buffers must carry to be read back into another layout."""
+        return [[k, list(self.shapes[k]), int(self.offsets[k])] for k in self.names]
+
 
 def modality_names(M: int) -> Tuple[str, ...]:
     return MODAL[:M] if M == 3 else ("image", "text")
@@ -1429,6 +1433,8 @@ class DiffusionEngine:
     def generate_view_bf16(self, m: int, x0: Tensor) -> Tensor:
         """Reverse chain on the dedicated bf16 NT GEMM: bf16 weights / activations as MFMA operands, fp32 accumulation, the
         running x_t kept in fp32 for the posterior-mean residual and the final top-k."""
+        if self.ishard is not None:
+            raise ValueError("DiffusionEngine: the stepwise reverse chain is not item-sharded (a replica holds W1 / W2 over its item slice only)")
         B, I, P, Kp = x0.shape[0], self.I, self.P[m], self.Kp
         self._refresh_bf16_weights(m)
         self.xa[:B, :I].copy_(x0)
@@ -1452,6 +1458,8 @@ class DiffusionEngine:
         bf16 copy the next layer-1 GEMM reads.  One HIP stream per modality by default (hp chain_streams / DMM_CHAIN_STREAMS=0: one
         batched launch per layer and step instead).  (Carrying only the bf16 copy between steps was measured: no faster, 0.6 % of the
         rebuilt edges change -- not kept.)"""
+        if self.ishard is not None:
+            raise ValueError("DiffusionEngine: the stepwise reverse chain is not item-sharded (a replica holds W1 / W2 over its item slice only)")
         B, I, M = x0.shape[0], self.I, self.M
         for m in range(M):
             self._refresh_bf16_weights(m)
@@ -1548,6 +1556,8 @@ class DiffusionEngine:
         gather of W1^T rows (dmm_csr_gather_sum_bf16: x_0 is 0/1 with ~6 non-zeros per row), layer 2 as the usual GEMM with the epilogue
         c1 * pred, and adds the residual c2 * x_0 at the row's non-zeros (dmm_csr_add_rows); steps T-2 .. 0 are the dense chain.  One HIP
         stream per modality, launches recorded once per batch size (the user ids live in a static buffer)."""
+        if self.ishard is not None:
+            raise ValueError("DiffusionEngine: the stepwise reverse chain is not item-sharded (a replica holds W1 / W2 over its item slice only)")
         B, I, M, T = rows.shape[0], self.I, self.M, self.T
         if self._w1T_chain is None:
             self._w1T_chain = [torch.zeros(self.Kp, self.H, dtype=torch.bfloat16, device=self.dev) for _ in range(M)]
@@ -1663,6 +1673,10 @@ class DiffusionEngine:
         csr = (ptr int64 over all users, col int32, id offset): with it (bf16 chain, sampling_step 0) x_0 is never densified.
         sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time."""
         out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
+        if self.ishard is not None and not (precision == 1 and self._latent_mode() and csr is not None and sampling_step == 0):
+            # the stepwise / dense-start chains would run on this replica's W1 / W2 SLICE while the top-k ranks all I_chain columns: wrong graphs, silently
+            raise ValueError("DiffusionEngine: an item-sharded Denoise rebuilds through the latent chain from CSR rows only (bf16 mode, chain_mode = latent, "
+                             "sampling_step = 0); run with DMM_DENOISE_SHARD=rows for the stepwise chain or a noised chain start")
         if precision == 1:  # re-chunk: every user exactly once, in chunks as large as the chain buffers allow
             all_users = torch.cat([b.reshape(-1) for b in user_batches])
             n = int(all_users.numel())

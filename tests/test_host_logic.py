@@ -223,3 +223,102 @@ def test_local_comm_keeps_the_own_part():
     out = torch.zeros(6, 2)
     comm.all_gather_into(out, torch.ones(2, 2), rank=1, group=comm.LOCAL)
     assert torch.equal(out, torch.tensor([[0, 0], [0, 0], [1, 1], [1, 1], [0, 0], [0, 0]], dtype=torch.float32))
+
+
+# ---- the reference's positional constructors of the three dataset classes (DataHandler.py:145-228) ------------------------------
+def _mid_mats():
+    import scipy.sparse as sp
+    z = np.load(os.path.join(REPO, "tests", "golden", "epoch_mid.npz"))
+    U, I = int(z["users"]), int(z["items"])
+    trn = sp.coo_matrix((np.ones(len(z["trn_rows"]), np.float32), (z["trn_rows"], z["trn_cols"])), shape=(U, I))
+    tst = sp.coo_matrix((np.ones(len(z["tst_rows"]), np.float32), (z["tst_rows"], z["tst_cols"])), shape=(U, I))
+    return z, U, I, trn, tst
+
+
+def test_dataset_classes_take_the_reference_positional_forms():
+    """TrainData(coomat, config), TestData(testMat, trainMat), DiffusionData(data, config) -- the reference's signatures -- build the same
+    objects as the array forms LoadData() uses."""
+    import torch
+    from diffmm_amd.Conf import Config
+    from diffmm_amd.DataHandler import DiffusionData, TestData, TrainData
+    z, U, I, trn, tst = _mid_mats()
+    cfg = Config()
+    cfg.data.user_num, cfg.data.item_num = U, I
+    a, b = TrainData(trn, cfg), TrainData(z["trn_rows"], z["trn_cols"], cfg, "cpu")
+    assert np.array_equal(a.rows, trn.row) and np.array_equal(a.cols, trn.col), "COO order is kept (DataHandler.py:150-151)"
+    assert np.array_equal(a.rows, b.rows) and np.array_equal(a.cols, b.cols) and len(a) == len(z["trn_rows"])
+    assert [list(x) for x in a.user_pos_items] == [list(x) for x in b.user_pos_items]
+    a.negSampling()
+    keys = set((z["trn_rows"].astype(np.int64) * I + z["trn_cols"]).tolist())
+    assert not (set((a.rows.astype(np.int64) * I + a.negs).tolist()) & keys), "no sampled negative is a train positive"
+    u, p, n = a[5]
+    assert (u, p) == (trn.row[5], trn.col[5]) and n == a.negs[5]
+    ta, tb = TestData(tst, trn), TestData(z["tst_rows"], z["tst_cols"], z["trn_rows"], z["trn_cols"], U, I)
+    assert np.array_equal(ta.test_users, tb.test_users) and len(ta) == len(np.unique(z["tst_rows"]))
+    assert ta.test_user_its == tb.test_user_its
+    usr, mask = ta[3]
+    want = np.asarray(trn.tocsr()[usr].todense()).reshape(-1)
+    assert np.array_equal(mask, want), "TestData[i] = (user, the user's train row) (DataHandler.py:206-208)"
+    dense = torch.tensor(trn.toarray(), dtype=torch.float)
+    da, db, dc = DiffusionData(dense, cfg), DiffusionData(z["trn_rows"], z["trn_cols"], U, I), DiffusionData(trn, cfg)
+    for d in (da, dc):
+        assert len(d) == U and torch.equal(d.ptr.cpu(), db.ptr) and torch.equal(d.col.cpu(), db.col)
+    if not torch.cuda.is_available():
+        assert torch.equal(da.data, dense)
+        row, idx = da[7]
+        assert idx == 7 and torch.equal(row, dense[7])
+    with pytest.raises(TypeError):
+        TrainData(z["trn_rows"], z["trn_cols"])
+    with pytest.raises(TypeError):
+        TestData(tst, z["trn_rows"])
+    with pytest.raises(TypeError):
+        DiffusionData(z["trn_rows"], z["trn_cols"])
+
+
+STALE_TOML = """
+[base]
+latdim = 32
+trans = 1          # key of an older code base: Conf.py has no such field
+cl_method = 1
+[data]
+name = "baby"
+[hyper]
+steps = 7
+keepRate = 1
+e_loss = 0.01
+sampling_steps = 5
+rebuild_k = 1
+[train]
+batch = 256
+norm = false
+sampling_noise = false
+[legacy]
+x = 1
+"""
+
+
+def test_tolerant_config_loading(tmp_path, caplog):
+    """strict loading (the default) raises TypeError on unknown keys exactly like the reference's Conf.py:69-77 -- which is why
+    the reference's own conf/baby.toml and conf/test.toml do not load --; strict=False drops them with ONE logged line."""
+    import logging
+    from diffmm_amd.Conf import load_config
+    p = tmp_path / "stale.toml"
+    p.write_text(STALE_TOML)
+    with pytest.raises(TypeError, match="trans"):
+        load_config(str(p))
+    with caplog.at_level(logging.WARNING, logger="diffmm_amd.Conf"):
+        cfg = load_config(str(p), strict=False)
+    lines = [r.getMessage() for r in caplog.records if r.name == "diffmm_amd.Conf"]
+    assert len(lines) == 1
+    for k in ("base.trans", "hyper.keepRate", "hyper.e_loss", "hyper.sampling_steps", "hyper.rebuild_k", "train.norm", "train.sampling_noise", "[legacy]"):
+        assert k in lines[0]
+    assert (cfg.base.latdim, cfg.base.cl_method, cfg.data.name, cfg.hyper.steps, cfg.train.batch) == (32, 1, "baby", 7, 256)
+    assert cfg.hyper.sampling_step == 0 and cfg.hyper.sim_weight == 0.1, "nothing is renamed or guessed: dropped keys leave the defaults"
+    ref_conf = "/root/reference/conf"  # build container only: the reference's own files (never read on the GPU box -- this is a CPU test)
+    if os.path.isdir(ref_conf):
+        for f in sorted(os.listdir(ref_conf)):
+            cfg = load_config(os.path.join(ref_conf, f), strict=False)
+            assert cfg.data.name and cfg.hyper.steps >= 1
+        for f in ("baby.toml", "test.toml"):
+            with pytest.raises(TypeError):
+                load_config(os.path.join(ref_conf, f))

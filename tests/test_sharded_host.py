@@ -137,3 +137,88 @@ def test_item_shard_slices_partition_the_items():
         assert all(0 < s.items_local <= s.S for s in sl) and all(s.i0 == s.rank * s.S for s in sl)
     with pytest.raises(ValueError):
         ItemShard(0, 8, 9)  # ceil(9 / 8) = 2 items per slice leave the last replicas without items
+
+
+# ---- Coach.check_replicas: a first mismatch is healed from replica 0, a repeat raises -------------------------------------------------------
+def _stub_coach(rank, world):
+    """A Coach with just the state check_replicas reads (flat parameter sets on the CPU)."""
+    from types import SimpleNamespace
+    from diffmm_amd.Main import Coach
+    from diffmm_amd.engine import FlatParams
+    torch.manual_seed(5)  # the same "replicated" values on every rank
+    JP = FlatParams([("emb", (6 + 4, 4)), ("image_layer.weight", (4, 3)), ("modal_weight", (3,))], "cpu")
+    DP = [FlatParams([("emb_layer.weight", (3, 3)), ("out_layers.0.bias", (5,)), ("in_layers.0.weight", (8, 8))], "cpu") for _ in range(2)]
+    for P in [JP] + DP:
+        P.data.normal_(); P.m.normal_(); P.v.uniform_()
+    JP.data[:6 * 4] += rank  # the own user rows legitimately differ
+    c = Coach.__new__(Coach)
+    c.rank, c.world, c.group, c.item_shard, c.epoch_idx = rank, world, None, None, 3
+    c.model = SimpleNamespace(engine=SimpleNamespace(nu=6, D=4, P=JP, _emb16_step=7))
+    c.diff_engine = SimpleNamespace(P=DP, M=2, n_replicated=0, w16_step=[1, 1], w16_train_step=[1, 1])
+    return c, JP, DP
+
+
+def _heal_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c, JP, DP = _stub_coach(rank, world)
+        c.check_replicas()  # identical: nothing happens
+        res = {"heals0": getattr(c, "replica_heals", 0)}
+        want = (JP.data[24:].clone(), DP[1].v.clone())
+        if rank == 1:  # one flipped low bit in an item row and one in a Denoise's Adam state
+            JP.data[24 + 5] = torch.nextafter(JP.data[24 + 5], torch.tensor(9.0))
+            DP[1].v[3] = torch.nextafter(DP[1].v[3], torch.tensor(9.0))
+        c.check_replicas()
+        res["heals1"] = c.replica_heals
+        res["restored"] = bool(torch.equal(JP.data[24:], want[0]) and torch.equal(DP[1].v, want[1]))
+        res["own_rows_kept"] = bool((JP.data[:24] - rank).abs().max() < 10)  # untouched by the broadcast (not a replicated slice)
+        res["stale_marks"] = (c.diff_engine.w16_step, c.model.engine._emb16_step)
+        if rank == 1:
+            DP[0].data[1] += 1.0
+        try:
+            c.check_replicas()
+            res["second"] = "no error"
+        except RuntimeError as e:
+            res["second"] = str(e)
+        out[rank] = res
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_replica_mismatch_is_healed_once_then_raises():
+    world, port = 2, 34500 + (os.getpid() % 2000)
+    out = mp.Manager().dict()
+    mp.spawn(_heal_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        res = out[r]
+        assert res["heals0"] == 0 and res["heals1"] == 1 and res["restored"] and res["own_rows_kept"]
+        assert res["stale_marks"] == ([-1, -1], -1)
+        assert "again, right after a re-broadcast" in res["second"], "a mismatch at the very next check raises on every replica"
+
+
+def test_checkpoint_layout_is_versioned_and_remapped_by_name():
+    """the flat parameter layout changed between builds; a checkpoint carries its ordered (name, shape, offset) list and is
+    remapped tensor by tensor when the order differs, refused when it has no layout record or other tensors -- never read positionally."""
+    from diffmm_amd.Main import restore_flat
+    from diffmm_amd.engine import FlatParams
+    new = [("emb_layer.weight", (3, 3)), ("gate_layer.weight", (4, 4)), ("out_layers.0.bias", (7,)), ("in_layers.0.weight", (5, 12)), ("out_layers.0.weight", (7, 5))]
+    old = [new[0], new[2], new[1], new[4], new[3]]  # the previous order: b2 before the gate layer, W2 before W1
+    src = FlatParams(old, "cpu")
+    src.data.normal_(); src.m.normal_(); src.v.uniform_(); src.step = 11
+    rec = {"data": src.data.clone(), "m": src.m.clone(), "v": src.v.clone(), "step": 11, "layout": src.signature()}
+    dst = FlatParams(new, "cpu")
+    assert dst.size == src.size, "same element count: a numel check alone would have let the scrambled load through"
+    restore_flat(dst, rec, "test")
+    for k in src.names:
+        for a, b in ((src.data, dst.data), (src.m, dst.m), (src.v, dst.v)):
+            assert torch.equal(src.view(k, a), dst.view(k, b)), k
+    assert dst.step == 11
+    same = FlatParams(old, "cpu")
+    restore_flat(same, rec, "test")
+    assert torch.equal(same.data, src.data)
+    with pytest.raises(ValueError, match="no layout record"):
+        restore_flat(dst, {k: v for k, v in rec.items() if k != "layout"}, "test")
+    other = FlatParams(new[:-1] + [("out_layers.0.weight", (5, 7))], "cpu")
+    with pytest.raises(ValueError, match="do not match"):
+        restore_flat(other, rec, "test")

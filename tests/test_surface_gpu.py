@@ -193,3 +193,33 @@ def test_neg_sampling_rejects_train_positives_and_is_uniform(dev):
     chi2 = float(((counts - expect) ** 2 / expect).sum())
     assert chi2 < g.items + 6 * np.sqrt(2 * g.items), f"chi-square {chi2:.0f} for {g.items} bins"
     assert abs(counts / expect - 1.0).max() < 0.5
+
+
+# ---- DataHandler.py:145-228: the three dataset classes built the way the reference's LoadData() builds them ---------------------------------
+def test_dataset_classes_in_the_reference_positional_forms_drive_an_epoch(dev):
+    """TrainData(coomat, config), TestData(testMat, trainMat), DiffusionData(dense tensor, config) -- DataHandler.py:114-128's calls, verbatim --
+    replace the handler's own objects; one epoch + evaluation then reproduces the reference's epoch (tests/golden/epoch_mid.npz, recorded draws)."""
+    import scipy.sparse as sp
+    from diffmm_amd.DataHandler import BatchLoader, DiffusionData, TestData, TrainData
+    from test_epoch_gpu import _Draws, _coach
+    z = load("epoch_mid.npz")
+    coach, h, M = _coach(z)
+    cfg, U, I = coach.config, int(z["users"]), int(z["items"])
+    trainMat = sp.coo_matrix((np.ones(len(z["trn_rows"]), np.float32), (z["trn_rows"], z["trn_cols"])), shape=(U, I))
+    testMat = sp.coo_matrix((np.ones(len(z["tst_rows"]), np.float32), (z["tst_rows"], z["tst_cols"])), shape=(U, I))
+    h.trainData = TrainData(trainMat, cfg)
+    h.testData = TestData(testMat, trainMat)
+    h.diffusionData = DiffusionData(torch.tensor(trainMat.toarray(), dtype=torch.float, device=dev), cfg)
+    assert h.trainData.device.type == "cuda" and h.diffusionData.ptr.is_cuda and h.testData._users_d.is_cuda
+    h.trainLoader = BatchLoader(h.trainData, int(cfg.train.batch), True, dev)
+    h.diffusionLoader = BatchLoader(h.diffusionData, int(cfg.train.batch), True, dev)
+    h.trainLoader.fixed_perm = T(z["train_perm"].astype(np.int64))
+    h.diffusionLoader.fixed_perm = T(z["diff_perm"].astype(np.int64))
+    h.trainData.set_negs(z["ep0/negs"])
+    res = coach.trainEpoch(draws=_Draws(z))
+    for k, v in res.items():
+        close(v, z[f"ep0/train/{k}"], rtol=5e-3, atol=1e-5, what=f"train {k}")
+    for k, v in coach.testEpoch().items():
+        close(v, z[f"ep0/test/{k}"], rtol=0.02, atol=2e-3, what=f"test {k}")
+    d = h.diffusionData.data
+    assert d.shape == (U, I) and float(d.sum()) == len(z["trn_rows"])
