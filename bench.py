@@ -9,6 +9,15 @@ section 8(d):  value = (n_diff + n_joint) * K / wall_seconds, B-sized minibatche
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts itself: the parent -- before it makes any GPU call -- launches
+the line above as a child (one rank per GPU, backend nccl = RCCL), relays rank 0's single JSON line and exits with the children's status.
+
+--workload scale --users U --items I --latdim d --T T [--batch B --scale-mode strong|weak]: the synthetic graph of SURVEY 8(d) at any size (TikTok degree
+law, 3 modalities), a step = a BOUNDED SAMPLE of an epoch (--diff-iters diffusion iterations, the reverse chain + top-k over --rebuild-users users
+per replica -- the other users keep their observed interactions --, --joint-iters joint iterations; all three named in config.workload).  strong: U
+users in total at every N; weak: U users PER GPU (BASELINE config 5 is `--scale-mode weak --users 1250000 --items 1000000 --latdim 256 --T 1000
+--batch 8192` at N = 8), `value` then counts shard-iterations (N per iteration of the N-shard job: the per-GPU work of an iteration is fixed).
+
 N > 1: one process per GPU over RCCL, users sharded over the ranks (diffmm_amd/sharded.py): every rank owns a
 contiguous user range (its embedding rows, Adam state, adjacency rows), items are replicated; every SpMM is a local launch
 + one all-reduce of the item partials, every minibatch is the reference's minibatch with its rows split by owner, the
@@ -34,7 +43,34 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 PMC_CHAIN_JSON = "r3_pmc_chain_gemm.json"  # committed PMC summary of tools/roofline_target.py (tools/final_profile.sh)
 
 
+def scale_graph(users: int, items: int, chunk: int = 1_250_000):
+    """The synthetic graph of the scale workload, generated one user range at a time (the generator's working set is ~2 KB per user) and identical on
+    every rank (per-range draws are keyed on the range's first user id)."""
+    from diffmm_amd import synth
+    parts = [synth.make_graph(users, items, feats=(128, 768, 128) if lo == 0 else (), seed=1818, heavy_p=0.011, heavy=(300, 520), user_lo=lo,
+                              user_hi=min(users, lo + chunk)) for lo in range(0, users, chunk)]
+    cat = lambda k: np.concatenate([getattr(p, k) for p in parts])
+    return synth.SynthGraph(users, items, cat("trn_rows"), cat("trn_cols"), cat("tst_rows"), cat("tst_cols"), parts[0].feats)
+
+
+class _Head:
+    """The first n minibatches of a loader's epoch (bounded samples of the scale workload)."""
+
+    def __init__(self, loader, n):
+        self.loader, self.n = loader, n
+
+    def __iter__(self):
+        for i, b in enumerate(self.loader):
+            if i >= self.n:
+                return
+            yield b
+
+    def __len__(self):
+        return min(len(self.loader), self.n)
+
+
 def make_coach(args, rank: int, world: int):
+    from diffmm_amd import comm
     from diffmm_amd.Conf import load_config
     from diffmm_amd.DataHandler import DataHandler
     from diffmm_amd.Main import Coach, seed_it
@@ -44,9 +80,19 @@ def make_coach(args, rank: int, world: int):
     cfg.data.name = args.workload
     seed_it(cfg.base.seed)
     h = DataHandler(cfg)
-    h.LoadData()
+    if args.workload == "scale":
+        total = args.users * world if args.scale_mode == "weak" else args.users
+        h.LoadData(graph_data=scale_graph(total, args.items), sharded=comm.active(world))
+    else:
+        h.LoadData()
     coach = Coach(h, cfg, precision=args.precision, rank=rank, world=world)
     coach.prepareModel()
+    if args.workload == "scale":  # a bounded sample of the epoch
+        coach.rebuild_limit = args.rebuild_users
+        h.trainLoader = _Head(h.trainLoader, args.joint_iters)
+        full_idx = h.diffusionLoader.index_batches
+        h.diffusionLoader.index_batches = lambda: full_idx()[: args.diff_iters]
+        h.diffusionLoader.bounded = args.diff_iters
     return coach, h, cfg
 
 
@@ -260,31 +306,81 @@ def cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint):
                       f"{', '.join(f'{k}: {v * 1e3:.0f} ms' for k, v in sweep.items())} on a 2048 x 6720 x 1024 GEMM + tanh)"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N`, N > 1, outside torchrun: start the N ranks as children (this process has made no GPU call), relay rank 0's JSON
+    line, return the children's status."""
+    import subprocess
+    if args.backend == "nccl":
+        n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} GPUs, this node shows {n_dev} (--backend gloo lets ranks share a GPU: tests only)", file=sys.stderr)
+            return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=REPO, env=env)
+    line = None
+    for out in p.stdout:  # stderr passes through; stdout is forwarded except that exactly one JSON line is printed, last
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            sys.stdout.write(out); sys.stdout.flush()
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line); sys.stdout.flush()
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="tiktok"); ap.add_argument("--T", type=int, default=40); ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--workload", default="tiktok", help="a named synthetic shape (tiktok, baby, sports, mid, toy) or `scale` (--users / --items / ...)")
+    ap.add_argument("--T", type=int, default=40); ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--latdim", type=int, default=64); ap.add_argument("--precision", type=int, default=1, choices=(1, 3))
+    ap.add_argument("--users", type=int, default=1_000_000, help="--workload scale: users in total (strong) or per GPU (weak)")
+    ap.add_argument("--items", type=int, default=100_000); ap.add_argument("--scale-mode", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--diff-iters", type=int, default=2); ap.add_argument("--joint-iters", type=int, default=8)
+    ap.add_argument("--rebuild-users", type=int, default=4096, help="--workload scale: users per replica whose reverse chain + top-k run in a step")
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-shard-roofline", action="store_true", help="skip the 1M x 500k SpMM measurement (roofline_spmm_shard)")
     ap.add_argument("--no-fp32-like", action="store_true", help="skip the extra precision-3 (bf16 hi/lo split, ~fp32) epochs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
-    if world > 1:
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, or under torch.distributed.run with "
+                         f"--nproc-per-node equal to --gpus)")
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    from diffmm_amd import comm
+    if comm.active(world):
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
-        dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
+        if "MASTER_ADDR" not in os.environ:  # a single forced-collectives replica started by hand
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        kw = dict(device_id=torch.device("cuda", local)) if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, **kw)
     coach, h, cfg = make_coach(args, rank, world)
-    n_diff, n_joint = len(h.diffusionLoader), len(h.trainLoader)
+    n_diff, n_joint = min(len(h.diffusionLoader), getattr(h.diffusionLoader, "bounded", 1 << 60)), len(h.trainLoader)
     iters_per_epoch = n_diff + n_joint
+    scale, weak = args.workload == "scale", args.workload == "scale" and args.scale_mode == "weak"
+    import torch.distributed as dist  # (only used when a process group exists)
+    grouped = comm.active(world)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -298,41 +394,62 @@ def main():
         phases += np.array(getattr(coach, "phase_seconds", [0, 0, 0]))
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    replicas_identical = None
+    if grouped:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    replicas_identical = None
-    if world > 1:  # the replicated parameters (items, projections, Denoise weights) must stay bit-identical: they only receive all-reduced gradients
-        import torch.distributed as dist
-        J = coach.model.engine
-        flat = torch.cat([J.P.data[J.nu * J.D:]] + [p.data for p in coach.diff_engine.P])
+        # the replicated parameters (items, projections, Denoise weights or their replicated small tensors) must be bit-identical: they only ever
+        # receive all-reduced gradients.  (Coach.check_replicas made the same comparison after every epoch and would have healed / raised.)
+        J, DE = coach.model.engine, coach.diff_engine
+        nr = DE.n_replicated if coach.item_shard is not None else None
+        flat = torch.cat([J.P.data[J.nu * J.D:]] + [p.data[:nr] for p in DE.P])
         lo, hi = flat.clone(), flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        replicas_identical = bool(torch.equal(lo, hi))
-    if rank != 0:
-        return
-    out = {"metric": "BPR+diffusion train iters/sec on TikTok d=64 T=40, at 1/2/4/8 GPUs", "value": iters_per_epoch * args.steps / dt, "unit": "iters/s",
+        replicas_identical = bool(torch.equal(lo, hi)) and getattr(coach, "replica_heals", 0) == 0
+    if rank == 0:
+        report(args, coach, h, cfg, world, dt, phases, n_diff, n_joint, replicas_identical)
+    if grouped:  # the other ranks wait here while rank 0 takes its roofline / baseline measurements (none of them communicates)
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def report(args, coach, h, cfg, world, dt, phases, n_diff, n_joint, replicas_identical):
+    from diffmm_amd import comm
+    iters_per_epoch = n_diff + n_joint
+    scale, weak = args.workload == "scale", args.workload == "scale" and args.scale_mode == "weak"
+    units = world if weak else 1  # weak form: an iteration of the N-shard job counts as N shard-iterations (fixed per-GPU work per iteration)
+    step_desc = (f"step = a bounded sample of an epoch = {n_diff} diffusion iters + reverse chain / top-k of {args.rebuild_users} users per replica + {n_joint} joint iters"
+                 + (f"; weak scaling: {args.users} users per GPU, value counts shard-iterations (x{world})" if weak else "; strong scaling: the graph is fixed")
+                 if scale else f"step = 1 epoch = {n_diff} diffusion iters + rebuild + {n_joint} joint iters")
+    out = {"metric": "BPR+diffusion train iters/sec on TikTok d=64 T=40, at 1/2/4/8 GPUs", "value": units * iters_per_epoch * args.steps / dt, "unit": "iters/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
+           "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
            "data": "synthetic",
            "config": {"workload": f"synthetic {args.workload}-shape graph: U={h.graph.users} I={h.graph.items} E={h.graph.nnz}, M={len(h.graph.feats)} modalities, "
-                                  f"d={args.latdim}, T={args.T}, batch={args.batch}; step = 1 epoch = {n_diff} diffusion iters + rebuild + {n_joint} joint iters",
-                      "parallelism": f"user-shard{world}" if world > 1 else "single", "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
+                                  f"d={args.latdim}, T={args.T}, batch={args.batch}; {step_desc}",
+                      "parallelism": f"user-shard{world}" if comm.active(world) else "single", "backend": args.backend if comm.active(world) else None,
+                      "denoise_shard": ("items" if coach.item_shard is not None else "rows") if comm.active(world) else None, "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
                       "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3},
                       # the two per-phase rates next to the blended headline (`value`); host-side phase boundaries of rank 0
                       "phase_iters_per_s": {"diffusion": n_diff * args.steps / max(phases[0], 1e-9), "joint": n_joint * args.steps / max(phases[2], 1e-9)}}}
     if replicas_identical is not None:
         out["replicated_params_identical"] = replicas_identical
-    if not args.no_roofline:
-        g, s, g2 = roofline(coach, args)
-        out["roofline"], out["roofline_spmm"] = g, s
-        if g2 is not None:
-            out["roofline_item_gemm"] = g2
+    if getattr(coach, "replica_heals", 0):
+        out["replica_heals"] = coach.replica_heals
+    if not args.no_roofline and coach.item_shard is None and not scale:  # (the roofline replays need the whole Denoise on this rank)
+        try:
+            g, s, g2 = roofline(coach, args)
+            out["roofline"], out["roofline_spmm"] = g, s
+            if g2 is not None:
+                out["roofline_item_gemm"] = g2
+        except Exception as e:  # a replica's engines hold local blocks: never lose the result line over the side measurements
+            if not comm.active(world):
+                raise
+            out["roofline_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_shard_roofline and args.workload == "tiktok":
             out["roofline_spmm_shard"] = roofline_spmm_shard()
-    if world == 1 and args.precision == 1 and not args.no_fp32_like:  # the same epochs in split-bf16 (~fp32) arithmetic, next to the bf16 headline
+    if world == 1 and not comm.active(world) and args.precision == 1 and not args.no_fp32_like and not scale:  # the same epochs in split-bf16 (~fp32) arithmetic, next to the bf16 headline
         coach.precision = 3
         coach.model.precision = 3
         coach.trainEpoch(); torch.cuda.synchronize()
@@ -343,7 +460,7 @@ def main():
         out["config"]["fp32_like_iters_per_s"] = iters_per_epoch * 2 / (time.perf_counter() - t1)
         coach.precision = 1
         coach.model.precision = 1
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not scale:
         out["cpu_baseline"] = cpu_baseline(args, h, cfg, iters_per_epoch, n_diff, n_joint)
     print(json.dumps(out))
 

@@ -51,10 +51,13 @@ class Coach:
         self.layout = layout
         if emulate_replica:
             self.group = comm.LOCAL
-        if self.world > 1 and layout is None:
+        if comm.active(self.world) and layout is None:
             from .sharded import ShardLayout
             self.layout = ShardLayout.make(handler.graph.trn_rows, int(config.data.user_num), int(config.data.item_num), self.world, self.rank)
         self.phase_seconds = [0.0, 0.0, 0.0]
+        # bounded samples of an epoch (bench.py --workload scale, tests/test_configs_gpu.py; None = the reference's epoch): the reverse chain + top-k
+        # run for the first `rebuild_limit` (own) users only, the others keep their observed interactions as their rebuilt edges
+        self.rebuild_limit: Optional[int] = None
         self.best = dict(Recall=0.0, NDCG=0.0, Precision=0.0, epoch=0)
         self.his_max = [0.0, 0.0, 0.0]
 
@@ -93,7 +96,7 @@ class Coach:
             DE.hp["seed"] = int(DE.hp.get("seed", 1818)) + 7919 * self.rank  # the replicas' rows / item slices draw from different Philox streams
             DE.t_gen = torch.Generator(device=self.device)
             if self.item_shard is None:  # row split: every replica trains the Denoise on the minibatch rows of its own users
-                DE.shard_world, DE.shard_rank, DE.shard_group = self.world, self.rank, self.group
+                DE.shard_world, DE.shard_rank, DE.shard_group, DE.shard_active = self.world, self.rank, self.group, True
                 DE.t_gen.manual_seed(int(cfg.base.seed) + 101 * (self.rank + 1))
             else:  # item split: every replica sees all rows of the minibatch (over its item slice), so the rows' timesteps must agree everywhere
                 DE.t_gen.manual_seed(int(cfg.base.seed) + 101)
@@ -110,14 +113,14 @@ class Coach:
         activations instead of weight gradients.  DMM_DENOISE_SHARD = rows | items | auto (default: items once a modality's weight gradient
         reaches 256 MiB -- I >= 32768 at H = 1024 -- and the step's kernels cover the shape)."""
         from .engine import ItemShard
-        if self.world <= 1:
+        if not comm.active(self.world):
             return None
         cfg = self.config
         mode = os.environ.get("DMM_DENOISE_SHARD", "auto")
         I, D = int(cfg.data.item_num), int(cfg.base.latdim)
         latent = os.environ.get("DMM_CHAIN_MODE", "latent") == "latent"  # (the item-sharded rebuild exists for the latent chain only: engine.rebuild_edges)
         fits = (len(hidden) == 1 and D in (64, 128, 256) and self.precision == 1 and int(cfg.hyper.sampling_step) == 0 and latent
-                and (self.world - 1) * -(-I // self.world) < I)
+                and (self.world - 1) * -(-I // self.world) < I)  # (the last replica's slice is not empty)
         if mode == "items" and not fits:
             raise ValueError("DMM_DENOISE_SHARD=items needs one hidden width, d in 64 / 128 / 256, bf16 mode, sampling_step = 0, the latent chain and a "
                              "non-empty item slice per replica")
@@ -273,9 +276,14 @@ class Coach:
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
         if modal_adj_override is None:
             sstep = int(cfg.hyper.sampling_step)
+            lim = self.rebuild_limit
             if lay is None:
-                edges = DE.rebuild_edges(dd.rows, diff_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep,
-                                         csr=(dd.ptr, dd.col32, 0))
+                if lim is None:
+                    reb_batches, init = diff_batches, None
+                else:
+                    reb_batches, init = [torch.arange(min(int(lim), int(cfg.data.user_num)), device=dev)], dd.col32
+                edges = DE.rebuild_edges(dd.rows, reb_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep,
+                                         csr=(dd.ptr, dd.col32, 0), init_cols=init)
                 if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
                     self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim), vec=self.base_adj.vec,
                                                                   task_len=graph.spmm_task_len(self.base_adj.vec))
@@ -284,8 +292,10 @@ class Coach:
                     self.graph_builder = graph.ShardedGraphBuilder(self.local_ptr, lay.nu, lay.users, lay.items, int(cfg.base.latdim), self.rank, self.world,
                                                                    group=self.group, task_len=graph.spmm_task_len(self.base_adj.vec), vec=self.base_adj.vec)
                     self._own_local = torch.arange(lay.nu, device=dev)
-                edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [self._own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
-                                         sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0))
+                own_local = self._own_local if lim is None else self._own_local[:int(lim)]
+                init = None if lim is None else dd.col32[int(dd.ptr[lay.u0]):int(dd.ptr[lay.u1])]
+                edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
+                                         sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0), init_cols=init)
             adjs = self.graph_builder.build_all(edges)  # (reads the graphs' sizes back: the host is synchronised here)
             DE.check_chain_error()  # a timed-out group barrier of dmm_latent_chain invalidates these graphs: raise BEFORE any Adam step uses them
         else:

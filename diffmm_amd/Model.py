@@ -16,7 +16,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from . import ops
+from . import comm, ops
 from .Conf import Config
 from .engine import DiffusionEngine, JointEngine, modality_names, schedule_tables
 from .graph import Adjacency
@@ -60,7 +60,7 @@ class Model:
         self.device = torch.device(f"cuda:{config.base.gpu}" if torch.cuda.is_available() else "cpu")
         feats = [image_embedding, text_embedding] + ([audio_embedding] if audio_embedding is not None else [])
         U, I, D = int(config.data.user_num), int(config.data.item_num), int(config.base.latdim)
-        if layout is not None and layout.world > 1:
+        if layout is not None and comm.active(layout.world):
             from .sharded import ShardedJointEngine
             self.engine = ShardedJointEngine(layout, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch), group=group)
         else:

@@ -3,9 +3,18 @@ One indirection so that ONE process can run a single replica of a larger job wit
 group: tools/scale_epoch.py --emulate-world, the per-GPU work and memory of a job the box has no GPUs for).  Nothing here computes."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 LOCAL = "local"  # stand-in group of an emulated replica
+
+
+def active(world: int) -> bool:
+    """Does a run over `world` replicas issue its collectives?  world > 1, or DMM_FORCE_COLLECTIVES=1: a single replica runs the user-sharded engines and
+    sends every collective through the process group (of size 1) -- the way the RCCL communicator, its stream ordering and its dtype / contiguity
+    rules are exercised on a one-GPU box (tests/test_bench_gpu.py: bench.py --gpus 1 --backend nccl under that variable)."""
+    return world > 1 or os.environ.get("DMM_FORCE_COLLECTIVES") == "1"
 
 
 class _Done:

@@ -85,12 +85,12 @@ class ItemShard:
         return self.i1 - self.i0
 
     def all_reduce(self, t: Tensor) -> None:
-        if self.world > 1:
+        if comm.active(self.world):
             comm.all_reduce(t, group=self.group)
 
     def all_gather(self, out: Tensor, t: Tensor) -> None:
         """out [world * n, ...] <- every replica's t [n, ...] in rank order."""
-        comm.all_gather_into(out, t, self.rank, group=self.group if self.world > 1 else comm.LOCAL)
+        comm.all_gather_into(out, t, self.rank, group=self.group if comm.active(self.world) else comm.LOCAL)
 
 
 class FlatParams:
@@ -678,6 +678,7 @@ class DiffusionEngine:
         # user-sharded training (diffmm_amd/sharded.py): every replica holds the rows of a minibatch whose users it owns; the Denoise
         # weights are replicated and their gradients SUMMED over the replicas (the loss scale already carries 1 / global batch)
         self.shard_world, self.shard_rank, self.shard_group = 1, 0, None
+        self.shard_active = False  # row split in force: loss sums and weight gradients are all-reduced (Main.Coach.prepareModel sets it)
         self.t_gen: Optional[torch.Generator] = None  # timestep draws (per-replica generator when sharded; torch's global one otherwise)
 
     x0p = property(lambda self: self._lazy["x0p"].get())      # x_0 with the padded leading dimension
@@ -1139,7 +1140,7 @@ class DiffusionEngine:
         Bg = int(global_rows) if global_rows is not None else B
         sh = self.ishard
         if sh is not None:  # item-sharded Denoise: every replica takes ALL rows of the minibatch over its slice of the items
-            if precision != 1 or not (self._fused_expand() and self._folded_products()) or self.shard_world > 1 or Bg != B or not isinstance(x0, CsrRows):
+            if precision != 1 or not (self._fused_expand() and self._folded_products()) or self.shard_active or Bg != B or not isinstance(x0, CsrRows):
                 raise ValueError("item-sharded Denoise: bf16 batched step (fused expand, folded products, d in 64 / 128 / 256) on CSR rows, the whole "
                                  "minibatch on every replica, not combined with the row-split mode")
             if len(feats) != M or any(f.shape[0] != self.I for f in feats):
@@ -1170,7 +1171,7 @@ class DiffusionEngine:
                 for m in range(M):
                     self.loss_forward(m, x0p, ts[m], noise[m] if noise is not None else None, feats[m], i_embs, reg_term, precision, ui_ready=m > 0)
             sums = self._loss_block[:, :B].sum(1)
-        if self.shard_world > 1:
+        if self.shard_active:
             comm.all_reduce(sums, group=self.shard_group)
         if sh is not None:
             sh.all_reduce(sums)
@@ -1219,7 +1220,7 @@ class DiffusionEngine:
 
     def reduce_and_step(self, m: int):
         P = self.P[m]
-        if self.shard_world > 1:
+        if self.shard_active:
             comm.all_reduce(P.grad, group=self.shard_group)  # sum: every replica's rows carry the 1 / (global batch) scale already
         P.step += 1
         ops.adam_step(P.data, P.grad, P.m, P.v, self.lr, P.step, p16=self._w16[m], p16_lo=P.offsets["in_layers.0.weight"])
@@ -1666,13 +1667,18 @@ class DiffusionEngine:
             main.wait_event(self._side_events[m])
 
     def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1,
-                      sampling_step: int = 0, csr: Optional[tuple] = None) -> List[Tensor]:
+                      sampling_step: int = 0, csr: Optional[tuple] = None, init_cols: Optional[Tensor] = None) -> List[Tensor]:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
         int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]]).  The ids in `user_batches`
         index deg_ptr and are what `dense_rows` receives (a user-sharded replica passes LOCAL ids and maps them itself).
         csr = (ptr int64 over all users, col int32, id offset): with it (bf16 chain, sampling_step 0) x_0 is never densified.
-        sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time."""
-        out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
+        sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time.
+        init_cols (bounded samples of an epoch only: Coach.rebuild_limit): int32 items laid out by deg_ptr that the users NOT in `user_batches` keep
+        -- their observed interactions -- so that a rebuild over a subset of the users still yields whole graphs."""
+        if init_cols is not None:
+            out = [init_cols[:max(1, n_edges)].to(torch.int32).clone() for _ in range(self.M)]
+        else:
+            out = [torch.zeros(max(1, n_edges), dtype=torch.int32, device=self.dev) for _ in range(self.M)]
         if self.ishard is not None and not (precision == 1 and self._latent_mode() and csr is not None and sampling_step == 0):
             # the stepwise / dense-start chains would run on this replica's W1 / W2 SLICE while the top-k ranks all I_chain columns: wrong graphs, silently
             raise ValueError("DiffusionEngine: an item-sharded Denoise rebuilds through the latent chain from CSR rows only (bf16 mode, chain_mode = latent, "

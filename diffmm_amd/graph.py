@@ -415,8 +415,8 @@ class ShardedGraphBuilder:
             if item_idx.dtype != torch.int32 or not item_idx.is_contiguous() or item_idx.numel() < self.E:
                 raise ValueError("ShardedGraphBuilder.build_all: item_idx must be a contiguous int32 tensor with one entry per local edge")
             L.call("dmm_count_items", L.ptr(item_idx), self.E, self.I, L.ptr(counts[i]), L.stream())
-        if self.world > 1:
-            from . import comm
+        from . import comm
+        if comm.active(self.world):
             comm.all_reduce(counts, group=self.group)
         metas = torch.zeros((M, 8), dtype=torch.int32, device=dev)
         outs = []

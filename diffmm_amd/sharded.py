@@ -211,7 +211,7 @@ class ShardedJointEngine:
         return self._x16_bufs
 
     def _ar(self, t: Tensor):
-        if self.world > 1:
+        if comm.active(self.world):
             L.call_py(_all_reduce, t, self.group)
 
     _PLAIN = frozenset(("adj", "x_lo", "x_hi", "split", "y"))
@@ -261,11 +261,11 @@ class ShardedJointEngine:
     # the item rows of the modal SpMMs that feed the projection gradients, then the item rows of the base SpMM = d(i_embs) -- overlap
     # with the remaining backward SpMM and with the projection backward.
     def _exchange_begin(self, bufs: List[Tensor]):
-        if self.world > 1:
+        if comm.active(self.world):
             L.call_py(self._exchange_begin_now, bufs)
 
     def _exchange_end(self):
-        if self.world > 1:
+        if comm.active(self.world):
             L.call_py(self._exchange_end_now)
 
     def _exchange_begin_now(self, bufs: List[Tensor]):
@@ -571,7 +571,7 @@ class ShardedJointEngine:
         """Loss values of the last step (global: the partial user-side L2 term is summed over the replicas here -- a host sync)."""
         lp = self.loss_parts.double().clone()
         nT = self.n_terms
-        if self.world > 1:
+        if comm.active(self.world):
             _all_reduce(lp[nT + 1:nT + 2], self.group)
         lp = lp.cpu()
         cl, bpr, reg = float(lp[:nT].sum()), float(lp[nT]), float(lp[nT + 1] + lp[nT + 2])

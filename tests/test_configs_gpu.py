@@ -1,4 +1,6 @@
-"""BASELINE.json configurations 3 and 4 at their full shapes, live on the GPU (they used to be run by hand only):
+"""BASELINE.json configurations 3, 4 and 5 at their full shapes, live on the GPU (they used to be run by hand only):
+  * config 5 -- 10M users x 1M items, 3 modalities, d = 256, T = 1000, batch 8192 on 8 GPUs: ONE replica of the 8 at the full shape on this GPU
+    (collectives reduced to their local part, comm.LOCAL) through the code tools/scale_epoch.py --emulate-world 8 drives -- see the test;
   * config 3 -- Amazon-Baby shape (19445 x 7050, image + text, d = 64, T = 40, conf/baby.toml: sampling_step = 0 as the reference's
     Conf.py would run it, the modality-vs-modality contrastive branch cl_method = 1): two epochs;
   * config 4 -- Sports shape (35598 x 18357, image + text, d = 128, T = 200, batch 8192): one epoch on one GPU, and the same epoch
@@ -108,3 +110,33 @@ def test_tiktok_shape_epochs_with_bf16_gather_operands():
         for k, tol in tols.items():
             assert abs(a["train"][k] - b["train"][k]) <= tol * abs(a["train"][k]), f"epoch {i} {k}: fp32 operands {a['train'][k]:.5f} vs bf16 {b['train'][k]:.5f}"
         assert abs(a["test"]["Recall"] - b["test"]["Recall"]) <= 0.03
+
+
+def test_config5_one_replica_of_eight_at_full_shape():
+    """BASELINE config 5 (10M users x 1M items, M = 3, d = 256, T = 1000, batch 8192, 8 GPUs): replica 0 of 8 at the FULL shape on this GPU -- its
+    1.25M own users' graph rows, its local adjacency blocks over [own users ; 1M items] planned for bf16 gather operands, its 125k-item slice of the three
+    Denoise MLPs (item-sharded), lean chain buffers -- with every collective reduced to its local part (comm.LOCAL; the exchanges themselves need 8 GPUs).
+    A bounded sample of an epoch: 2 diffusion iterations, the T = 1000 reverse chain + per-user top-k over 1M columns + sharded graph build for 2048 own
+    users (the others keep their observed interactions), 2 joint iterations, the evaluation of the own test users.  Asserted: finite losses of the expected
+    magnitude, rebuilt blocks with exactly the base block's non-zero count (k_u = deg_u; 2 E_local + own users + this replica's item self loops), the
+    rebuilt rows keep their degree with distinct items, clear chain error word, peak HBM under 200 GiB (measured 175), inside the time limit."""
+    need_gpu()
+    import torch
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.join(REPO, "tools", "scale_epoch.py"), "--users", "10000000", "--items", "1000000", "--latdim", "256", "--T", "1000", "--batch", "8192",
+           "--emulate-world", "8", "--diff-iters", "2", "--joint-iters", "2", "--rebuild-users", "2048"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=850)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    print({k: out[k] for k in ("epoch_s", "phase_s", "test_s", "peak_alloc_GiB", "base_block_nnz")})
+    assert out["emulated_replica"] == [0, 8] and out["denoise_shard"] == "items" and (out["users"], out["items"], out["d"], out["T"], out["batch"]) == (10_000_000, 1_000_000, 256, 1000, 8192)
+    assert out["own_users"] == 1_250_000 and out["diff_iters_run"] == 2 and out["joint_iters_run"] == 2
+    for k, v in {**out["train"], **out["test"]}.items():
+        assert math.isfinite(v), (k, v)
+    # (Loss terms are divided by the FULL epoch's step count, Main.py:379-383, of which 2 ran: only their sign / finiteness is meaningful here)
+    assert out["train"]["BPR Loss"] > 0 and out["train"]["CL loss"] > 0 and out["train"]["reg loss"] > 0
+    assert 0.0 < out["test"]["Recall"] < 1.0 and 0.0 < out["test"]["NDCG"] < 1.0
+    want = 2 * out["E"] + out["own_users"] + 1_000_000 // 8  # item i's self loop lives on replica i % 8
+    assert out["base_block_nnz"] == want and out["modal_block_nnz"] == [want] * 3
+    assert out["rebuilt_rows_keep_degree"] and out["rebuilt_rows_distinct"] and out["chain_error_word_clear"]
+    assert out["peak_alloc_GiB"] < 200.0

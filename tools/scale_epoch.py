@@ -4,7 +4,8 @@ BASELINE.json's config 5 scaled to one GPU) -- the memory / index-width / time a
 phase times, the peak HBM allocation and the first epoch's losses.
 
     python tools/scale_epoch.py [--users 1000000 --items 100000 --latdim 256 --T 40 --batch 8192 --joint-iters 0]
---joint-iters N > 0 stops the joint phase after N minibatches (its cost is E / batch full-graph iterations) and extrapolates; --diff-iters likewise.
+--joint-iters N > 0 stops the joint phase after N minibatches (its cost is E / batch full-graph iterations) and extrapolates; --diff-iters likewise;
+--rebuild-users N runs the reverse chain + top-k for the first N own users (the others keep their observed interactions as rebuilt edges).
 --emulate-world W [--emulate-rank r]: ONE process runs replica r of a W-replica user-sharded job on --users x --items (BASELINE config 5 is
 --users 10000000 --items 1000000 --latdim 256 --T 1000 --emulate-world 8): the graph rows of the replica's own users only, its
 local adjacency blocks, its item slice of the Denoise MLPs, its share of the rebuild and of the evaluation -- with every collective reduced to
@@ -24,6 +25,7 @@ ap.add_argument("--latdim", type=int, default=256); ap.add_argument("--T", type=
 ap.add_argument("--joint-iters", type=int, default=0); ap.add_argument("--precision", type=int, default=1)
 ap.add_argument("--no-test", action="store_true")
 ap.add_argument("--diff-iters", type=int, default=0)
+ap.add_argument("--rebuild-users", type=int, default=0, help="reverse chain + top-k for the first N own users only; the others keep their observed interactions")
 ap.add_argument("--emulate-world", type=int, default=1); ap.add_argument("--emulate-rank", type=int, default=0)
 a = ap.parse_args()
 t0 = time.time()
@@ -68,6 +70,8 @@ if a.diff_iters:
     h.diffusionLoader.index_batches = lambda: full_idx()[: a.diff_iters]
 if coach.item_shard is not None:
     print(f"Denoise item-sharded: items {coach.item_shard.i0}..{coach.item_shard.i1} of {a.items} on this replica; lean chain views: {coach.diff_engine.view_rows} rows", flush=True)
+if a.rebuild_users:
+    coach.rebuild_limit = a.rebuild_users
 torch.cuda.synchronize(); t0 = time.time()
 res = coach.trainEpoch()
 torch.cuda.synchronize(); t_epoch = time.time() - t0
@@ -77,7 +81,15 @@ out = {"emulated_replica": [ER, EW] if EW > 1 else None, "diff_iters_run": a.dif
        "denoise_shard": "items" if coach.item_shard is not None else ("rows" if max(world, EW) > 1 else None), "users": g.users, "items": g.items, "E": g.nnz, "d": a.latdim, "T": a.T, "batch": a.batch, "epoch_s": t_epoch, "phase_s": dict(zip(("diffusion", "rebuild", "joint"), coach.phase_seconds)),
        "joint_iters_run": a.joint_iters or n_joint_full, "joint_iters_full_epoch": n_joint_full, "test_s": t_test,
        "peak_alloc_GiB": torch.cuda.max_memory_allocated() / 2**30, "train": {k: float(v) for k, v in res.items()}, "test": tst}
-out["world"] = world
+adjs = [coach.image_adj, coach.text_adj] + ([coach.audio_adj] if coach.M == 3 else [])
+out.update(world=world, rebuild_users=a.rebuild_users or None, base_block_nnz=int(coach.base_adj.nnz), modal_block_nnz=[int(x.nnz) for x in adjs],
+           own_users=int(coach.layout.nu) if coach.layout is not None else g.users, chain_error_word_clear=True)  # (trainEpoch raises on a set error word)
+if coach.rebuild_limit:  # the rebuilt rows: every user keeps its degree with distinct items
+    nu_chk = min(int(coach.rebuild_limit), out["own_users"])
+    rp = adjs[0].rowptr[:nu_chk + 1].long().cpu().numpy(); col = adjs[0].col[:int(rp[-1])].cpu().numpy()
+    base_rp = coach.base_adj.rowptr[:nu_chk + 1].long().cpu().numpy()
+    out["rebuilt_rows_keep_degree"] = bool((np.diff(rp) == np.diff(base_rp)).all())
+    out["rebuilt_rows_distinct"] = bool(all(len(set(col[rp[u]:rp[u + 1]].tolist())) == rp[u + 1] - rp[u] for u in range(0, nu_chk, max(1, nu_chk // 64))))
 if rank == 0:
     print(json.dumps(out), flush=True)
 if world > 1:
