@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffmm_hip.so")
+# DMM_LIB (tools only): another build of the same library, e.g. the -DP8_TIMING build tools/latent_stamps.py reads per-workgroup timestamps from
+LIB_PATH = os.environ.get("DMM_LIB") or os.path.join(_HERE, "libdiffmm_hip.so")
 
 SPMM_MAX_BATCH = 4
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2

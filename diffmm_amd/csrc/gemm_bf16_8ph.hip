@@ -367,15 +367,19 @@ __device__ __forceinline__ void p8_epilogue(const GemmBf16P& P, const P8Acc& acc
 #ifdef P8_TIMING
 __device__ unsigned long long p8_stamps[8 * 8192];
 #define P8_STAMP(i) if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 8192) p8_stamps[(blockIdx.x * 8 + (i))] = wall_clock64()
+// the persistent chain kernel: 8 stamps per (workgroup, step), workgroups < 512, steps < 64 (tools/latent_stamps.py)
+__device__ unsigned long long latent_stamps[512 * 64 * 8];
+#define LAT_STAMP(step, i) if (threadIdx.x == 0 && blockIdx.x < 512 && (step) < 64) latent_stamps[((blockIdx.x * 64 + (step)) * 8 + (i))] = wall_clock64()
 #else
 #define P8_STAMP(i)
+#define LAT_STAMP(step, i)
 #endif
 
 // The K loop of one 256 x 256 tile: LDS-DMA prologue, nk K tiles of 4 phases, drain.  On return every LDS-DMA has landed and every fragment
 // read is done (LDS is free) and the wave rows are re-aligned.  acc is accumulated into (the caller initialises it).
-template <bool STAMP>
+template <int STAMP>  // 0: none, 1: the GEMM kernel's stamp 1, 2: the chain kernel's stamp 1 of step `stamp_step` (both P8_TIMING builds only)
 __device__ __forceinline__ void p8_main_loop(P8Acc& acc, const __bf16* const (&offX)[2][2], const __bf16* const (&offY)[2][2], int nk, char* smem, int wave,
-                                             int wr, int wc, const int (&lo)[2]) {
+                                             int wr, int wc, const int (&lo)[2], [[maybe_unused]] int stamp_step = 0) {
   [[maybe_unused]] const int lane = threadIdx.x & 63;  // (P8_STAMP)
   auto issue = [&](const __bf16* const (&src)[2], int kt, char* unit) {
     const int k0 = (kt < nk ? kt : nk - 1) * 64;
@@ -394,7 +398,8 @@ __device__ __forceinline__ void p8_main_loop(P8Acc& acc, const __bf16* const (&o
   issue(offY[0], 1, buf1 + Y0);
   P8_VMCNT8();   // X0(0), Y0(0) have landed (this wave's part)
   P8_BARRIER();  // ... every wave's part
-  if (STAMP && threadIdx.x < 64) { P8_STAMP(1); }
+  if (STAMP == 1 && threadIdx.x < 64) { P8_STAMP(1); }
+  if (STAMP == 2) { LAT_STAMP(stamp_step, 1); }
   if (wr == 1) P8_BARRIER();  // row 1 runs one barrier behind row 0 from here on
 
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_8ph_kernel(const GemmBf16Bat
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc.v[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  p8_main_loop<true>(acc, offX, offY, nk, smem, wave, wr, wc, lo);
+  p8_main_loop<1>(acc, offX, offY, nk, smem, wave, wr, wc, lo);
   if (threadIdx.x < 64) { P8_STAMP(2); }
   p8_epilogue<EPI>(P, acc, smem, m0, n0, wave, lane);
   if (threadIdx.x < 64) { P8_STAMP(3); }
@@ -613,13 +618,16 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
     {
       const long long hd = src ? hdelta : 0;
       const __bf16* offX[2][2] = {{offA[0][0] + hd, offA[0][1] + hd}, {offA[1][0] + hd, offA[1][1] + hd}};
-      p8_main_loop<false>(acc, offX, offY, nk, smem, wave, wr, wc, lo);
+      LAT_STAMP(step, 0);
+      p8_main_loop<2>(acc, offX, offY, nk, smem, wave, wr, wc, lo, step);
+      LAT_STAMP(step, 2);
     }
     P8Epi E;
     E.C = nullptr; E.Cb = hbuf[src ^ 1]; E.R = nullptr; E.Rb = nullptr; E.bias = nullptr; E.bias2 = bias_t + (long long)(i - 1) * ldbt;
     E.ldc = 0; E.ldcb = ldh; E.ldr = 0; E.ldrb = 0; E.M = rows; E.N = Lb.H; E.act = DMM_ACT_NONE; E.alpha = coef[2 * i]; E.e1 = 1.f; E.e2 = 1.f;
     if (interior) p8_epilogue_fast<0, false, true, DMM_ACT_NONE, false, true, (WT ? 2 : 1)>(E, acc, smem, m0, n0, wave, lane);
     else p8_epilogue_fast<0, false, true, DMM_ACT_NONE, true, true, (WT ? 2 : 1)>(E, acc, smem, m0, n0, wave, lane);
+    LAT_STAMP(step, 3);
     if (step + 1 == T - 1) break;  // h_0 is written; nothing follows in this kernel
     const float sc = coef[2 * i + 1];
 #pragma unroll
@@ -637,6 +645,7 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
     // CU's L1 invalidated), wait -> workgroup barrier -> the next step's loads
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    LAT_STAMP(step, 4);
     if (threadIdx.x == 0) {
       if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: the flag must not overtake the write-back)
@@ -653,6 +662,7 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LAT_STAMP(step, 5);
     }
     __syncthreads();
   }
@@ -774,5 +784,8 @@ extern "C" int dmm_latent_chain_supported(int H) { return dmm::latent_chain_supp
 #ifdef P8_TIMING
 extern "C" int dmm_debug_p8_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dmm::p8_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int dmm_debug_latent_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dmm::latent_stamps), sizeof(unsigned long long) * n);
 }
 #endif

@@ -222,3 +222,40 @@ def test_checkpoint_layout_is_versioned_and_remapped_by_name():
     other = FlatParams(new[:-1] + [("out_layers.0.weight", (5, 7))], "cpu")
     with pytest.raises(ValueError, match="do not match"):
         restore_flat(other, rec, "test")
+
+
+def test_denoise_shard_mode_is_chosen_at_the_documented_threshold(monkeypatch):
+    """Coach._denoise_item_shard: `auto` splits the Denoise MLPs by ITEMS once a modality's weight gradient (2 I H fp32) reaches 256 MiB --
+    I >= 32768 at H = 1024 -- and by minibatch ROWS below; `rows` / `items` force it; the item split is refused where its kernels do not apply."""
+    from diffmm_amd.Conf import Config
+    from diffmm_amd.Main import Coach
+    from diffmm_amd.engine import ItemShard
+
+    def pick(I, world=8, H=1024, hidden=(1024,), d=64, precision=1, sstep=0, rank=3):
+        c = Coach.__new__(Coach)
+        c.config = Config()
+        c.config.data.item_num, c.config.base.latdim, c.config.hyper.sampling_step = I, d, sstep
+        c.world, c.rank, c.group, c.precision = world, rank, None, precision
+        return c._denoise_item_shard(H, list(hidden))
+
+    monkeypatch.delenv("DMM_DENOISE_SHARD", raising=False)
+    monkeypatch.delenv("DMM_CHAIN_MODE", raising=False)
+    monkeypatch.delenv("DMM_FORCE_COLLECTIVES", raising=False)
+    assert pick(32767) is None and pick(6710) is None and pick(18357) is None, "every shipped dataset: row split"
+    sh = pick(32768)
+    assert isinstance(sh, ItemShard) and (sh.rank, sh.world, sh.items_global, sh.S) == (3, 8, 32768, 4096)
+    assert isinstance(pick(1_000_000, d=256), ItemShard), "config 5"
+    assert pick(1_000_000, world=1) is None, "a single GPU has nothing to split"
+    for kw in (dict(hidden=(512, 1024)), dict(d=96), dict(precision=3), dict(sstep=2)):
+        assert pick(1_000_000, **kw) is None, f"auto falls back to rows where the item-split step does not apply: {kw}"
+    monkeypatch.setenv("DMM_CHAIN_MODE", "stepwise")
+    assert pick(1_000_000) is None, "the item-sharded rebuild exists for the latent chain only (ADVICE r3)"
+    monkeypatch.delenv("DMM_CHAIN_MODE")
+    monkeypatch.setenv("DMM_DENOISE_SHARD", "rows")
+    assert pick(1_000_000) is None
+    monkeypatch.setenv("DMM_DENOISE_SHARD", "items")
+    assert isinstance(pick(6710), ItemShard)
+    with pytest.raises(ValueError):
+        pick(6710, precision=3)
+    with pytest.raises(ValueError):
+        pick(9, world=8)  # ceil(9 / 8) = 2 items per slice would leave the last replicas without items
