@@ -25,7 +25,7 @@ class SpmmProblem(C.Structure):
                 ("y_mean", C.c_void_p), ("m1", C.c_void_p), ("m2", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("partial", C.c_void_p), ("fix", C.c_void_p), ("n_partial_blocks", C.c_int32), ("n_fix", C.c_int32), ("n_rows", C.c_int32), ("n_tasks", C.c_int32), ("n_head_tasks", C.c_int32), ("split", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
                 ("noise_degree", C.c_float), ("raw", C.c_void_p), ("raw_from", C.c_int32), ("rng_row_split", C.c_int32), ("rng_row_add_lo", C.c_int32),
-                ("rng_row_add_hi", C.c_int32), ("y16", C.c_void_p), ("y_pert16", C.c_void_p)]
+                ("rng_row_add_hi", C.c_int32), ("y16", C.c_void_p), ("y_pert16", C.c_void_p), ("fix_count", C.c_void_p)]
 
 
 class GemmArgs(C.Structure):

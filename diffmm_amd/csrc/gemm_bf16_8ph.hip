@@ -540,16 +540,22 @@ struct LatentBatch {
   int* flags;         // [0, 256): group counters, [256, 512): per-group XCC-id masks (both zero on entry), flags[err_at] = error word
   float s_init;       // c2[T - 1] / c1[T - 1]
   int rows, H, T, rbs, g0, n_groups, err_at;
+  int contig;                   // groups dealt to the XCDs in contiguous runs (1) or strided (0)
+  int first_wave, phase_ticks;  // second form: workgroup slots per XCD that get a CU to themselves; start delay of the later ones (0: none)
 };
 constexpr int LATENT_SPIN_MAX = 1 << 22;  // x (s_sleep(2) + an L2 round trip, ~0.3 us): about a second, then give up (the step kernel path takes a few ms in total)
 
-template <bool WT>
+template <bool WT, bool EARLY_INV>
 __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch Lb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nt = Lb.H >> 8;
   const int slot = blockIdx.x >> 3;
-  const int gl = (slot / nt) * 8 + (blockIdx.x & 7);
-  if (gl >= Lb.n_groups) return;  // (uniform over the workgroup; such workgroups belong to no group)
+  // group of this workgroup: strided over the XCDs (consecutive groups on different XCDs), or -- Lb.contig -- each XCD takes a CONTIGUOUS run of
+  // groups, i.e. (mostly) one modality: that modality's G (2 MiB at H = 1024) then stays in the XCD's 4 MiB L2 instead of two or three of them
+  // competing for it with the h exchange
+  const int gpx = (Lb.n_groups + 7) >> 3;
+  const int gl = Lb.contig ? (int)(blockIdx.x & 7) * gpx + slot / nt : (slot / nt) * 8 + (int)(blockIdx.x & 7);
+  if (gl >= Lb.n_groups || (Lb.contig && slot / nt >= gpx)) return;  // (uniform over the workgroup; such workgroups belong to no group)
   const int group = Lb.g0 + gl;
   const LatentP& P = Lb.p[group / Lb.rbs];
   const int m0 = (group % Lb.rbs) * 256, n0 = (slot % nt) * 256;
@@ -622,6 +628,12 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
       p8_main_loop<2>(acc, offX, offY, nk, smem, wave, wr, wc, lo, step);
       LAT_STAMP(step, 2);
     }
+    // The acquire's L1 invalidate, HOISTED in front of the epilogue (DMM_LATENT_EARLY_INV, default on): this CU's loads of h are over for this step
+    // (the main loop ended with vmcnt(0) + barrier) and none is issued before the group barrier below has been passed, so no line of either h buffer
+    // can enter L1 between this invalidate and the next step's loads -- the stale copies the acquire exists to drop (lines of the buffer the next
+    // step reads, cached when it was last read two steps ago) are dropped here, and the 1.5-1.7 us the invalidate takes (MI355X_MICROARCH.md,
+    // inter-workgroup visibility) pass under the epilogue instead of behind the poll.  Its completion is waited for by wave 0's vmcnt(0) below.
+    if (EARLY_INV && threadIdx.x == 0) asm volatile("buffer_inv sc1" ::: "memory");
     P8Epi E;
     E.C = nullptr; E.Cb = hbuf[src ^ 1]; E.R = nullptr; E.Rb = nullptr; E.bias = nullptr; E.bias2 = bias_t + (long long)(i - 1) * ldbt;
     E.ldc = 0; E.ldcb = ldh; E.ldr = 0; E.ldrb = 0; E.M = rows; E.N = Lb.H; E.act = DMM_ACT_NONE; E.alpha = coef[2 * i]; E.e1 = 1.f; E.e2 = 1.f;
@@ -660,9 +672,214 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
         const int mask = __hip_atomic_load(Lb.flags + 256 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (mask & (mask - 1)) __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!EARLY_INV) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       LAT_STAMP(step, 5);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- the persistent chain, second form: TWO workgroups per CU ------------------------------------------------------------------------------------
+// Per-workgroup timestamps of the kernel above (tools/latent_stamps.py) split a step of 32 us into 21 us of main loop and 11 us in which the matrix
+// pipe idles: epilogue 4.7 (bound by the exp / rcp of the tanh: VALU, not memory), store drain 2.2, group barrier 2.4, prologue 1.  One workgroup per
+// CU cannot overlap those phases with anything.  Here a workgroup is FOUR waves (one per SIMD) that keep a 128 x 256 tile of z (128 accumulator
+// registers per lane, wave tile 64 x 128) and two workgroups share a CU: while one runs its epilogue / waits at its group barrier, the other one's
+// MFMAs have the matrix pipe to themselves.  LDS per workgroup 72 KiB: a ring of three stages of K = 32 (A: 128 rows x 64 B, B: 256 rows x 64 B,
+// linear images -- a 16 x 32 bf16 fragment read is 1 KiB contiguous, conflict-free without a swizzle), filled by LDS-DMA two stages ahead with counted
+// completion (vmcnt(6): the next stage's six loads per wave may still be in flight) and ONE raw barrier per stage.  Registers <= 256 per lane.
+// Group = the H / 256 workgroups of a 128-row block; placement, hand-off and error word exactly as above.  The host launches at most 2 CUs / nt groups
+// at a time (every member workgroup resident: two per CU, checked by an occupancy query; otherwise the first form runs).
+constexpr int V2_KT = 32;                           // K per stage
+constexpr int V2_A_BYTES = 128 * V2_KT * 2;         // 8 KiB
+constexpr int V2_STAGE = (128 + 256) * V2_KT * 2;   // 24 KiB
+constexpr int V2_STAGES = 3;
+constexpr int V2_LDS = V2_STAGES * V2_STAGE;        // 72 KiB
+constexpr int V2_SLAB_LD = 132;                     // epilogue slab: 32 rows x 128 columns of fp32 per wave, row stride 132 floats (conflict-free writes)
+
+#ifdef P8_TIMING
+#define LAT2_STAMP(step, i) if (threadIdx.x == 0 && blockIdx.x < 512 && (step) < 64) latent_stamps[((blockIdx.x * 64 + (step)) * 8 + (i))] = wall_clock64()
+#else
+#define LAT2_STAMP(step, i)
+#endif
+
+template <bool WT>
+__global__ __launch_bounds__(256, 2) void latent_chain_v2_kernel(const LatentBatch Lb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = Lb.H >> 8;
+  const int slot = blockIdx.x >> 3;
+  // group of this workgroup: strided over the XCDs (consecutive groups on different XCDs), or -- Lb.contig -- each XCD takes a CONTIGUOUS run of
+  // groups, i.e. (mostly) one modality: that modality's G (2 MiB at H = 1024) then stays in the XCD's 4 MiB L2 instead of two or three of them
+  // competing for it with the h exchange
+  const int gpx = (Lb.n_groups + 7) >> 3;
+  const int gl = Lb.contig ? (int)(blockIdx.x & 7) * gpx + slot / nt : (slot / nt) * 8 + (int)(blockIdx.x & 7);
+  if (gl >= Lb.n_groups || (Lb.contig && slot / nt >= gpx)) return;  // (uniform over the workgroup; such workgroups belong to no group)
+  const int group = Lb.g0 + gl;
+  const LatentP& P = Lb.p[group / Lb.rbs];
+  const int m0 = (group % Lb.rbs) * 128, n0 = (slot % nt) * 256;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, q = lane >> 4;
+  const int nk = Lb.H / V2_KT, rows = Lb.rows, T = Lb.T;
+  const float* const coef = Lb.coef;
+  const float* const bias_t = P.bias_t;
+  const long long ldbt = P.ldbt, ldh = P.ldh;
+  __bf16* const hbuf[2] = {P.ha, P.hb};
+  int* const flag = Lb.flags + gl;
+  int* const err = Lb.flags + Lb.err_at;
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_or(Lb.flags + 256 + gl, 1 << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- staging: a wave-load (buffer_load ... lds) moves 16 rows x 64 B (lane -> row lane / 4, 16-byte chunk lane % 4) to 1 KiB of LDS; wave w
+  // fills row blocks {w, w + 4} of A (8 blocks) and {w, w + 4, w + 8, w + 12} of B (16 blocks) of every stage.  Buffer addressing keeps the per-lane
+  // part of an address in ONE register per operand (the row block and the K offset ride in the scalar offset) and returns zeros for rows past the
+  // operand's end (the ragged last row block needs no clamp).
+  const unsigned h_bytes = (unsigned)((unsigned long long)rows * (unsigned long long)ldh * 2ull);
+  const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.ha, 0, h_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.hb, 0, h_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.G, 0, (unsigned)((unsigned long long)Lb.H * (unsigned long long)P.ldg * 2ull), 0x00020000);
+  const unsigned voffA = (unsigned)(lane >> 2) * (unsigned)ldh * 2u + (unsigned)(lane & 3) * 16u;
+  const unsigned voffB = (unsigned)(lane >> 2) * (unsigned)P.ldg * 2u + (unsigned)(lane & 3) * 16u;
+  const unsigned sA = (unsigned)((unsigned long long)(m0 + wave * 16) * (unsigned long long)ldh * 2ull), sA_step = 64u * (unsigned)ldh * 2u;
+  const unsigned sB = (unsigned)(n0 + wave * 16) * (unsigned)P.ldg * 2u, sB_step = 64u * (unsigned)P.ldg * 2u;
+  const int offA = (wr * 64 + fr) * 64 + q * 16;                   // fragment of m-tile mt: + mt * 1024
+  const int offB = V2_A_BYTES + (wc * 128 + fr) * 64 + q * 16;     // fragment of n-tile nt: + nt * 1024
+
+  // a_init = (c2 / c1)[T - 1] z_T + g in the accumulator layout: acc[mt][n][r] is row m0 + wr 64 + mt 16 + q 4 + r, column n0 + wc 128 + n 16 + fr
+  f32x4 acc[4][8];
+  const float* const gp = P.g + n0 + wc * 128 + fr;  // g of the lane's columns: gp[n * 16] (re-read per step: 8 registers less across the main loop)
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const float gn = gp[n * 16];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + mt * 16 + q * 4 + r;
+        acc[mt][n][r] = Lb.s_init * P.z[(long long)(row < rows ? row : rows - 1) * P.ldz + n0 + wc * 128 + fr + n * 16] + gn;
+      }
+  }
+
+  float* const slab = reinterpret_cast<float*>(smem) + wave * (32 * V2_SLAB_LD);
+  const bool interior = m0 + 128 <= rows;
+  // De-phasing.  Two workgroups that share a CU start together and run the same program: left alone they stay in lockstep -- both in their main loops
+  // (each at half the matrix rate), then both in their epilogues (no MFMA at all) -- and the second workgroup buys nothing.  The workgroups an XCD
+  // receives after its first `Lb.first_wave` (one per CU) are the ones that land next to an earlier workgroup; they -- whole groups, slot / nt being
+  // the group -- start `Lb.phase_ticks` (100 MHz ticks, about half a step) late, so that one workgroup's epilogue / barrier falls into the other's
+  // main loop.  A group's own members stay in phase through their barrier; the two workgroups of a CU belong to different groups.
+  if (Lb.phase_ticks > 0 && (slot / nt) * nt >= Lb.first_wave) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)Lb.phase_ticks) __builtin_amdgcn_s_sleep(32);
+  }
+  for (int step = 0; step < T - 1; ++step) {
+    const int i = T - 1 - step, src = step & 1;
+    LAT2_STAMP(step, 0);
+    // ---- main loop: nk stages of K = 32
+    auto issue = [&](int t, int buf) {
+      const unsigned k0 = (unsigned)t * (V2_KT * 2);
+      char* const st = smem + buf * V2_STAGE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (lds_ptr_t)(st + (wave + 4 * j) * 1024), 16, voffA, sA + j * sA_step + k0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (lds_ptr_t)(st + (wave + 4 * j) * 1024), 16, voffA, sA + j * sA_step + k0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(st + V2_A_BYTES + (wave + 4 * j) * 1024), 16, voffB, sB + j * sB_step + k0, 0, 0);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's part of stage t has landed (stage t + 1 may be in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      P8_BARRIER();  // every wave's part of stage t; and every wave is done reading stage t - 1, whose buffer the next issue refills
+      if (t == 0) { LAT2_STAMP(step, 1); }
+      if (t + 2 < nk) issue(t + 2, buf == 0 ? 2 : buf - 1);
+      const char* const st = smem + buf * V2_STAGE;
+      bf16x8 fa[4], fb[8];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(st + offA + mt * 1024);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(st + offB + n * 1024);
+      P8_LGKM0();
+      __builtin_amdgcn_sched_barrier(0);
+      // (no s_setprio around the MFMAs here: the wave that shares this SIMD belongs to the OTHER workgroup and may be in its epilogue -- a raised
+      // priority starves its exp / rcp chain, MI355X_MICROARCH.md "two waves per SIMD" item 2: measured 11.5 us of epilogue instead of 5)
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[n], acc[mt][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    P8_BARRIER();  // every wave is done reading the last stage: LDS is free for the epilogue slabs
+    LAT2_STAMP(step, 2);
+    // the acquire's L1 invalidate, hoisted in front of the epilogue (see the first form): no load of h is issued between here and the group barrier
+    if (threadIdx.x == 0) asm volatile("buffer_inv sc1" ::: "memory");
+    // ---- epilogue: h' = tanh(c1[i] a + bias_t[i - 1]) in bf16, 2 passes of 32 rows through the wave's LDS slab; a lane stores 8 consecutive columns
+    {
+      const float alpha = coef[2 * i];
+      const float4 bb = *reinterpret_cast<const float4*>(bias_t + (long long)(i - 1) * ldbt + n0 + wc * 128 + (lane & 31) * 4);
+      __bf16* const dst = hbuf[src ^ 1] + (long long)(m0 + wr * 64) * ldh + n0 + wc * 128 + (lane & 31) * 4;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(ml * 16 + q * 4 + r) * V2_SLAB_LD + n * 16 + fr] = acc[pass * 2 + ml][n][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        // a lane owns 4 consecutive columns of 16 rows of the pass: 32 lanes cover a row's 128 columns (256 bytes of bf16: two whole 128-byte
+        // lines per store instruction and row), two rows per instruction
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int rl = it * 2 + (lane >> 5);  // row of the pass
+          const float4 a4 = *reinterpret_cast<const float4*>(slab + rl * V2_SLAB_LD + (lane & 31) * 4);
+          const float w[4] = {tanh_fast_bf16(fmaf(alpha, a4.x, bb.x)), tanh_fast_bf16(fmaf(alpha, a4.y, bb.y)), tanh_fast_bf16(fmaf(alpha, a4.z, bb.z)),
+                              tanh_fast_bf16(fmaf(alpha, a4.w, bb.w))};
+          // (interior tiles store unconditionally: a bounds branch around these stores makes the compiler wait for ALL outstanding stores in
+          // every branch -- 14.6 us of epilogue instead of 5, measured)
+          if (interior) p8_st_keep<(WT ? 2 : 1)>(dst + (long long)(pass * 32 + rl) * ldh, w);
+          else if (m0 + wr * 64 + pass * 32 + rl < rows) p8_st_keep<(WT ? 2 : 1)>(dst + (long long)(pass * 32 + rl) * ldh, w);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    LAT2_STAMP(step, 3);
+    if (step + 1 == T - 1) break;  // h_0 is written; nothing follows in this kernel
+    const float sc = coef[2 * i + 1];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const float gn = gp[n * 16];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][n][r] = fmaf(sc, acc[mt][n][r], gn);
+    }
+    // ---- group barrier (as in the first form)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    LAT2_STAMP(step, 4);
+    if (threadIdx.x == 0) {
+      if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int target = (step + 1) * nt;
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > LATENT_SPIN_MAX) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      if (step == 0) {
+        const int mask = __hip_atomic_load(Lb.flags + 256 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mask & (mask - 1)) __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      LAT2_STAMP(step, 5);
     }
     __syncthreads();
   }
@@ -670,8 +887,12 @@ __global__ __launch_bounds__(512) void latent_chain_8ph_kernel(const LatentBatch
 
 static void latent_chain_attrs() {
   static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_8ph_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_v2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(latent_chain_v2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
     return true;
   }();
   (void)once;
@@ -689,7 +910,7 @@ static int latent_chain_cus() {
   int n = 0, occ = 0;
   if (const char* e = getenv("DMM_LATENT_CUS")) n = atoi(e);
   else if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 0) n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(latent_chain_8ph_kernel<true>), 512, P8_LDS) != hipSuccess || occ < 1) n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(latent_chain_8ph_kernel<true, true>), 512, P8_LDS) != hipSuccess || occ < 1) n = 0;
   cached[dev].store(n + 1, std::memory_order_relaxed);
   return n;
 }
@@ -697,23 +918,69 @@ static int latent_chain_cus() {
 // The group barrier needs all H / 256 member workgroups of the 8 groups of a launch slice co-resident: 8 * H / 256 CUs at least.
 bool latent_chain_supported(int H) { return H >= 256 && H % 256 == 0 && H <= 2048 && latent_chain_cus() >= 8 * (H / 256); }
 
+// Workgroups of the second form a CU holds at once (occupancy query; 0 or 1: the first form runs)
+static int latent_chain_v2_per_cu() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  static std::atomic<int> cached[64];
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v) return v - 1;
+  latent_chain_attrs();
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(latent_chain_v2_kernel<true>), 256, V2_LDS) != hipSuccess || occ < 0) occ = 0;
+  cached[dev].store(occ + 1, std::memory_order_relaxed);
+  return occ;
+}
+
 int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
   latent_chain_attrs();
   // write-through h' stores and no release fence (default; rebuild 5.57 -> 5.20 ms at the bench shape) or plain stores + agent release (0)
   static const int wt = [] { const char* e = getenv("DMM_LATENT_WT"); return e ? atoi(e) : 1; }();
+  static const int early = [] { const char* e = getenv("DMM_LATENT_EARLY_INV"); return e ? atoi(e) : 1; }();
+  // DMM_LATENT_FORM=2 selects the second form (two 128-row workgroups per CU).  It is correct (same tests) but, as measured in round 4
+  // (profiles/r4_chain_forms.txt), slower: a step takes 41-47 us against 31 -- alone on a CU its single wave per SIMD runs the main loop at 20 us
+  // for HALF a tile (reads, waits and MFMAs of a stage serialise: the fragment registers cannot be double-buffered next to 128 accumulators within
+  // 256 registers) and its epilogue at 14 us; sharing the CU recovers part of it but not enough.  Kept for the record; the first form is the default.
+  static const int form = [] { const char* e = getenv("DMM_LATENT_FORM"); return e ? atoi(e) : 1; }();
+  static const int contig = [] { const char* e = getenv("DMM_LATENT_CONTIG"); return e ? atoi(e) : 1; }();
   const int cus = latent_chain_cus();
   const int nt = base.H / 256;
   if (cus < 8 * nt) return -1;  // the groups of a launch could not all be resident: the caller runs one launch per step instead
+  if (form == 2 && latent_chain_v2_per_cu() >= 2) {
+    static const int per_env = [] { const char* e = getenv("DMM_LATENT_V2_GROUPS"); return e ? atoi(e) : 0; }();  // (experiments: fewer groups per launch)
+    const int per = per_env > 0 ? std::min(per_env & ~7, (2 * cus / nt) & ~7) : std::min(256, (2 * cus / nt) & ~7);  // groups per launch: every member workgroup resident, two to a CU
+    static const int phase = [] { const char* e = getenv("DMM_LATENT_PHASE"); return e ? atoi(e) : 900; }();  // x 10 ns
+    LatentBatch b = base;
+    b.rbs = (base.rows + 127) / 128;
+    b.first_wave = cus / 8;
+    b.phase_ticks = phase;
+    b.contig = contig;
+    const int total = n_mod * b.rbs;
+    for (int g0 = 0; g0 < total; g0 += per) {
+      b.g0 = g0;
+      b.n_groups = std::min(per, total - g0);
+      hipError_t e = hipMemsetAsync(b.flags, 0, sizeof(int) * 512, s);
+      if (e != hipSuccess) return (int)e;
+      const dim3 grid(8 * nt * ((b.n_groups + 7) / 8));
+      if (wt) hipLaunchKernelGGL(latent_chain_v2_kernel<true>, grid, dim3(256), V2_LDS, s, b);
+      else hipLaunchKernelGGL(latent_chain_v2_kernel<false>, grid, dim3(256), V2_LDS, s, b);
+    }
+    return 0;
+  }
   const int per = (cus / nt) & ~7;  // groups per launch: every member workgroup gets a CU of its own
   const int total = n_mod * base.rbs;
   for (int g0 = 0; g0 < total; g0 += per) {
     LatentBatch b = base;
     b.g0 = g0;
     b.n_groups = std::min(per, total - g0);
+    b.contig = contig;
     hipError_t e = hipMemsetAsync(b.flags, 0, sizeof(int) * 512, s);
     if (e != hipSuccess) return (int)e;
-    if (wt) hipLaunchKernelGGL(latent_chain_8ph_kernel<true>, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
-    else hipLaunchKernelGGL(latent_chain_8ph_kernel<false>, dim3(8 * nt * ((b.n_groups + 7) / 8)), dim3(512), P8_LDS, s, b);
+    const dim3 grid(8 * nt * ((b.n_groups + 7) / 8));
+    if (wt && early) hipLaunchKernelGGL((latent_chain_8ph_kernel<true, true>), grid, dim3(512), P8_LDS, s, b);
+    else if (wt) hipLaunchKernelGGL((latent_chain_8ph_kernel<true, false>), grid, dim3(512), P8_LDS, s, b);
+    else if (early) hipLaunchKernelGGL((latent_chain_8ph_kernel<false, true>), grid, dim3(512), P8_LDS, s, b);
+    else hipLaunchKernelGGL((latent_chain_8ph_kernel<false, false>), grid, dim3(512), P8_LDS, s, b);
   }
   return 0;
 }

@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256) void spmm_epilogue_rows_kernel(const SpmmBatch
   }
 }
 
+template <int D>
+__device__ __forceinline__ void spmm_fix_row(const dmm_spmm_problem& P, int fi, float4* part);
+
 // VEC 4 = fp32 operands, VEC 8 = bf16 operands; DEPTH = X-row gathers in flight per lane; MINW = waves per SIMD the register
 // allocation must leave room for (the kernel is bound by the number of tasks in flight: tools/spmm_scale.py)
 template <int D, int VEC, int DEPTH, int MINW>
@@ -238,30 +241,62 @@ __global__ __launch_bounds__(256, MINW) void spmm_kernel(const SpmmBatch batch) 
 #pragma unroll
   for (int j = 0; j < VEC; ++j) part[j * 256 + threadIdx.x] = acc.v[j];
   __syncthreads();
-  if (row < 0 || run_pos != 0) return;
-  for (int t = 1; t < run_len; ++t) {
+  const bool run_head = row >= 0 && run_pos == 0;
+  if (run_head) {
+    for (int t = 1; t < run_len; ++t) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc.v[j] += part[j * 256 + (g + t) * LANES + l];
+      for (int j = 0; j < VEC; ++j) acc.v[j] += part[j * 256 + (g + t) * LANES + l];
+    }
   }
-
-  if (lb < P.n_partial_blocks) {  // segment of a giant row: park the raw partial row; spmm_fixup_kernel sums the segments in order
-    store_f32<VEC>(P.partial + (size_t)lb * D + VEC * l, acc);
+  if (lb >= P.n_partial_blocks) {  // (uniform over the workgroup)
+    if (run_head) spmm_finish<D, VEC>(P, row, l, acc);
     return;
   }
-  spmm_finish<D, VEC>(P, row, l, acc);
+  // ---- segment of a giant row: park the raw partial row; the segments are summed in order by spmm_fixup_kernel (a second launch) or, with
+  // fix_count, by whichever segment workgroup of the row arrives last (no second launch; the same order and grouping: bit-identical)
+  if (run_head) store_f32<VEC>(P.partial + (size_t)lb * D + VEC * l, acc);
+  if (!P.fix_count) return;
+  __shared__ int s_fix;  // index of the giant row when this workgroup's arrival was the last one, else -1
+  // publish (MI355X_MICROARCH.md, inter-workgroup visibility, R1): every storing wave drains its stores, workgroup barrier, ONE lane: agent release
+  // (L2 write-back) -> wait -> agent-scope add; the last arriver: agent acquire -> wait -> (barrier) -> plain loads
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // (also: every read of `part` above is done before spmm_fix_row reuses it)
+  if (threadIdx.x == 0) {
+    const int4* fix = reinterpret_cast<const int4*>(P.fix);
+    int lo = 0, hi = P.n_fix - 1;  // the giant row whose slots [first_slot, first_slot + n_slots) hold lb (rows are listed by first_slot)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (fix[mid].y <= lb) lo = mid; else hi = mid - 1;
+    }
+    const int n_slots = fix[lo].z;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: the add must not overtake the write-back)
+    const int old = __hip_atomic_fetch_add(P.fix_count + lo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int mine = -1;
+    if (old == n_slots - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(P.fix_count + lo, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+      mine = lo;
+    }
+    s_fix = mine;
+  }
+  __syncthreads();
+  const int fi = s_fix;
+  if (fi < 0) return;
+  spmm_fix_row<D>(P, fi, reinterpret_cast<float4*>(part));
 }
 
 // Rows longer than one workgroup's worth of tasks are cut into segments (one workgroup each, planned first in the task list).
-// This pass adds a row's segment partials and applies the epilogue: one WORKGROUP per giant row -- group g sums the segments
-// g, g + G, g + 2G, ... and the G partial rows are then added in group order through LDS (a fixed order: deterministic).
+// spmm_fix_row adds a row's segment partials and applies the epilogue: one WORKGROUP per giant row -- group g sums the segments
+// g, g + G, g + 2G, ... and the G partial rows are then added in group order through LDS (a fixed order: deterministic).  It is run by
+// the last-arriving segment workgroup of the main launch (dmm_spmm_problem.fix_count) or by spmm_fixup_kernel, a second launch.
+// part = 256 float4 of LDS; all 256 threads of the workgroup must call it.
 template <int D>
-__global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) {
+__device__ __forceinline__ void spmm_fix_row(const dmm_spmm_problem& P, int fi, float4* part) {
   constexpr int LANES = D / 4, G = 256 / LANES;
-  __shared__ float4 part[256];
-  const dmm_spmm_problem& P = batch.p[blockIdx.y];
-  if ((int)blockIdx.x >= P.n_fix) return;
   const int g = threadIdx.x / LANES, l = threadIdx.x % LANES;
-  const int4 f = reinterpret_cast<const int4*>(P.fix)[blockIdx.x];  // {row, first_slot, n_slots, -}
+  const int4 f = reinterpret_cast<const int4*>(P.fix)[fi];  // {row, first_slot, n_slots, -}
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int sidx = g; sidx < f.z; sidx += G) {
     const float4 o = *reinterpret_cast<const float4*>(P.partial + (size_t)(f.y + sidx) * D + 4 * l);
@@ -279,6 +314,14 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) 
   spmm_finish<D, 4>(P, f.x, l, acc);
 }
 
+template <int D>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) {
+  __shared__ float4 part[256];
+  const dmm_spmm_problem& P = batch.p[blockIdx.y];
+  if ((int)blockIdx.x >= P.n_fix || P.fix_count) return;  // (fix_count: the main launch finished this problem's giant rows itself)
+  spmm_fix_row<D>(P, blockIdx.x, part);
+}
+
 template <int D, int VEC>
 static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
   // Measured at 1M users x 500k items, d = 64 (profiles/README.md): fp32 operands are bound by the bytes that miss L2 (450-465 us in
@@ -288,8 +331,9 @@ static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
   const bool deep = variant == 0 ? VEC == 4 : variant == 2;
   if (deep) hipLaunchKernelGGL((spmm_kernel<D, VEC, 8, 4>), dim3(blocks), dim3(256), 0, s, b);
   else hipLaunchKernelGGL((spmm_kernel<D, VEC, 4, 8>), dim3(blocks), dim3(256), 0, s, b);
-  int max_fix = 0;
-  for (int i = 0; i < b.n; ++i) max_fix = max_fix > b.p[i].n_fix ? max_fix : b.p[i].n_fix;
+  int max_fix = 0;  // giant rows the main launch did not finish itself (no fix_count)
+  for (int i = 0; i < b.n; ++i)
+    if (!b.p[i].fix_count) max_fix = max_fix > b.p[i].n_fix ? max_fix : b.p[i].n_fix;
   if (max_fix > 0) hipLaunchKernelGGL(spmm_fixup_kernel<D>, dim3(max_fix, b.n), dim3(256), 0, s, b);
   DMM_LAUNCH_CHECK("dmm_spmm_csr");
   return 0;

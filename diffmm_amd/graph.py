@@ -233,6 +233,16 @@ class Adjacency:
             pool.append(torch.empty((self.n_partial_blocks, self.D), dtype=torch.float32, device=self.col.device))
         return pool[i]
 
+    def fix_counter(self, i: int) -> Optional[torch.Tensor]:
+        """Arrival counters of the giant rows for the i-th concurrent use of this adjacency in one launch (dmm_spmm_problem.fix_count: zero
+        between launches -- the kernel leaves them zero)."""
+        if self.fix is None or not self.n_partial_blocks:
+            return None
+        pool = self.__dict__.setdefault("_fix_count_pool", [])
+        while len(pool) <= i:
+            pool.append(torch.zeros(int(self.fix.shape[0]), dtype=torch.int32, device=self.col.device))
+        return pool[i]
+
     def algorithmic_bytes(self, elem_bytes: int = 4) -> int:
         """Compulsory HBM traffic of one SpMM: indices + values + row pointers + X + Y."""
         return self.nnz * 8 + (self.n + 1) * 4 + 2 * self.n * self.D * elem_bytes

@@ -6,6 +6,7 @@ caller-visible HBM buffers.  No CPU path exists: non-CUDA tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -91,6 +92,9 @@ class SpmmOp:
         self.p, self.D = p, D
 
 
+_SPMM_FOLD = os.environ.get("DMM_SPMM_FOLD", "1") != "0"  # 0: the giant rows' second launch (spmm_fixup_kernel), as before
+
+
 def spmm_batched(ops: Sequence[SpmmOp]):
     if not 1 <= len(ops) <= L.SPMM_MAX_BATCH:
         raise ValueError("1..4 problems per launch")
@@ -101,6 +105,8 @@ def spmm_batched(ops: Sequence[SpmmOp]):
             i = uses.get(id(o.adj), 0)
             uses[id(o.adj)] = i + 1
             o.p.partial = L.ptr(o.adj.partial_buffer(i))
+            if _SPMM_FOLD:  # giant rows finished by the last-arriving segment workgroup of the main launch: no fix-up launch
+                o.p.fix_count = L.ptr(o.adj.fix_counter(i))
     if any(o.adj.vec != ops[0].adj.vec for o in ops):
         raise ValueError("one launch takes fp32-operand or bf16-operand problems, not both")
     arr = (L.SpmmProblem * len(ops))(*[o.p for o in ops])

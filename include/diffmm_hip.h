@@ -82,6 +82,12 @@ typedef struct dmm_spmm_problem {
    * producing launch instead of a separate cast pass */
   void* y16;
   void* y_pert16;
+  /* Giant rows finished inside the main launch (optional; NULL = the second launch described above).  int32 [n_fix], ZERO on entry and zero
+   * again on return: every segment workgroup of a giant row parks its partial row, publishes it (agent-scope release) and adds 1 to the row's
+   * counter; the workgroup whose add comes last (agent-scope acquire) sums the row's segments IN SEGMENT ORDER -- the same order and grouping
+   * as the second launch, so the result is bit-identical to it and reproducible whichever workgroup is last --, applies the epilogue and resets
+   * the counter.  One buffer per concurrent use of an adjacency (like `partial`); a launch aborted mid-way leaves it dirty (re-zero it). */
+  int32_t* fix_count;
 } dmm_spmm_problem;
 
 int dmm_spmm_tasks_per_block(int D);

@@ -133,6 +133,29 @@ def test_spmm_giant_rows(dev, D):
     y3 = torch.empty_like(y)
     ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=y3, alpha=2.0, c1=C1.to(dev), beta=0.5)])
     assert torch.equal(y, y3), "segmented rows stay bitwise reproducible"
+    # the giant rows finished by the last-arriving segment workgroup of the main launch (dmm_spmm_problem.fix_count; the default) against the second
+    # launch (spmm_fixup_kernel): the same order and grouping of the sums -> bit-identical, whichever workgroup arrives last, every time
+    assert ops._SPMM_FOLD and adj.fix_counter(0) is not None
+    ops._SPMM_FOLD = False
+    try:
+        y4, y5, yp5 = (torch.empty_like(y) for _ in range(3))
+        ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=y4, alpha=2.0, c1=C1.to(dev), beta=0.5),
+                          ops.SpmmOp(adj, C1.to(dev), y=y5, y_pert=yp5, noise=noise.to(dev), noise_degree=1.5)])
+    finally:
+        ops._SPMM_FOLD = True
+    assert torch.equal(y4, y) and torch.equal(y5, y2) and torch.equal(yp5, yp), "folded fix-up == second-launch fix-up, bit for bit"
+    side = torch.cuda.Stream()
+    junk = torch.randn(32 << 20, device=dev)
+    for it in range(40):  # under uneven background load (the hand-off between the segment workgroups must hold whoever arrives last)
+        if it % 2:
+            with torch.cuda.stream(side):
+                junk[: (1 + it % 5) << 22].mul_(1.0001)
+        ya, yb, ypb = (torch.empty_like(y) for _ in range(3))
+        ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=ya, alpha=2.0, c1=C1.to(dev), beta=0.5),
+                          ops.SpmmOp(adj, C1.to(dev), y=yb, y_pert=ypb, noise=noise.to(dev), noise_degree=1.5)])
+        assert torch.equal(ya, y) and torch.equal(yb, y2) and torch.equal(ypb, yp), f"run {it}"
+    torch.cuda.synchronize()
+    assert int(adj.fix_counter(0).abs().sum()) == 0 and int(adj.fix_counter(1).abs().sum()) == 0, "the arrival counters are zero again after every launch"
 
 
 @pytest.mark.parametrize("name,D,hub", [("toy", 16, False), ("mid", 32, False), ("mid", 64, False), ("mid", 128, False), ("mid", 256, False), ("tiktok", 64, False),
