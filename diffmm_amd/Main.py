@@ -251,6 +251,7 @@ class Coach:
         dl = [0.0] * M
         step_means = []
         diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
+        DE.begin_phase()  # feats / i_embs are constant until end_phase(): what the steps derive from them alone is made once
         for idx in diff_batches:
             own = idx if (lay is None or ish is not None) else idx[(idx >= lay.u0) & (idx < lay.u1)]  # (item split: all rows, own item slice)
             x0 = dd.csr_rows(own)  # x_0 stays CSR: the engine densifies it straight into its operand buffer
@@ -263,6 +264,7 @@ class Coach:
             means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]),
                                   host_means=prec != 1)
             step_means.append(means)
+        DE.end_phase()
         if step_means and isinstance(step_means[0], torch.Tensor):  # bf16 mode: the steps left their means on the device -- one read for the whole phase
             step_means = torch.stack(step_means).tolist()
         for means in step_means:  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total

@@ -47,6 +47,11 @@ class LatentChainArgs(C.Structure):
                 ("ldh", C.c_int64), ("bias_t", C.c_void_p), ("ldbt", C.c_int64)]
 
 
+class TanhBwdFusedArgs(C.Structure):
+    _fields_ = [("dh", C.c_void_p), ("ld_dh", C.c_int64), ("h", C.c_void_p), ("ld_h", C.c_int64), ("d16", C.c_void_p), ("ld16", C.c_int64),
+                ("dT16", C.c_void_p), ("ldT", C.c_int64), ("csum", C.c_void_p)]
+
+
 class ProjectProblem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("F", C.c_void_p), ("ldf", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64), ("bias", C.c_void_p),
                 ("rows", C.c_int32), ("K", C.c_int32)]
@@ -134,6 +139,7 @@ _SIGS = {
     "dmm_mul_sigmoid_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "dmm_gate_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "dmm_tanh_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
+    "dmm_tanh_bwd_fused": (C.c_int, [_P, _I, _I, _I, _I, _P]),
     "dmm_add_inplace": (C.c_int, [_P, _P, _F, _L, _P]),
     "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dmm_colsum_add": (C.c_int, [_P, _L, _I, _I, _P, _P]),

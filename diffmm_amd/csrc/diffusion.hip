@@ -210,28 +210,40 @@ __global__ __launch_bounds__(256) void noised_start_kernel(const float* __restri
   }
 }
 
-// d w_emb[c][k] += sum_b dtemb[b][c] * e_b[k],  d b_emb[c] += sum_b dtemb[b][c]   (te <= 32; one workgroup per TEMB_ROWS batch rows,
-// thread = one (c, k) pair, partial sums added with fp32 atomics).  The loop over the rows is a chain of strided loads + sin / cos:
-// 64 rows per workgroup took 42 us at B = 4096 (64 workgroups, latency-bound); 8 rows per workgroup fills the chip instead.
-constexpr int TEMB_ROWS = 8;
+// d w_emb[c][k] += sum_b dtemb[b][c] * e_b[k],  d b_emb[c] += sum_b dtemb[b][c]   (te <= 32).  A workgroup takes TEMB_WG_ROWS batch rows:
+// thread = (row lane r, pair (c, k)) with R = 1024 / te^2 row lanes (10 at te = 10: every thread works, where one (c, k) pair per thread left 9 in 10
+// idle), each walking the rows r, r + R, ...; the row lanes' partial sums are combined through LDS and ONE fp32 atomic per pair and workgroup goes
+// out.  (Round-2 form: 8 rows per workgroup, 512 workgroups at B = 4096, every pair's partial added by atomics -- 56k atomics on 110 addresses:
+// 25 us per modality, all contention.  Now 52 workgroups, 5.7k atomics.)
+constexpr int TEMB_WG_ROWS = 80;
 __global__ __launch_bounds__(1024) void temb_bwd_kernel(const int32_t* __restrict__ t, const float* __restrict__ dxcat, long long ldx, int I,
                                                          int te, int B, float* __restrict__ dw, float* __restrict__ db) {
-  const int c = threadIdx.x / te, k = threadIdx.x % te;
-  if (c >= te) return;
-  const int b0 = blockIdx.x * TEMB_ROWS, b1 = min(B, b0 + TEMB_ROWS);
+  __shared__ double sw[1024], sb[1024];
+  const int pairs = te * te, R = 1024 / pairs;
+  const int r = threadIdx.x / pairs, pk = threadIdx.x % pairs;
+  const int c = pk / te, k = pk % te;
+  const int b0 = blockIdx.x * TEMB_WG_ROWS, b1 = min(B, b0 + TEMB_WG_ROWS);
   double aw = 0.0, ab = 0.0;
-  const int half = te / 2;
-  const bool is_pad = (te & 1) && k == te - 1;
-  const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
-  for (int b = b0; b < b1; ++b) {
-    const float ang = (float)t[b] * f;
-    const float ek = is_pad ? 0.f : (k < half ? cosf(ang) : sinf(ang));
-    const float g = dxcat[(long long)b * ldx + I + c];
-    aw += (double)g * (double)ek;
-    ab += (double)g;
+  if (r < R) {
+    const int half = te / 2;
+    const bool is_pad = (te & 1) && k == te - 1;
+    const float f = expf((-9.210340371976184f * (float)(k < half ? k : k - half)) / (float)half);
+    for (int b = b0 + r; b < b1; b += R) {
+      const float ang = (float)t[b] * f;
+      const float ek = is_pad ? 0.f : (k < half ? cosf(ang) : sinf(ang));
+      const float g = dxcat[(long long)b * ldx + I + c];
+      aw += (double)g * (double)ek;
+      ab += (double)g;
+    }
   }
-  atomicAdd(dw + c * te + k, (float)aw);
-  if (k == 0) atomicAdd(db + c, (float)ab);
+  sw[threadIdx.x] = aw;
+  sb[threadIdx.x] = ab;
+  __syncthreads();
+  if (r == 0) {  // the row lanes in order: a fixed summation order inside the workgroup
+    for (int j = 1; j < R; ++j) { aw += sw[j * pairs + pk]; ab += sb[j * pairs + pk]; }
+    atomicAdd(dw + c * te + k, (float)aw);
+    if (k == 0) atomicAdd(db + c, (float)ab);
+  }
 }
 
 // diffusion loss: one workgroup per batch row
@@ -1090,7 +1102,7 @@ extern "C" int dmm_noised_start(const float* x0, int64_t ldx0, const float* rand
 
 extern "C" int dmm_temb_bwd(const int32_t* t, const float* dxcat, int64_t ldx, int I, int te, int B, float* dw_emb, float* db_emb, void* stream) {
   DMM_CHECK_ARG(t && dxcat && dw_emb && db_emb && te >= 2 && te <= MAX_TE && B > 0, "dmm_temb_bwd: bad arguments");
-  hipLaunchKernelGGL(temb_bwd_kernel, dim3(cdiv(B, TEMB_ROWS)), dim3(1024), 0, (hipStream_t)stream, t, dxcat, (long long)ldx, I, te, B, dw_emb, db_emb);
+  hipLaunchKernelGGL(temb_bwd_kernel, dim3(cdiv(B, TEMB_WG_ROWS)), dim3(1024), 0, (hipStream_t)stream, t, dxcat, (long long)ldx, I, te, B, dw_emb, db_emb);
   DMM_LAUNCH_CHECK("dmm_temb_bwd");
   return 0;
 }

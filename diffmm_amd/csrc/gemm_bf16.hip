@@ -310,6 +310,43 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* _
   }
 }
 
+// dpre = dh * (1 - h^2) as the layer-1 weight-gradient GEMMs' operands (dmm_tanh_bwd_fused): a 64 x 64 tile per workgroup, blockIdx.z = problem.
+struct TanhBwdBatch {
+  dmm_tanh_bwd_fused_args p[4];
+  int R, C, Rp;
+};
+__global__ __launch_bounds__(256) void tanh_bwd_fused_kernel(const TanhBwdBatch b) {
+  __shared__ float tile[64][65];
+  __shared__ float cs[4][64];
+  const dmm_tanh_bwd_fused_args& P = b.p[blockIdx.z];
+  const int R = b.R, C = b.C, Rp = b.Rp;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  __bf16* const d16 = reinterpret_cast<__bf16*>(P.d16);
+  __bf16* const dT = reinterpret_cast<__bf16*>(P.dT16);
+  float colpart = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      const float t = P.h[(long long)r * P.ld_h + c];
+      v = P.dh[(long long)r * P.ld_dh + c] * (1.0f - t * t);
+      d16[(long long)r * P.ld16 + c] = (__bf16)v;
+    }
+    tile[ty + 4 * i][tx] = v;
+    colpart += v;
+  }
+  cs[ty][tx] = colpart;
+  __syncthreads();
+  if (ty == 0 && c0 + tx < C && r0 < R) atomicAdd(P.csum + c0 + tx, (cs[0][tx] + cs[1][tx]) + (cs[2][tx] + cs[3][tx]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < C && r < Rp) dT[(long long)c * P.ldT + r] = (__bf16)tile[tx][ty + 4 * i];
+  }
+}
+
 // time embedding of a single timestep (every row of the reverse chain shares it) -> bf16 columns I.. of xb, zero padded to ldx
 __global__ __launch_bounds__(256) void temb_bias_table_kernel(const float* __restrict__ w_emb, const float* __restrict__ b_emb, int te,
                                                                const float* __restrict__ w1, long long ldw1, int I, const float* __restrict__ b1,
@@ -456,6 +493,21 @@ extern "C" int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst,
   hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3(cdiv(cols, 64), cdiv(rows_pad, 64)), dim3(256), 0, (hipStream_t)stream, src, (long long)lds,
                      (__bf16*)dst, (long long)ldd, rows, cols, rows_pad, (__bf16*)nullptr);
   DMM_LAUNCH_CHECK("dmm_transpose_cast_bf16");
+  return 0;
+}
+
+extern "C" int dmm_tanh_bwd_fused(const dmm_tanh_bwd_fused_args* a, int n, int rows, int cols, int rows_pad, void* stream) {
+  DMM_CHECK_ARG(a && n >= 1 && n <= 4 && rows > 0 && cols > 0 && rows_pad >= rows && rows_pad % 8 == 0, "dmm_tanh_bwd_fused: bad arguments");
+  dmm::TanhBwdBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < n; ++i) {
+    DMM_CHECK_ARG(a[i].dh && a[i].h && a[i].d16 && a[i].dT16 && a[i].csum && a[i].ld_dh >= cols && a[i].ld_h >= cols && a[i].ld16 >= cols && a[i].ldT >= rows_pad,
+                  "dmm_tanh_bwd_fused: null operand or short leading dimension (problem %d)", i);
+    b.p[i] = a[i];
+  }
+  b.R = rows; b.C = cols; b.Rp = rows_pad;
+  hipLaunchKernelGGL(dmm::tanh_bwd_fused_kernel, dim3(dmm::cdiv(cols, 64), dmm::cdiv(rows_pad, 64), n), dim3(256), 0, (hipStream_t)stream, b);
+  DMM_LAUNCH_CHECK("dmm_tanh_bwd_fused");
   return 0;
 }
 

@@ -666,7 +666,11 @@ class DiffusionEngine:
         self._lat = None  # buffers / operands of the latent chain (generate_views_latent), allocated on first use
         self._x0_rows, self._ie16 = None, None  # the current training batch as CSR rows (if it came as such); bf16 i_embs for its gather
         self._FT16 = None  # F^T operands of the folded products (_folded_prepare)
-        self._feat16 = None  # bf16 copies of the modality features for the fused expand kernels (made per training step)
+        self._feat16 = None  # bf16 copies of the modality features for the fused expand kernels (made per training step, or once per phase)
+        # Main.Coach brackets the diffusion phase with begin_phase() / end_phase(): the projected features and i_embs do not move inside it (only the
+        # Denoise optimisers step there, Main.py:145-192), so what a step derives from them alone -- the bf16 feature copies, F^T, bf16 i_embs and
+        # x_0 @ i_embs of every user -- is made by the first step of the phase and reused (`_phase`: None outside a phase = made per step, as before)
+        self._phase: Optional[dict] = None
         self._x0_bits, self._bits_buf = None, None  # the current batch's x_0 rows as bit masks (batched bf16 step fed with CSR rows)
         self._xT_calls = 0  # Philox stream position of the noised chain starts (checkpointed)
         Bp8 = (B_max + 63) & ~63  # K of the weight-gradient GEMMs: whole 64-wide tiles
@@ -801,6 +805,22 @@ class DiffusionEngine:
         d[x'|temb] = dpre W1: d(proj*gate) = (dpre W1x) F = dpre (W1x F), d temb = dpre W1e.  Forward: model_output @ F = h (F^T W2)^T + b2 F.
         hp folded_products / DMM_FOLDED_PRODUCTS=0: the [B, Kp] GEMM and the passes over [B, I]."""
         return self._item_kernels(1) and self.D % 8 == 0 and bool(self.hp.get("folded_products", os.environ.get("DMM_FOLDED_PRODUCTS", "1") != "0"))
+
+    def begin_phase(self) -> None:
+        """Start of a diffusion-training phase (Main.Coach.trainEpoch): see `_phase`."""
+        self._phase = {}
+
+    def end_phase(self) -> None:
+        self._phase = None
+
+    def _phase_has(self, key) -> bool:
+        """True when `key` was already made in this phase; marks it made otherwise (always False outside a phase: made per step)."""
+        if self._phase is None:
+            return False
+        if key in self._phase:
+            return True
+        self._phase[key] = True
+        return False
 
     def _folded_prepare(self):
         """Buffers of the folded products, on first use."""
@@ -938,7 +958,8 @@ class DiffusionEngine:
             if self._fused_expand():  # x_t += (proj * gate) F^T written only as layer 1's bf16 operand and its transposed copy (the backward's)
                 if self._feat16 is None:  # bf16 copies of the modality features: what the expand kernels stage (both directions of this step)
                     self._feat16 = [torch.zeros(I, self.D, dtype=torch.bfloat16, device=self.dev) for _ in range(M)]
-                ops.cast_bf16(feats[m], self._feat16[m])
+                if not self._phase_has(("feat16", m)):
+                    ops.cast_bf16(feats[m], self._feat16[m])
                 ops.item_expand_fused(a["pg"][:B], feats[m], a["xcat"][:B], W[m]["xa16"][:B], W[m]["xcatT16"], I, self.Kp, self.Kp, F16=self._feat16[m])
             elif self._item_kernels(1):
                 ops.item_expand(a["pg"][:B], feats[m], a["xcat"][:B], a["xcat"][:B], I)  # x_t += (proj * gate) F^T
@@ -967,7 +988,8 @@ class DiffusionEngine:
             ops.zero_(self._G2f)
             for m in range(M):
                 ops.transpose_cast_bf16(self.P[m].view(self.L2 + ".weight"), W[m]["w2T16"], rows=I, cols=self.H)  # W2^T [H, I -> Kp]
-                self._FT32[m][:, :I].copy_(feats[m].t())
+                if not self._phase_has(("FT32", m)):
+                    self._FT32[m][:, :I].copy_(feats[m].t())
                 ops.gemv_rows(self._FT32[m], self.P[m].view(self.L2 + ".bias"), self._b2F[m], cols=I)
             if self.D <= 128:
                 ops.item_project_batched_x16([dict(X=W[m]["w2T16"], F=feats[m], out=self._G2f[m], K=I) for m in range(M)], self.D)
@@ -992,8 +1014,19 @@ class DiffusionEngine:
                         self._ie16 = torch.zeros(i_embs.shape[0], self.D, dtype=torch.bfloat16, device=self.dev)  # (all items, also when the Denoise is item-sharded)
                         self._zero_d = torch.zeros(self.D, dtype=torch.float32, device=self.dev)
                         self._ui16 = torch.zeros(self.B_max, self.D, dtype=torch.bfloat16, device=self.dev)
-                    ops.cast_bf16(i_embs, self._ie16)
-                    ops.csr_gather_sum_latent(rows.ptr, rows.col, rows.users, self._ie16, self._zero_d, self.ui[:B], self._ui16[:B])
+                    n_users = int(rows.ptr.shape[0]) - 1
+                    if self._phase is not None and n_users * self.D * 4 <= (64 << 20):
+                        # inside a phase: x_0 @ i_embs of EVERY user once (one gather over the whole CSR), a row gather per step
+                        if not self._phase_has("ui_all"):
+                            ops.cast_bf16(i_embs, self._ie16)
+                            ui_all = torch.empty(n_users, self.D, dtype=torch.float32, device=self.dev)
+                            ops.csr_gather_sum_latent(rows.ptr, rows.col, torch.arange(n_users, device=self.dev), self._ie16, self._zero_d, ui_all,
+                                                      torch.empty(n_users, self.D, dtype=torch.bfloat16, device=self.dev))
+                            self._phase["ui_all_t"] = ui_all
+                        torch.index_select(self._phase["ui_all_t"], 0, rows.users, out=self.ui[:B])
+                    else:
+                        ops.cast_bf16(i_embs, self._ie16)
+                        ops.csr_gather_sum_latent(rows.ptr, rows.col, rows.users, self._ie16, self._zero_d, self.ui[:B], self._ui16[:B])
                 else:
                     self._project_items(x0p, i_embs, self.ui[:B], 1)
             a["w"] = self.w_table.index_select(0, a["t"][:B])
@@ -1043,7 +1076,11 @@ class DiffusionEngine:
         if sh is not None:  # dh = sum over the item slices of dout[:, I_g] W2[I_g, :]
             for m in range(M):
                 sh.all_reduce(W[m]["dh"][:B])
-        for m in range(M):
+        fused_tanh = not self.mids and self._fused_expand() and self._folded_products() and os.environ.get("DMM_TANH_FUSED", "1") != "0"
+        if fused_tanh:  # dpre only ever feeds the GEMMs below: written as their bf16 operands (+ the bias gradient) by one launch for all modalities
+            ops.tanh_bwd_fused([dict(dh=W[m]["dh"][:B], h=self.act[m]["h"][:B], d16=W[m]["dpre16"][:B], dT16=W[m]["dpreT16"], csum=self.P[m].g("in_layers.0.bias"))
+                                for m in range(M)], B, H, Bp)
+        for m in range(M if not fused_tanh else 0):
             a, P, w = self.act[m], self.P[m], W[m]
             dh = self._mids_bwd(m, a["h"][:B], w["dh"][:B], 1) if self.mids else w["dh"][:B]
             ops.tanh_bwd(dh, a["h"][:B], w["dpre"][:B])

@@ -92,7 +92,10 @@ class SpmmOp:
         self.p, self.D = p, D
 
 
-_SPMM_FOLD = os.environ.get("DMM_SPMM_FOLD", "1") != "0"  # 0: the giant rows' second launch (spmm_fixup_kernel), as before
+# DMM_SPMM_FOLD=1: the giant rows are finished by the last-arriving segment workgroup of the main launch (dmm_spmm_problem.fix_count) instead of by the
+# second launch (spmm_fixup_kernel).  Bit-identical, and measured in round 4: SLOWER at TikTok size -- the release / add / acquire of the hand-off sits
+# on the launch's critical path (joint phase 7.92 -> 8.10 ms for the six launches per iteration it saves) -- so the second launch stays the default.
+_SPMM_FOLD = os.environ.get("DMM_SPMM_FOLD", "0") != "0"
 
 
 def spmm_batched(ops: Sequence[SpmmOp]):
@@ -669,6 +672,20 @@ def bias_tanh_rows(x: Tensor, bias: Tensor, out16: Optional[Tensor] = None) -> N
 
 def tanh_bwd(dh: Tensor, h: Tensor, dpre: Tensor) -> None:
     L.call("dmm_tanh_bwd", L.ptr(dh), L.ptr(h), L.ptr(dpre), dh.numel(), L.stream())
+
+
+def tanh_bwd_fused(problems: Sequence[dict], rows: int, cols: int, rows_pad: int) -> None:
+    """dpre = dh * (1 - h^2) of up to 4 problems in one pass: dicts with dh, h (fp32 [rows, cols] row-strided), d16 (bf16 [rows, cols]), dT16 (bf16
+    [cols, >= rows_pad], columns rows..rows_pad zeroed) and csum (fp32 [cols], accumulated into)."""
+    arr = (L.TanhBwdFusedArgs * len(problems))()
+    for a, p in zip(arr, problems):
+        dh, h, d16, dT, cs = p["dh"], p["h"], p["d16"], p["dT16"], p["csum"]
+        if dh.dtype != torch.float32 or h.dtype != torch.float32 or d16.dtype != torch.bfloat16 or dT.dtype != torch.bfloat16 or cs.dtype != torch.float32 or \
+                any(t.stride(1) != 1 for t in (dh, h, d16, dT)) or any(t.shape[0] < rows or t.shape[1] < cols for t in (dh, h, d16)) or dT.shape[0] < cols or \
+                dT.stride(0) < rows_pad or cs.numel() < cols or not cs.is_contiguous() or rows_pad < rows or rows_pad % 8:
+            raise ValueError("tanh_bwd_fused: bad operands")
+        a.dh, a.ld_dh, a.h, a.ld_h, a.d16, a.ld16, a.dT16, a.ldT, a.csum = L.ptr(dh), dh.stride(0), L.ptr(h), h.stride(0), L.ptr(d16), d16.stride(0), L.ptr(dT), dT.stride(0), L.ptr(cs)
+    L.call("dmm_tanh_bwd_fused", arr, len(problems), rows, cols, rows_pad, L.stream())
 
 
 def add_inplace(y: Tensor, x: Tensor, alpha: float = 1.0) -> None:

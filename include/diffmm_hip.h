@@ -370,6 +370,19 @@ int dmm_mul_sigmoid_fwd(const float* proj, const float* gate_pre_sig /*sigmoid a
 int dmm_gate_bwd(const float* dout, const float* proj, const float* gate, float* dproj /*out: dout*gate*/,
                  float* dgate_pre /*out: dout*proj*gate*(1-gate)*/, int64_t n, void* stream);
 int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* stream); /* dpre = dh * (1 - h^2) */
+/* The same product as the operands the layer-1 weight-gradient GEMMs want, in ONE pass over dh and h for up to 4 problems (the modalities of a
+ * diffusion-training step): dpre = dh * (1 - h^2) is written only as bf16 rows d16 [rows, cols], as its bf16 transpose dT16 [cols, rows_pad]
+ * (columns rows..rows_pad zero: the K-contiguous operand of an NT GEMM with K = rows_pad, a multiple of 8) and added, column-summed, to csum [cols]
+ * (fp32 atomics: the bias gradient).  Replaces dmm_tanh_bwd + dmm_transpose_cast_bf16 + dmm_colsum_add + dmm_cast_bf16 (4 launches and an fp32
+ * round trip of dpre per problem); the bf16 values are bit-identical to theirs. */
+typedef struct dmm_tanh_bwd_fused_args {
+  const float* dh; int64_t ld_dh;
+  const float* h; int64_t ld_h;
+  void* d16; int64_t ld16;    /* bf16 [rows, cols] */
+  void* dT16; int64_t ldT;    /* bf16 [cols, >= rows_pad] */
+  float* csum;                /* [cols], accumulated into */
+} dmm_tanh_bwd_fused_args;
+int dmm_tanh_bwd_fused(const dmm_tanh_bwd_fused_args* a /*host*/, int n, int rows, int cols, int rows_pad, void* stream);
 /* x = tanh(x + bias[col]) in place on a contiguous fp32 [rows, cols] (cols % 4 == 0), out16 (optional): its bf16 copy.  Denoise layer 1's activation
  * (Model.py:212) applied AFTER the item-sliced partial products x_t[:, I_g] W1[:, I_g]^T have been summed over the replicas. */
 int dmm_bias_tanh_rows(float* x, const float* bias, int rows, int cols, void* out16 /*bf16 [rows, cols] or NULL*/, void* stream);

@@ -135,25 +135,23 @@ def test_spmm_giant_rows(dev, D):
     assert torch.equal(y, y3), "segmented rows stay bitwise reproducible"
     # the giant rows finished by the last-arriving segment workgroup of the main launch (dmm_spmm_problem.fix_count; the default) against the second
     # launch (spmm_fixup_kernel): the same order and grouping of the sums -> bit-identical, whichever workgroup arrives last, every time
-    assert ops._SPMM_FOLD and adj.fix_counter(0) is not None
-    ops._SPMM_FOLD = False
+    # (the second launch is the default -- the fold measured slower at TikTok size, ops._SPMM_FOLD -- so `y`, `y2`, `yp` above are the second launch's)
+    assert adj.fix_counter(0) is not None
+    fold_was = ops._SPMM_FOLD
+    ops._SPMM_FOLD = True
     try:
-        y4, y5, yp5 = (torch.empty_like(y) for _ in range(3))
-        ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=y4, alpha=2.0, c1=C1.to(dev), beta=0.5),
-                          ops.SpmmOp(adj, C1.to(dev), y=y5, y_pert=yp5, noise=noise.to(dev), noise_degree=1.5)])
+        side = torch.cuda.Stream()
+        junk = torch.randn(32 << 20, device=dev)
+        for it in range(40):  # under uneven background load (the hand-off between the segment workgroups must hold whoever arrives last)
+            if it % 2:
+                with torch.cuda.stream(side):
+                    junk[: (1 + it % 5) << 22].mul_(1.0001)
+            ya, yb, ypb = (torch.empty_like(y) for _ in range(3))
+            ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=ya, alpha=2.0, c1=C1.to(dev), beta=0.5),
+                              ops.SpmmOp(adj, C1.to(dev), y=yb, y_pert=ypb, noise=noise.to(dev), noise_degree=1.5)])
+            assert torch.equal(ya, y) and torch.equal(yb, y2) and torch.equal(ypb, yp), f"run {it}: folded fix-up == second-launch fix-up, bit for bit"
     finally:
-        ops._SPMM_FOLD = True
-    assert torch.equal(y4, y) and torch.equal(y5, y2) and torch.equal(yp5, yp), "folded fix-up == second-launch fix-up, bit for bit"
-    side = torch.cuda.Stream()
-    junk = torch.randn(32 << 20, device=dev)
-    for it in range(40):  # under uneven background load (the hand-off between the segment workgroups must hold whoever arrives last)
-        if it % 2:
-            with torch.cuda.stream(side):
-                junk[: (1 + it % 5) << 22].mul_(1.0001)
-        ya, yb, ypb = (torch.empty_like(y) for _ in range(3))
-        ops.spmm_batched([ops.SpmmOp(adj, X.to(dev), y=ya, alpha=2.0, c1=C1.to(dev), beta=0.5),
-                          ops.SpmmOp(adj, C1.to(dev), y=yb, y_pert=ypb, noise=noise.to(dev), noise_degree=1.5)])
-        assert torch.equal(ya, y) and torch.equal(yb, y2) and torch.equal(ypb, yp), f"run {it}"
+        ops._SPMM_FOLD = fold_was
     torch.cuda.synchronize()
     assert int(adj.fix_counter(0).abs().sum()) == 0 and int(adj.fix_counter(1).abs().sum()) == 0, "the arrival counters are zero again after every launch"
 
@@ -1322,3 +1320,31 @@ def test_bf16_gather_copies_written_by_their_producers(dev):
     zero = [torch.zeros(N, D, device=dev) for _ in range(M)]
     ops.gcn_mix_bwd(dmx, bx, z, zero, extra, w, 0.2)
     assert all(torch.equal(a, b) for a, b in zip(junk, zero)) and all(torch.equal(h, cast(f)) for h, f in zip(dz16, zero))
+
+
+@pytest.mark.parametrize("B,H,M", [(300, 256, 3), (4096, 1024, 2), (65, 64, 1)])
+def test_tanh_bwd_fused_equals_the_four_passes(dev, B, H, M):
+    """dmm_tanh_bwd_fused (dpre = dh (1 - h^2) written only as the weight-gradient GEMMs' bf16 operands + the bias gradient, all modalities in one
+    launch) against dmm_tanh_bwd + dmm_transpose_cast_bf16 + dmm_cast_bf16 + dmm_colsum_add: the bf16 values bit for bit, the column sums to fp32
+    round-off (both are atomic sums)."""
+    from diffmm_amd import ops
+    torch.manual_seed(B + H)
+    Bp = (B + 63) & ~63
+    probs, want = [], []
+    for m in range(M):
+        dh, h = torch.randn(B, H + 8, device=dev)[:, :H], torch.tanh(torch.randn(B, H, device=dev))
+        dpre = torch.empty(B, H, device=dev)
+        ops.tanh_bwd(dh.contiguous(), h, dpre)
+        d16, dT = torch.empty(B, H, device=dev, dtype=torch.bfloat16), torch.full((H, Bp), 7.0, device=dev, dtype=torch.bfloat16)
+        ops.cast_bf16(dpre, d16)
+        ops.transpose_cast_bf16(dpre, dT, rows=B, cols=H, rows_pad=Bp)
+        cs = torch.full((H,), 0.5, device=dev)
+        ops.colsum(dpre, B, H, cs, add=True)
+        want.append((d16, dT, cs))
+        probs.append(dict(dh=dh, h=h, d16=torch.empty(B, H, device=dev, dtype=torch.bfloat16), dT16=torch.full((H, Bp + 8), 7.0, device=dev, dtype=torch.bfloat16),
+                          csum=torch.full((H,), 0.5, device=dev)))
+    ops.tanh_bwd_fused(probs, B, H, Bp)
+    for m in range(M):
+        assert torch.equal(probs[m]["d16"], want[m][0]), "bf16 rows"
+        assert torch.equal(probs[m]["dT16"][:, :Bp], want[m][1]) and float(probs[m]["dT16"][:, Bp:].float().min()) == 7.0, "bf16 transpose, zero pad, nothing beyond rows_pad"
+        close(probs[m]["csum"], want[m][2], rtol=1e-5, atol=1e-4, what="column sums")
