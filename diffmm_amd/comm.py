@@ -39,6 +39,22 @@ def all_gather_into(out: torch.Tensor, t: torch.Tensor, rank: int, group=None) -
     dist.all_gather_into_tensor(out, t, group=group)
 
 
+def reduce_scatter(out: torch.Tensor, inp: torch.Tensor, rank: int, world: int, group=None) -> None:
+    """out [n, ...] <- the rank-th of the `world` equal chunks of the sum of every replica's inp [world * n, ...].  RCCL: one reduce-scatter
+    (7/8 of the buffer out per GPU at world 8, against twice that for an all-reduce); gloo (tests) has no reduce-scatter: all-reduce + slice, the same
+    values.  LOCAL: the own chunk of the own partial."""
+    n = out.shape[0]
+    if group is LOCAL:
+        out.copy_(inp[rank * n:(rank + 1) * n])
+        return
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(out, inp, group=group)
+    else:
+        dist.all_reduce(inp, group=group)
+        out.copy_(inp[rank * n:(rank + 1) * n])
+
+
 def broadcast(t: torch.Tensor, src: int = 0, group=None) -> None:
     """t <- replica `src`'s t (LOCAL: nothing to do)."""
     if group is LOCAL:

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void rows_move_kernel(SlotTable S, int B, cons
   const int32_t* __restrict__ idx = S.idx[s];
   for (int b = b0 + blockIdx.x * G + threadIdx.x / LANES; b < b1; b += gridDim.x * G) {
     float* t = buf + ((size_t)s * B + b) * D + 4 * l;
+    if (idx[b] < 0) continue;  // a masked entry (item-sharded replicas: a row another replica owns): its table row is left as it is
     if (SCATTER) {  // columns l + j LANES per lane: contiguous atomic segments (scatter_normalize_bwd_kernel)
       float* dst = S.grad[s] + (size_t)idx[b] * D + l;
       const float* ts = buf + ((size_t)s * B + b) * D + l;

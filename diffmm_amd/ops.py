@@ -57,13 +57,16 @@ class SpmmOp:
         for nm, t in (("x_lo", x_lo), ("x_hi", x_hi)):
             if t is not None and (t.dtype != xdt or not t.is_contiguous()):
                 raise ValueError(f"SpMM {nm}: this adjacency is planned for contiguous {xdt} operands, got {t.dtype}")
+        # (with `raw`, rows >= raw_from are parked there and never touch the outputs / epilogue operands: those may end after raw_from rows --
+        # an item-sharded replica's tensors hold [own users ; own item slice], the adjacency's rows are [own users ; all items])
+        rows_ok = (lambda r: r == n) if raw is None else (lambda r: r >= raw_from)
         for nm, t in (("y", y), ("c1", c1), ("c2", c2), ("y_pert", y_pert), ("noise", noise), ("y_mean", y_mean), ("m1", m1), ("m2", m2)):
             if t is not None:
                 _f32c(t, nm)
-                if tuple(t.shape) != (n, D):
+                if t.dim() != 2 or t.shape[1] != D or not rows_ok(t.shape[0]):
                     raise ValueError(f"SpMM {nm} must be [{n}, {D}], got {tuple(t.shape)}")
         for nm, t in (("y16", y16), ("y_pert16", y_pert16)):
-            if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (n, D)):
+            if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != D or not rows_ok(t.shape[0])):
                 raise ValueError(f"SpMM {nm} must be a contiguous bfloat16 [{n}, {D}] tensor")
         self.keep = (adj, x_lo, x_hi, y, c1, c2, y_pert, noise, y_mean, m1, m2, y16, y_pert16)
         p = L.SpmmProblem()

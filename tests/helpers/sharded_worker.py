@@ -28,10 +28,16 @@ def problem(fx: str, cl_method: int):
     return z, U, I, M, D, users, pos, neg, noise, hp
 
 
-def build_sharded(z, U, I, M, D, hp, dev, rank, world, group=None, B_max=256, vec=None):
+def build_sharded(z, U, I, M, D, hp, dev, rank, world, group=None, B_max=256, vec=None, two_d=None):
+    """two_d (or DMM_TEST_JOINT_SHARD=2d): the engine that shards the items as well (diffmm_amd/sharded2d.py)."""
     from diffmm_amd import sharded
     lay = sharded.ShardLayout.make(z["trn_rows"], U, I, world, rank)
-    E = sharded.ShardedJointEngine(lay, D, [torch.from_numpy(z[f"feat{m}"]) for m in range(M)], hp, dev, B_max, group=group)
+    two_d = os.environ.get("DMM_TEST_JOINT_SHARD", "1d") == "2d" if two_d is None else two_d
+    if two_d:
+        from diffmm_amd.sharded2d import Sharded2DJointEngine as Engine
+    else:
+        Engine = sharded.ShardedJointEngine
+    E = Engine(lay, D, [torch.from_numpy(z[f"feat{m}"]) for m in range(M)], hp, dev, B_max, group=group)
     E.load_reference_state({k[2:]: z[k] for k in z.files if k.startswith("p/")})
     vec = int(os.environ.get("DMM_TEST_SPMM_VEC", "4")) if vec is None else vec  # 8: local blocks planned for bf16 gather operands
     adj = sharded.make_sharded_adjacency(lay, z["trn_rows"], z["trn_cols"], D, dev, vec=vec)
@@ -44,7 +50,7 @@ def run_steps(E, lay, users, pos, neg, noise, dev, precision=3):
     """-> dict of numpy arrays: loss parts + gradients of one step (no update), then parameters after two optimiser steps (the second
     one with in-kernel Philox noise through the recorded launch plan)."""
     t = lambda a: torch.from_numpy(a).to(dev)
-    loc = [lay.local_rows(t(n)) for n in noise]
+    loc = [(E.local_rows if hasattr(E, "local_rows") else lay.local_rows)(t(n)) for n in noise]
     E.step(t(users), t(pos), t(neg), noise=loc, precision=precision, update=False)
     out = {"loss/" + k: np.float64(v) for k, v in E.losses().items()}
     for k, v in E.full_grads().items():
@@ -69,6 +75,7 @@ def main():
     lay, E = build_sharded(z, U, I, M, D, hp, dev, rank, world)
     out = run_steps(E, lay, users, pos, neg, noise, dev)
     out["u0"], out["u1"] = np.int64(lay.u0), np.int64(lay.u1)
+    out["i0"], out["i1"] = np.int64(getattr(E, "i0", 0)), np.int64(getattr(E, "i1", I))
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()

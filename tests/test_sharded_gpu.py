@@ -46,7 +46,7 @@ def _single(fx, cl_method, dev, vec=4):
     return out, U
 
 
-def _compare(ref, got, u0, u1, what, vec=4):
+def _compare(ref, got, u0, u1, what, vec=4, i0=None, i1=None):
     # vec = 8 (bf16 gather operands on both sides): the engines' fp32 results differ in the last bits (summation order), which now and then moves
     # the bf16 rounding of an operand element by one ulp (2^-9): losses 1e-4, gradients 2e-3 of their scale, a larger share of Adam-step outliers
     tl, tg, frac = (1e-5, 1e-5, 0.01) if vec == 4 else (1e-4, 2e-3, 0.08)
@@ -54,7 +54,7 @@ def _compare(ref, got, u0, u1, what, vec=4):
         a, b = float(got["loss/" + k]), float(ref["loss/" + k])
         assert abs(a - b) <= tl * max(1.0, abs(b)), f"{what}: {k} {a} vs {b}"
     for k in [k for k in ref if k.startswith("grad/") or k.startswith("param/")]:
-        r = ref[k][u0:u1] if k.endswith("/u_embs") else ref[k]
+        r = ref[k][u0:u1] if k.endswith("/u_embs") else (ref[k][i0:i1] if (k.endswith("/i_embs") and i0 is not None) else ref[k])
         g = got[k]
         assert g.shape == r.shape, f"{what}: {k} shape {g.shape} vs {r.shape}"
         scale = float(np.abs(ref[k]).max()) + 1e-30
@@ -104,3 +104,43 @@ def test_replicas_over_gloo_equal_joint_engine(fx, cl_method, world, vec):
             assert np.array_equal(outs[0][k], outs[r][k]), f"replicated parameter {k} differs between replica 0 and {r}"
     for r in range(1, world):
         assert np.array_equal(outs[0]["loss3"][:-2], outs[r]["loss3"][:-2]) or np.allclose(outs[0]["loss3"][:-2], outs[r]["loss3"][:-2], rtol=1e-6)
+
+
+# ---- users AND items sharded (diffmm_amd/sharded2d.py): reduce-scatter of the item partials, epilogue on the own slice, all-gather of the gather operands ----
+@pytest.mark.parametrize("fx,cl_method,vec", [("gcn_mid_M3", 0, 4), ("gcn_mid_M2", 1, 4), ("gcn_toy_M3", 0, 4), ("gcn_mid_M3", 0, 8)])
+def test_world1_2d_engine_equals_joint_engine(fx, cl_method, vec):
+    need_gpu()
+    dev = torch.device("cuda:0")
+    ref, U = _single(fx, cl_method, dev, vec)
+    z, U, I, M, D, users, pos, neg, noise, hp = W.problem(fx, cl_method)
+    lay, E = W.build_sharded(z, U, I, M, D, hp, dev, 0, 1, vec=vec, two_d=True)
+    got = W.run_steps(E, lay, users, pos, neg, noise, dev)
+    _compare(ref, got, 0, U, f"{fx} 2D world=1 vec={vec}", vec, 0, I)
+
+
+@pytest.mark.parametrize("fx,cl_method,world,vec", [("gcn_mid_M3", 0, 2, 4), ("gcn_mid_M2", 1, 3, 4), ("gcn_mid_M3", 0, 2, 8)])
+def test_2d_replicas_over_gloo_equal_joint_engine(fx, cl_method, world, vec):
+    """Every replica's loss equals the single-GPU loss; its gradients and its parameters after optimiser steps equal the single-GPU engine's
+    restricted to the rows it owns (own users, own item slice) and in full for the replicated projections / modal_weight, within 1e-5 of the
+    gradient scale (fp32 gather operands; the bf16-operand tolerance otherwise); the replicated tensors stay bit-identical across the replicas; the
+    user ranges and the item slices partition the users and the items."""
+    need_gpu()
+    dev = torch.device("cuda:0")
+    ref, U = _single(fx, cl_method, dev, vec)
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_TEST_SPMM_VEC=str(vec), DMM_TEST_JOINT_SHARD="2d")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(29400 + os.getpid() % 250), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), fx, str(cl_method), tmp]
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-4000:]
+        outs = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(world)]
+    cu = ci = 0
+    I = ref["param/i_embs"].shape[0]
+    for r, got in enumerate(outs):
+        u0, u1, i0, i1 = int(got["u0"]), int(got["u1"]), int(got["i0"]), int(got["i1"])
+        cu, ci = cu + u1 - u0, ci + i1 - i0
+        _compare(ref, got, u0, u1, f"{fx} 2D rank {r}/{world}", vec, i0, i1)
+    assert cu == U and ci == I, "the user ranges and the item slices partition the users and the items"
+    for k in [k for k in outs[0] if k.startswith("param/") and not k.endswith("/u_embs") and not k.endswith("/i_embs")]:
+        for r in range(1, world):
+            assert np.array_equal(outs[0][k], outs[r][k]), f"replicated parameter {k} differs between replica 0 and {r}"
