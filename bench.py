@@ -403,7 +403,7 @@ def main():
         # receive all-reduced gradients.  (Coach.check_replicas made the same comparison after every epoch and would have healed / raised.)
         J, DE = coach.model.engine, coach.diff_engine
         nr = DE.n_replicated if coach.item_shard is not None else None
-        flat = torch.cat([J.P.data[J.nu * J.D:]] + [p.data[:nr] for p in DE.P])
+        flat = torch.cat([J.P.data[getattr(J, "replicated_lo", J.nu * J.D):]] + [p.data[:nr] for p in DE.P])
         lo, hi = flat.clone(), flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi)) and getattr(coach, "replica_heals", 0) == 0
@@ -428,7 +428,7 @@ def report(args, coach, h, cfg, world, dt, phases, n_diff, n_joint, replicas_ide
            "data": "synthetic",
            "config": {"workload": f"synthetic {args.workload}-shape graph: U={h.graph.users} I={h.graph.items} E={h.graph.nnz}, M={len(h.graph.feats)} modalities, "
                                   f"d={args.latdim}, T={args.T}, batch={args.batch}; {step_desc}",
-                      "parallelism": f"user-shard{world}" if comm.active(world) else "single", "backend": args.backend if comm.active(world) else None,
+                      "parallelism": (f"user-shard{world}" + ("" if getattr(coach.model.engine, "replicated_items", True) else "+item-shard")) if comm.active(world) else "single", "backend": args.backend if comm.active(world) else None,
                       "denoise_shard": ("items" if coach.item_shard is not None else "rows") if comm.active(world) else None, "embedding_dtype": "f32", "gemm_dtype": "bf16 MFMA, f32 accumulate" if args.precision == 1 else "bf16 hi/lo x3",
                       "phase_ms_per_epoch": {"diffusion": phases[0] / args.steps * 1e3, "rebuild": phases[1] / args.steps * 1e3, "joint": phases[2] / args.steps * 1e3},
                       # the two per-phase rates next to the blended headline (`value`); host-side phase boundaries of rank 0

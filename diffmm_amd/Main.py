@@ -246,8 +246,14 @@ class Coach:
         # ---- phase 1: diffusion training (Main.py:145-192) ----
         J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
         ish = self.item_shard
-        feats = [J.feat[m] if ish is None else J.feat[m][ish.i0:ish.i1] for m in range(M)]
-        reg_term = DE.reg_term(J.i_embs)  # i_embs does not move in this phase either
+        two_d = not getattr(J, "replicated_items", True)  # items sharded as well (sharded2d.py): J holds the features / embeddings of its own item slice
+        if two_d:  # (the slices are engine.ItemShard's: an item-sharded Denoise reads exactly the replica's own rows; the row split reads all items)
+            assert ish is None or (ish.i0, ish.i1) == (J.i0, J.i1)
+            feats = [J.feat[m][:J.ni] for m in range(M)] if ish is not None else J.all_feats()
+        else:
+            feats = [J.feat[m] if ish is None else J.feat[m][ish.i0:ish.i1] for m in range(M)]
+        i_embs = J.i_embs  # (2D: one all-gather of the replicas' slices) -- does not move in this phase either
+        reg_term = DE.reg_term(i_embs)
         dl = [0.0] * M
         step_means = []
         diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
@@ -261,7 +267,7 @@ class Coach:
                 for m in range(M):
                     t.append(draws.randint(T, x0.shape[0]).to(dev, torch.int32))
                     noise.append(draws.randn((x0.shape[0], int(cfg.data.item_num))).to(dev))
-            means = DE.train_step(x0, feats, J.i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]),
+            means = DE.train_step(x0, feats, i_embs, t=t, noise=noise, precision=prec, reg_term=reg_term, global_rows=int(idx.shape[0]),
                                   host_means=prec != 1)
             step_means.append(means)
         DE.end_phase()
@@ -313,8 +319,9 @@ class Coach:
             noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
             acc += J.step(users, pos, neg, noise=noise, precision=prec)
         nT = J.n_terms
-        if lay is not None:  # [terms..., bpr, reg over the own users, reg over the items]: only the user part is a partial sum
-            comm.all_reduce(acc[nT + 1:nT + 2], group=self.group)
+        if lay is not None:  # [terms..., bpr, reg over the own users, reg over the items]: the user part is a partial sum -- the item part too when
+            part = acc[nT + 1:nT + 3] if not getattr(J, "replicated_items", True) else acc[nT + 1:nT + 2]  # the items are sharded as well
+            comm.all_reduce(part, group=self.group)
             acc = torch.cat([acc[:nT + 1], acc[nT + 1:nT + 2] + acc[nT + 2:nT + 3]])
         a = acc.cpu().numpy()
         if lay is not None:
@@ -329,7 +336,7 @@ class Coach:
 
     def _replicated_parts(self):
         J, DE = self.model.engine, self.diff_engine
-        lo = J.nu * J.D
+        lo = getattr(J, "replicated_lo", J.nu * J.D)  # (items sharded as well: only the projections and modal_weight are replicated)
         nr = DE.n_replicated if self.item_shard is not None else None  # item-sharded Denoise: only the small tensors are replicated
         return [J.P.data[lo:], J.P.m[lo:], J.P.v[lo:]] + [t[:nr] for p in DE.P for t in (p.data, p.m, p.v)]
 
@@ -381,7 +388,7 @@ class Coach:
         J.forward(with_cl=False, precision=self.precision)
         nu = J.nu if lay is not None else J.U
         u0 = lay.u0 if lay is not None else 0
-        uf, itf = J.Fin[:nu], J.Fin[nu:]
+        uf, itf = J.Fin[:nu], (J.Fin[nu:] if getattr(J, "replicated_items", True) else J.final_item_embs())
         td, k = h.testData, int(self.config.base.topk)
         # the reference ranks test_batch users at a time (Main.py:396-411); the metrics are per-user sums, so the batch size only sets how many launches
         # the evaluation takes: up to 8192 users per launch here (score buffer <= 2 GiB) -- 37 host-paced rounds -> 2 at TikTok shape

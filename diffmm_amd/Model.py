@@ -48,6 +48,21 @@ class GCNOutput:
     i_audio_embs: Optional[Tensor] = None
 
 
+def joint_shard_mode(world: int, items: int, D: int) -> str:
+    """How the joint step is sharded over the replicas (DMM_JOINT_SHARD = 1d | 2d | auto).  "1d" (sharded.py): users sharded, items replicated -- one
+    all-reduce of a [I, d] fp32 partial per propagation.  "2d" (sharded2d.py): items sharded as well -- reduce-scatter + all-gather of the gather
+    operands, item-side dense passes and Adam state 1 / world.  auto: 2d once a propagation's item partial reaches 64 MiB (I d >= 16M: the exchange
+    is then a bandwidth term) and every replica gets a non-empty slice; the small shipped datasets keep the fewer, smaller collectives."""
+    import os
+    mode = os.environ.get("DMM_JOINT_SHARD", "auto")
+    if mode not in ("1d", "2d", "auto"):
+        raise ValueError("DMM_JOINT_SHARD must be 1d, 2d or auto")
+    fits = (world - 1) * -(-items // world) < items
+    if mode == "2d" and not fits:
+        raise ValueError("DMM_JOINT_SHARD=2d: a replica's item slice would be empty")
+    return "2d" if (mode == "2d" or (mode == "auto" and fits and items * D * 4 >= (64 << 20))) else "1d"
+
+
 class Model:
     """Multi-modal graph encoder (Model.py:15-134).  `gcn_MM` returns views into the engine's HBM buffers."""
 
@@ -62,7 +77,9 @@ class Model:
         U, I, D = int(config.data.user_num), int(config.data.item_num), int(config.base.latdim)
         if layout is not None and comm.active(layout.world):
             from .sharded import ShardedJointEngine
-            self.engine = ShardedJointEngine(layout, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch), group=group)
+            from .sharded2d import Sharded2DJointEngine
+            Engine = Sharded2DJointEngine if joint_shard_mode(layout.world, I, D) == "2d" else ShardedJointEngine
+            self.engine = Engine(layout, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch), group=group)
         else:
             self.engine = JointEngine(U, I, D, feats, hyper_dict(config), self.device, int(batch_max or config.train.batch))
         self.precision = precision

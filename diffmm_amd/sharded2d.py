@@ -126,6 +126,7 @@ class Sharded2DJointEngine:
         self._philox_refs: Optional[list] = None
         self._tables: Dict[tuple, Tensor] = {}
         self._featsT = None
+        self._emb16_step = -1  # (interface of the other engines: nothing to refresh here, the gather tables are rebuilt per step)
 
     # -- parameters ------------------------------------------------------------------------------------
     @property

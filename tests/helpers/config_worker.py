@@ -32,6 +32,7 @@ def run_config(conf: str, latdim: int, T: int, batch: int, epochs: int, rank: in
                               "modal_nnz": [int(a.nnz) for a in adjs], "phase_s": list(coach.phase_seconds)})
     out["sampling_step"] = int(cfg.hyper.sampling_step)
     out["denoise_shard"] = "items" if getattr(coach, "item_shard", None) is not None else "rows"
+    out["joint_shard"] = "1d" if getattr(coach.model.engine, "replicated_items", True) else "2d"
     return out
 
 

@@ -57,19 +57,33 @@ def test_self_launch_refuses_more_rccl_ranks_than_gpus():
     assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
 
 
-@pytest.mark.parametrize("denoise_shard", ["rows", "items"])
+def test_two_replicas_with_the_items_sharded_as_well():
+    """DMM_JOINT_SHARD=2d (diffmm_amd/sharded2d.py): the joint step's item partials are reduce-scattered, the gather operands all-gathered, i_embs and the
+    item-side passes split over the replicas -- whole epochs over two replicas (gloo: all-reduce + slice stands in for the reduce-scatter)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_JOINT_SHARD="2d")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", *SMALL, "--no-cpu-baseline", "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = _json_line(p.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "user-shard2+item-shard" and j["replicated_params_identical"] is True and j["value"] > 0
+
+
+@pytest.mark.parametrize("denoise_shard", ["rows", "items", "items+2d"])
 def test_every_collective_of_an_epoch_runs_through_rccl(denoise_shard):
     """A one-GPU box cannot hold two RCCL ranks, but it can hold ONE: under DMM_FORCE_COLLECTIVES=1 a single replica runs the user-sharded engines and
     sends every collective of the epoch (item partials on the side stream under the next SpMM launch, batch table, gradient tails, Denoise partial
     activations / weight gradients, item counts of the rebuild, replica checksums in int64 MIN / MAX, metric sums) through an nccl process group of
     size 1: RCCL's communicator, stream ordering, dtype and contiguity rules all see the calls the 8-GPU job makes."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_FORCE_COLLECTIVES="1", DMM_DENOISE_SHARD=denoise_shard)
+    two_d = denoise_shard.endswith("+2d")  # ... and the 2D joint step's reduce_scatter_tensor / all_gather_into_tensor
+    denoise_shard = denoise_shard.split("+")[0]
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_FORCE_COLLECTIVES="1", DMM_DENOISE_SHARD=denoise_shard, DMM_JOINT_SHARD="2d" if two_d else "1d")
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--backend", "nccl", *SMALL, "--no-cpu-baseline", "--no-roofline"]
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     j = _json_line(p.stdout)
-    assert j["config"]["parallelism"] == "user-shard1" and j["config"]["backend"] == "nccl" and j["config"]["denoise_shard"] == denoise_shard
+    assert j["config"]["parallelism"] == "user-shard1" + ("+item-shard" if two_d else "") and j["config"]["backend"] == "nccl" and j["config"]["denoise_shard"] == denoise_shard
     assert j["replicated_params_identical"] is True and j["value"] > 0
 
 

@@ -140,3 +140,29 @@ def test_config5_one_replica_of_eight_at_full_shape():
     assert out["base_block_nnz"] == want and out["modal_block_nnz"] == [want] * 3
     assert out["rebuilt_rows_keep_degree"] and out["rebuilt_rows_distinct"] and out["chain_error_word_clear"]
     assert out["peak_alloc_GiB"] < 200.0
+
+
+@pytest.mark.parametrize("denoise_shard", ["rows", "items"])
+def test_tiktok_shape_epochs_with_users_and_items_sharded(denoise_shard):
+    """DMM_JOINT_SHARD=2d (diffmm_amd/sharded2d.py) through whole epochs: two replicas (gloo on this GPU) against the single-GPU run of the same
+    configuration -- the same minibatches and optimiser steps, other noise streams: first-epoch losses within 1-2 %, the replicas' rebuilt blocks
+    hold every entry of the rebuilt graphs exactly once, sane metrics; both Denoise splits (the item-sharded Denoise reads the replica's own slice
+    of the projected features, the row split an all-gather of them)."""
+    need_gpu()
+    single = run_config("tiktok", 64, 5, 1024, 2)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "out.json")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DMM_JOINT_SHARD="2d", DMM_DENOISE_SHARD=denoise_shard)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(29900 + os.getpid() % 40), os.path.join(REPO, "tests", "helpers", "config_worker.py"), "tiktok", "64", "5", "1024", "2", path]
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-4000:]
+        shard = json.load(open(path))
+    assert shard["joint_shard"] == "2d" and shard["denoise_shard"] == denoise_shard
+    _check(shard, 2)
+    N = single["users"] + single["items"]
+    assert shard["modal_nnz_sum_over_replicas"] == [2 * single["E"] + N] * 3
+    s, d = single["epochs"][0], shard["epochs"][0]
+    for k, tol in (("Loss", 0.02), ("BPR Loss", 0.01), ("CL loss", 0.02), ("reg loss", 0.08)):
+        assert abs(s["train"][k] - d["train"][k]) <= tol * abs(s["train"][k]), f"{k}: single {s['train'][k]:.5f} vs 2D-sharded {d['train'][k]:.5f}"
+    assert abs(single["epochs"][1]["test"]["Recall"] - shard["epochs"][1]["test"]["Recall"]) <= 0.03
