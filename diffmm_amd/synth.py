@@ -30,6 +30,7 @@ SHAPES: Dict[str, dict] = {
     "sports": dict(users=35598, items=18357, feats=(4096, 1024), heavy_p=0.0, heavy=(0, 0), light_shift=3),
     "toy": dict(users=12, items=9, feats=(5, 7, 6), heavy_p=0.1, heavy=(5, 7)),
     "mid": dict(users=300, items=200, feats=(32, 48, 16), heavy_p=0.02, heavy=(60, 120)),
+    "mid2": dict(users=2000, items=1200, feats=(64, 96, 32), heavy_p=0.011, heavy=(80, 160)),  # the paired 12-epoch golden (tests/golden/epoch_paired.npz)
 }
 
 

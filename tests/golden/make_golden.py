@@ -311,8 +311,10 @@ def build_handler(cfg, g, B, seed):
     return h, train_perm, diff_perm
 
 
-def gen_epoch(name, d, H, T, B, epochs, store_draws, cl_method=0, M=3, tag=None):
-    """One or more full Coach.trainEpoch()+testEpoch() of the reference with every random draw pinned."""
+def gen_epoch(name, d, H, T, B, epochs, store_draws, cl_method=0, M=3, tag=None, slim=False):
+    """One or more full Coach.trainEpoch()+testEpoch() of the reference with every random draw pinned.
+    slim: a LONG paired run -- only the initial weights, the per-epoch negatives and the per-epoch losses / metrics are kept (no per-epoch weights or
+    rebuilt graphs, draws by seed only): what the HIP path must reproduce epoch by epoch when it replays the same draws."""
     g = synth.named(name)
     cfg = mkcfg("tiktok" if M == 3 else "sports", base__latdim=d, base__denoise_dim=f"[{H}]", base__seed=1818,
                 base__cl_method=cl_method, base__topk=min(20, g.items // 2),
@@ -357,7 +359,7 @@ def gen_epoch(name, d, H, T, B, epochs, store_draws, cl_method=0, M=3, tag=None)
             for k, v in res.items():
                 save[f"ep{ep}/train/{k}"] = np.float64(v)
             adjs = [coach.image_adj, coach.text_adj] + ([coach.audio_adj] if M == 3 else [])
-            for m, a in enumerate(adjs):
+            for m, a in enumerate(adjs if not slim else []):
                 r, c, v = adj_arrays(a)
                 save[f"ep{ep}/adj{m}_row"], save[f"ep{ep}/adj{m}_col"], save[f"ep{ep}/adj{m}_val"] = r, c, v
             if cfg.train.use_lr_scheduler:  # Main.py:59-65
@@ -368,9 +370,10 @@ def gen_epoch(name, d, H, T, B, epochs, store_draws, cl_method=0, M=3, tag=None)
                 tres = coach.testEpoch()
             for k, v in tres.items():
                 save[f"ep{ep}/test/{k}"] = np.float64(v)
-            save.update(sd_np(f"ep{ep}/model/", coach.model))
-            for m, dn in enumerate(dens):
-                save.update(sd_np(f"ep{ep}/den{m}/", dn))
+            if not slim:
+                save.update(sd_np(f"ep{ep}/model/", coach.model))
+                for m, dn in enumerate(dens):
+                    save.update(sd_np(f"ep{ep}/den{m}/", dn))
             save[f"ep{ep}/lr_after"] = np.float64(coach.opt.param_groups[0]["lr"])
     finally:
         torch.randint, torch.randn_like, torch.rand_like = o
@@ -411,6 +414,8 @@ JOBS = {
                       gen_epoch("mid", 16, 64, 3, 128, 1, False, cl_method=1, tag="mid_cl1"),
                       gen_epoch("mid", 16, 64, 3, 128, 1, False, M=2, tag="mid_M2")],
     "calcres": gen_calcres,
+    # the paired long run: 12 reference epochs at 2000 x 1200, draws regenerated from their seed
+    "epoch_paired": lambda: gen_epoch("mid2", 32, 64, 10, 512, 12, False, tag="paired", slim=True),
 }
 
 if __name__ == "__main__":
