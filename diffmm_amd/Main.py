@@ -294,7 +294,8 @@ class Coach:
                                          csr=(dd.ptr, dd.col32, 0), init_cols=init)
                 if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
                     self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim), vec=self.base_adj.vec,
-                                                                  task_len=graph.spmm_task_len(self.base_adj.vec))
+                                                                  task_len=graph.spmm_task_len(self.base_adj.vec),
+                                                                  reuse=os.environ.get("DMM_GRAPH_REUSE", "1") != "0")
             else:  # own users only (local ids index the local CSR; the data rows are looked up by global id)
                 if getattr(self, "graph_builder", None) is None:
                     self.graph_builder = graph.ShardedGraphBuilder(self.local_ptr, lay.nu, lay.users, lay.items, int(cfg.base.latdim), self.rank, self.world,

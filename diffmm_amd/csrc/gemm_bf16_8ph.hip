@@ -701,9 +701,54 @@ constexpr int V2_SLAB_LD = 132;                     // epilogue slab: 32 rows x 
 
 #ifdef P8_TIMING
 #define LAT2_STAMP(step, i) if (threadIdx.x == 0 && blockIdx.x < 512 && (step) < 64) latent_stamps[((blockIdx.x * 64 + (step)) * 8 + (i))] = wall_clock64()
+// inside one stage (stage 8 of step 5), in shader clocks: slots (60, 0..5) of the workgroup's stamp rows
+#define LAT2_CYC(i) if (threadIdx.x == 0 && blockIdx.x < 512 && step == 5 && t == 8) latent_stamps[((blockIdx.x * 64 + 60) * 8 + (i))] = __builtin_readcyclecounter()
 #else
 #define LAT2_STAMP(step, i)
+#define LAT2_CYC(i)
 #endif
+
+// h' store of the second form: 4 bf16 = 8 bytes per lane.  Inline assembly for the same reason as its fragment reads: as a C++ (atomic) store through
+// a pointer the compiler cannot prove global it becomes flat_store with s_waitcnt vmcnt(0) on both sides -- every store serialised (14 us of epilogue).
+// Addressing: a wave-uniform base in SGPRs + a 32-bit per-lane byte offset (one register that walks the rows; 32 precomputed 64-bit row pointers
+// were hoisted out of the step loop and spilled).
+template <bool WT>
+__device__ __forceinline__ void v2_store_h(const __bf16* sbase, unsigned voff, const float (&v)[4]) {
+  const bf16x4 b = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  const u32x2 d = __builtin_bit_cast(u32x2, b);
+  if (WT) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(d), "s"(sbase) : "memory");  // write-through, agent scope
+  else asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(d), "s"(sbase) : "memory");
+}
+
+template <bool WT, bool EDGE>
+__device__ __forceinline__ void v2_epilogue(const f32x4 (&acc)[4][8], float* slab, float alpha, const float4& bb, const __bf16* sdst, unsigned voff, unsigned ldh,
+                                            int rows_left, int q, int fr, int lane) {
+  const unsigned row_step = 2u * ldh * 2u;  // two rows per store instruction
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(ml * 16 + q * 4 + r) * V2_SLAB_LD + n * 16 + fr] = acc[pass * 2 + ml][n][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    // a lane owns 4 consecutive columns of 16 rows of the pass: 32 lanes cover a row's 128 columns (256 bytes of bf16: two whole 128-byte
+    // lines per store instruction and row), two rows per instruction
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int rl = it * 2 + (lane >> 5);  // row of the pass
+      const float4 a4 = *reinterpret_cast<const float4*>(slab + rl * V2_SLAB_LD + (lane & 31) * 4);
+      const float w[4] = {tanh_fast_bf16(fmaf(alpha, a4.x, bb.x)), tanh_fast_bf16(fmaf(alpha, a4.y, bb.y)), tanh_fast_bf16(fmaf(alpha, a4.z, bb.z)),
+                          tanh_fast_bf16(fmaf(alpha, a4.w, bb.w))};
+      if (!EDGE || pass * 32 + rl < rows_left) v2_store_h<WT>(sdst, voff, w);
+      voff += row_step;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 
 template <bool WT>
 __global__ __launch_bounds__(256, 2) void latent_chain_v2_kernel(const LatentBatch Lb) {
@@ -743,6 +788,7 @@ __global__ __launch_bounds__(256, 2) void latent_chain_v2_kernel(const LatentBat
   const unsigned voffB = (unsigned)(lane >> 2) * (unsigned)P.ldg * 2u + (unsigned)(lane & 3) * 16u;
   const unsigned sA = (unsigned)((unsigned long long)(m0 + wave * 16) * (unsigned long long)ldh * 2ull), sA_step = 64u * (unsigned)ldh * 2u;
   const unsigned sB = (unsigned)(n0 + wave * 16) * (unsigned)P.ldg * 2u, sB_step = 64u * (unsigned)P.ldg * 2u;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   const int offA = (wr * 64 + fr) * 64 + q * 16;                   // fragment of m-tile mt: + mt * 1024
   const int offB = V2_A_BYTES + (wc * 128 + fr) * 64 + q * 16;     // fragment of n-tile nt: + nt * 1024
 
@@ -792,63 +838,55 @@ __global__ __launch_bounds__(256, 2) void latent_chain_v2_kernel(const LatentBat
     issue(1, 1);
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
+      LAT2_CYC(0);
       if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's part of stage t has landed (stage t + 1 may be in flight)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LAT2_CYC(1);
       P8_BARRIER();  // every wave's part of stage t; and every wave is done reading stage t - 1, whose buffer the next issue refills
+      LAT2_CYC(2);
       if (t == 0) { LAT2_STAMP(step, 1); }
       if (t + 2 < nk) issue(t + 2, buf == 0 ? 2 : buf - 1);
-      const char* const st = smem + buf * V2_STAGE;
+      LAT2_CYC(3);
+      // The fragment reads are INLINE ASSEMBLY: written as C++ loads, the compiler orders every LDS read behind ALL outstanding `buffer_load ... lds`
+      // (it cannot tell the ring's stages apart and inserts s_waitcnt vmcnt(0) in front of the reads -- the loads issued two lines above included:
+      // no prefetch at all; measured 20 us of main loop for half a tile).  The counted waits below are therefore explicit too.
+      const unsigned aA = lds_base + (unsigned)buf * V2_STAGE + (unsigned)offA, aB = lds_base + (unsigned)buf * V2_STAGE + (unsigned)offB;
       bf16x8 fa[4], fb[8];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(st + offA + mt * 1024);
-#pragma unroll
-      for (int n = 0; n < 8; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(st + offB + n * 1024);
-      P8_LGKM0();
+#define V2_DS(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+      V2_DS(fa[0], aA, 0); V2_DS(fa[1], aA, 1024); V2_DS(fa[2], aA, 2048); V2_DS(fa[3], aA, 3072);
+      V2_DS(fb[0], aB, 0); V2_DS(fb[1], aB, 1024); V2_DS(fb[2], aB, 2048); V2_DS(fb[3], aB, 3072);
+      V2_DS(fb[4], aB, 4096); V2_DS(fb[5], aB, 5120); V2_DS(fb[6], aB, 6144); V2_DS(fb[7], aB, 7168);
+#undef V2_DS
+      // (no s_setprio around the MFMAs: the wave that shares this SIMD belongs to the OTHER workgroup and may be in its epilogue -- MI355X_MICROARCH.md
+      // "two waves per SIMD" item 2)
+#define V2_MMA(n, cnt)                                                                                                                  \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")" ::: "memory");                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                                               \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[n], acc[mt][n], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);
-      // (no s_setprio around the MFMAs here: the wave that shares this SIMD belongs to the OTHER workgroup and may be in its epilogue -- a raised
-      // priority starves its exp / rcp chain, MI355X_MICROARCH.md "two waves per SIMD" item 2: measured 11.5 us of epilogue instead of 5)
-#pragma unroll
-      for (int n = 0; n < 8; ++n)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[n], acc[mt][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+      LAT2_CYC(4);
+      V2_MMA(0, 7) V2_MMA(1, 6) V2_MMA(2, 5) V2_MMA(3, 4) V2_MMA(4, 3) V2_MMA(5, 2) V2_MMA(6, 1) V2_MMA(7, 0)
+#undef V2_MMA
+      LAT2_CYC(5);
       buf = buf == 2 ? 0 : buf + 1;
     }
     P8_BARRIER();  // every wave is done reading the last stage: LDS is free for the epilogue slabs
+    // (every LDS-DMA has landed -- the last stage waited for vmcnt(0) -- but only a wait the COMPILER can see clears its scoreboard: without this one
+    // it orders each slab read of the epilogue behind the "outstanding" DMA with s_waitcnt vmcnt(2) / vmcnt(0), which in fact wait for the h' stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     LAT2_STAMP(step, 2);
     // the acquire's L1 invalidate, hoisted in front of the epilogue (see the first form): no load of h is issued between here and the group barrier
     if (threadIdx.x == 0) asm volatile("buffer_inv sc1" ::: "memory");
-    // ---- epilogue: h' = tanh(c1[i] a + bias_t[i - 1]) in bf16, 2 passes of 32 rows through the wave's LDS slab; a lane stores 8 consecutive columns
+    // ---- epilogue: h' = tanh(c1[i] a + bias_t[i - 1]) in bf16, 2 passes of 32 rows through the wave's LDS slab (interior tiles: no bounds branch --
+    // a branch per store splits the loop into basic blocks at whose heads the compiler re-waits vmcnt(0), i.e. for the previous store)
     {
       const float alpha = coef[2 * i];
       const float4 bb = *reinterpret_cast<const float4*>(bias_t + (long long)(i - 1) * ldbt + n0 + wc * 128 + (lane & 31) * 4);
-      __bf16* const dst = hbuf[src ^ 1] + (long long)(m0 + wr * 64) * ldh + n0 + wc * 128 + (lane & 31) * 4;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int ml = 0; ml < 2; ++ml)
-#pragma unroll
-          for (int n = 0; n < 8; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) slab[(ml * 16 + q * 4 + r) * V2_SLAB_LD + n * 16 + fr] = acc[pass * 2 + ml][n][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
-        // a lane owns 4 consecutive columns of 16 rows of the pass: 32 lanes cover a row's 128 columns (256 bytes of bf16: two whole 128-byte
-        // lines per store instruction and row), two rows per instruction
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int rl = it * 2 + (lane >> 5);  // row of the pass
-          const float4 a4 = *reinterpret_cast<const float4*>(slab + rl * V2_SLAB_LD + (lane & 31) * 4);
-          const float w[4] = {tanh_fast_bf16(fmaf(alpha, a4.x, bb.x)), tanh_fast_bf16(fmaf(alpha, a4.y, bb.y)), tanh_fast_bf16(fmaf(alpha, a4.z, bb.z)),
-                              tanh_fast_bf16(fmaf(alpha, a4.w, bb.w))};
-          // (interior tiles store unconditionally: a bounds branch around these stores makes the compiler wait for ALL outstanding stores in
-          // every branch -- 14.6 us of epilogue instead of 5, measured)
-          if (interior) p8_st_keep<(WT ? 2 : 1)>(dst + (long long)(pass * 32 + rl) * ldh, w);
-          else if (m0 + wr * 64 + pass * 32 + rl < rows) p8_st_keep<(WT ? 2 : 1)>(dst + (long long)(pass * 32 + rl) * ldh, w);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // the pass's LDS reads are done before the next pass overwrites the slab
-        __builtin_amdgcn_wave_barrier();
-      }
+      const __bf16* const sdst = hbuf[src ^ 1] + (long long)(m0 + wr * 64) * ldh + n0 + wc * 128;  // (wave-uniform)
+      const unsigned voff = ((unsigned)(lane >> 5) * (unsigned)ldh + (unsigned)(lane & 31) * 4u) * 2u;  // the lane's bytes from there: row lane / 32, 4 columns
+      if (interior) v2_epilogue<WT, false>(acc, slab, alpha, bb, sdst, voff, (unsigned)ldh, 0, q, fr, lane);
+      else v2_epilogue<WT, true>(acc, slab, alpha, bb, sdst, voff, (unsigned)ldh, rows - (m0 + wr * 64), q, fr, lane);
     }
     LAT2_STAMP(step, 3);
     if (step + 1 == T - 1) break;  // h_0 is written; nothing follows in this kernel

@@ -129,6 +129,27 @@ class FlatParams:
         return [[k, list(self.shapes[k]), int(self.offsets[k])] for k in self.names]
 
 
+def plan_spmm_refs(calls, adjs: Sequence[Adjacency]):
+    """The SpMM problems of a recorded plan that run on PERSISTENT adjacencies (graph.Adjacency.persistent: rebuilt in place every epoch), as
+    (argument array, index, adjacency) triples -- what patch_spmm_sizes refreshes after a rebuild."""
+    by_ptr = {a.tasks.data_ptr(): a for a in adjs if a.persistent}
+    refs = []
+    if by_ptr:
+        for _fn, args, name in calls:
+            if name in ("dmm_spmm_csr_f32", "dmm_spmm_csr_bf16", "dmm_spmm_epilogue_rows"):
+                arr, n = args[0], int(args[1])
+                refs += [(arr, i, by_ptr[arr[i].tasks]) for i in range(n) if arr[i].tasks in by_ptr]
+    return refs
+
+
+def patch_spmm_sizes(refs) -> None:
+    """A persistent adjacency keeps its device buffers across rebuilds; the sizes a recorded SpMM launch carries do not."""
+    for arr, i, a in refs:
+        p = arr[i]
+        p.n_tasks, p.n_head_tasks, p.n_partial_blocks = a.n_tasks, a.n_head_tasks, a.n_partial_blocks
+        p.n_fix = int(a.fix.shape[0]) if a.fix is not None else 0
+
+
 def modality_names(M: int) -> Tuple[str, ...]:
     return MODAL[:M] if M == 3 else ("image", "text")
 
@@ -463,8 +484,10 @@ class JointEngine:
         marshalling.  Per step only the batch indices (copied into static buffers), the Philox offsets and Adam's (lr, step)
         change.  (Several GPUs: diffmm_amd/sharded.py -- the user-sharded engine, same plan mechanism with the collectives in it.)"""
         B = int(users.shape[0])
-        key = (B, precision, self.adj.uid, tuple(a.uid for a in self.modal_adj))
+        graphs = [self.adj] + self.modal_adj
+        key = (B, precision, self.adj.uid, tuple(a.uid for a in self.modal_adj), tuple(a.version for a in graphs))
         plan = self._plans.get(key)
+        meta = tuple(a.meta_version for a in graphs)
         if plan is None:
             if len(self._plans) > 8:
                 self._plans.clear()
@@ -472,12 +495,15 @@ class JointEngine:
             try:
                 with L.Recorder() as calls:
                     self.step(self.users_s[:B], self.pos_s[:B], self.neg_s[:B], noise=None, precision=precision, update=True)
-                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in L.ADAM_CALLS])
+                plan = dict(calls=calls, philox=self._philox_refs, adam=[c for c in calls if c[2] in L.ADAM_CALLS], spmm=plan_spmm_refs(calls, graphs), meta=meta)
             finally:
                 self._philox_refs = None
             self.rng_step -= 1  # recording ran step()'s bookkeeping once without launching anything
             self.P.step -= 1
             self._plans[key] = plan
+        if plan["meta"] != meta:  # graphs rebuilt in place since the plan last ran: same pointers, new sizes
+            patch_spmm_sizes(plan["spmm"])
+            plan["meta"] = meta
         self._set_batch(users, pos, neg)
         x16 = self._x16()
         if x16 is not None and self._emb16_step != self.P.step:

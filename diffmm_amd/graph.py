@@ -218,6 +218,13 @@ class Adjacency:
     host: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
     uid: int = field(default_factory=lambda: next(_adjacency_uid))
     vec: int = 4  # columns per lane the task list was planned for: 4 = fp32 operands (dmm_spmm_csr_f32), 8 = bf16 operands (dmm_spmm_csr_bf16)
+    # A PERSISTENT adjacency (DeviceGraphBuilder(reuse=True): the rebuilt modality graphs) is rebuilt into the same device buffers epoch after epoch:
+    # recorded launch plans stay valid -- their pointers do not move -- and only the SIZES they carry (n_tasks, n_head_tasks, n_partial_blocks, n_fix)
+    # are patched when `meta_version` has moved (engine.patch_spmm_sizes); `version` moves when a buffer had to be reallocated (plans are dropped).
+    persistent: bool = False
+    version: int = 0
+    meta_version: int = 0
+    partial_cap: int = 0  # rows of the giant-row scratch buffers (persistent adjacencies allocate with headroom)
 
     @property
     def n_tasks(self) -> int:
@@ -226,21 +233,33 @@ class Adjacency:
     def partial_buffer(self, i: int) -> Optional[torch.Tensor]:
         """Scratch for the giant-row segments of the i-th concurrent use of this adjacency in one launch (owned here so that
         recorded launch plans keep valid pointers)."""
-        if not self.n_partial_blocks:
+        if not self.n_partial_blocks and not self.persistent:
             return None
         pool = self.__dict__.setdefault("_partial_pool", [])
+        self.ensure_capacity()
+        rows = max(self.partial_cap, 64) if self.persistent else self.n_partial_blocks
         while len(pool) <= i:
-            pool.append(torch.empty((self.n_partial_blocks, self.D), dtype=torch.float32, device=self.col.device))
+            pool.append(torch.empty((rows, self.D), dtype=torch.float32, device=self.col.device))
         return pool[i]
+
+    def ensure_capacity(self) -> None:
+        """Persistent adjacencies: the giant-row scratch buffers hold max(partial_cap, 64) rows; a rebuild that needs more gets new, larger
+        buffers and a new `version` (recorded plans, which hold the old pointers, are dropped by their owners).  Called by the builder after
+        every in-place rebuild and before a buffer is handed out."""
+        if self.persistent and self.n_partial_blocks > max(self.partial_cap, 64):
+            self.partial_cap = 2 * self.n_partial_blocks
+            self.__dict__.setdefault("_partial_pool", []).clear()
+            self.version += 1
 
     def fix_counter(self, i: int) -> Optional[torch.Tensor]:
         """Arrival counters of the giant rows for the i-th concurrent use of this adjacency in one launch (dmm_spmm_problem.fix_count: zero
         between launches -- the kernel leaves them zero)."""
-        if self.fix is None or not self.n_partial_blocks:
+        if self.fix is None or (not self.n_partial_blocks and not self.persistent):
             return None
         pool = self.__dict__.setdefault("_fix_count_pool", [])
+        cap = int(self.fix.shape[0]) if not self.persistent else max(1, self.fix.untyped_storage().nbytes() // 16)  # (persistent: the fix buffer's capacity)
         while len(pool) <= i:
-            pool.append(torch.zeros(int(self.fix.shape[0]), dtype=torch.int32, device=self.col.device))
+            pool.append(torch.zeros(cap, dtype=torch.int32, device=self.col.device))
         return pool[i]
 
     def algorithmic_bytes(self, elem_bytes: int = 4) -> int:
@@ -303,11 +322,15 @@ class DeviceGraphBuilder:
     are user u's items, distinct and ascending.  Bit-identical to `make_adjacency` on the same edges (tests/test_host_logic.py);
     the only host read-back is the 32-byte size record."""
 
-    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = TASK_LEN, vec: int = 4):
+    def __init__(self, user_ptr: torch.Tensor, users: int, items: int, D: int, task_len: int = TASK_LEN, vec: int = 4, reuse: bool = False):
+        """reuse: build_all() rebuilds graph i into the SAME device buffers and Adjacency object as its previous call (Adjacency.persistent): the
+        engines' recorded launch plans survive the rebuild (re-recording the joint step's plan cost ~0.5 ms of host time per epoch at TikTok
+        shape, with the GPU idle).  The previous build's graphs are overwritten: callers that need both generations build without reuse."""
         import ctypes as C
         from . import _lib as L
         if vec not in (4, 8):
             raise ValueError("vec must be 4 (fp32 operands) or 8 (bf16 operands)")
+        self.reuse, self._slots = bool(reuse), []
         self.D_full, self.vec = D, vec
         D = D * 4 // vec  # (bf16 operands: a lane owns 8 columns -- the task plan of width D / 2, as in adjacency_from_csr)
         self.U, self.I, self.N, self.D, self.task_len = users, items, users + items, D, task_len
@@ -339,9 +362,12 @@ class DeviceGraphBuilder:
         for i, item_idx in enumerate(item_lists):
             if item_idx.dtype != torch.int32 or not item_idx.is_contiguous() or item_idx.numel() < self.E:
                 raise ValueError("DeviceGraphBuilder.build: item_idx must be a contiguous int32 tensor with one entry per edge")
+            if self.reuse and i < len(self._slots):
+                outs.append(self._slots[i]["bufs"])
+                continue
             outs.append((torch.empty(N + 1, dtype=torch.int32, device=dev), torch.empty(nnz, dtype=torch.int32, device=dev),
                          torch.empty(nnz, dtype=torch.float32, device=dev), torch.empty((self.task_cap, 4), dtype=torch.int32, device=dev),
-                         torch.empty((self.fix_cap, 4), dtype=torch.int32, device=dev)))
+                         torch.empty((max(self.fix_cap, 1), 4), dtype=torch.int32, device=dev)))
         # the graphs are independent and their 7 launches each are latency-bound (scans, per-row sorts): one HIP stream and one scratch
         # buffer per graph, forked from and joined to the caller's stream (all outputs were allocated on it above)
         n = len(item_lists)
@@ -368,15 +394,26 @@ class DeviceGraphBuilder:
                 L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,
                        L.ptr(self.dinv), L.ptr(rowptr), L.ptr(col), L.ptr(val), L.ptr(tasks), L.ptr(fix), L.ptr(metas[i]), L.ptr(self._scratches[i]), L.stream())
         adjs = []
-        for (rowptr, col, val, tasks, fix), m in zip(outs, metas.tolist()):
+        for i, ((rowptr, col, val, tasks, fix), m) in enumerate(zip(outs, metas.tolist())):
             n_tasks, head, n_partial, n_fix, nnz_d = m[:5]
             if nnz_d != nnz or n_tasks > self.task_cap or n_fix > self.fix_cap:
                 raise RuntimeError(f"dmm_graph_build: inconsistent sizes (nnz {nnz_d} vs {nnz}, tasks {n_tasks}/{self.task_cap}, fix {n_fix}/{self.fix_cap})")
-            tasks = tasks[:n_tasks]
             if validate:
-                check_plan(rowptr.cpu().numpy().astype(np.int64), tasks.cpu().numpy(), self.D)
-            adjs.append(Adjacency(n=N, nnz=nnz, D=self.D_full, rowptr=rowptr, col=col, val=val, tasks=tasks, n_head_tasks=head, n_partial_blocks=n_partial,
-                                  fix=fix[:n_fix] if n_partial else None, vec=self.vec))
+                check_plan(rowptr.cpu().numpy().astype(np.int64), tasks[:n_tasks].cpu().numpy(), self.D)
+            if self.reuse:
+                if i < len(self._slots):  # the same Adjacency object, rebuilt in place: new sizes, same pointers
+                    a = self._slots[i]["adj"]
+                    a.tasks, a.n_head_tasks, a.n_partial_blocks, a.fix = tasks[:n_tasks], head, n_partial, fix[:n_fix]
+                    a.meta_version += 1
+                    a.ensure_capacity()
+                else:
+                    a = Adjacency(n=N, nnz=nnz, D=self.D_full, rowptr=rowptr, col=col, val=val, tasks=tasks[:n_tasks], n_head_tasks=head,
+                                  n_partial_blocks=n_partial, fix=fix[:n_fix], vec=self.vec, persistent=True)
+                    self._slots.append(dict(bufs=(rowptr, col, val, tasks, fix), adj=a))
+                adjs.append(a)
+            else:
+                adjs.append(Adjacency(n=N, nnz=nnz, D=self.D_full, rowptr=rowptr, col=col, val=val, tasks=tasks[:n_tasks], n_head_tasks=head,
+                                      n_partial_blocks=n_partial, fix=fix[:n_fix] if n_partial else None, vec=self.vec))
         return adjs
 
 

@@ -107,7 +107,7 @@ def spmm_batched(ops: Sequence[SpmmOp]):
     D = ops[0].D
     uses = {}
     for o in ops:  # giant-row scratch: one buffer per concurrent use of an adjacency, owned by the adjacency
-        if o.adj.n_partial_blocks and not o.p.partial:
+        if (o.adj.n_partial_blocks or o.adj.persistent) and not o.p.partial:
             i = uses.get(id(o.adj), 0)
             uses[id(o.adj)] = i + 1
             o.p.partial = L.ptr(o.adj.partial_buffer(i))

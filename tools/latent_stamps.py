@@ -38,3 +38,11 @@ for i, nm in enumerate(names):
 d = us(s[:, 3:T - 1, 0] - s[:, 2:T - 2, 5])
 print(f"  {'barrier passed -> next step start':40s} mean {d.mean():6.2f} us")
 skew = us(s[:, steps, 4].reshape(-1, 4, s[:, steps, 4].shape[1]).max(1) - s[:, steps, 4].reshape(-1, 4, s[:, steps, 4].shape[1]).min(1)) if len(wg) % 4 == 0 else None
+
+cyc = s[:, 60, :6]
+if (cyc[:, 0] > 0).any():  # second form, timing build: inside stage 8 of step 5 (shader clocks)
+    c = cyc[cyc[:, 0] > 0]
+    names = ["wait for the stage's loads (vmcnt)", "workgroup barrier", "issue 6 LDS-DMA loads", "12 fragment reads until the first 5 landed", "32 MFMAs (+ staged waits)"]
+    for i, nm in enumerate(names):
+        d = c[:, i + 1] - c[:, i]
+        print(f"  stage: {nm:45s} mean {d.mean():7.0f}  p10 {np.percentile(d, 10):6.0f}  p90 {np.percentile(d, 90):6.0f} cycles")
