@@ -108,6 +108,8 @@ class TrainData:
         self._cols_d = torch.from_numpy(self.cols).to(self.device)
         self._negs_d = torch.zeros(len(self.rows), dtype=torch.int32, device=self.device)
         self._rows64 = None  # user id * item_num as int64 keys (device), built by the first negSampling()
+        self._pos_ptr = self._pos_col = None  # CSR of the users' sorted train positives (device), built by the first negSampling() on the GPU
+        self.neg_calls = 0  # negSampling() calls so far: the Philox offset of the next draw (the GPU sampler's whole state)
         self._user_pos_items: Optional[List[np.ndarray]] = None
 
     @property
@@ -128,12 +130,25 @@ class TrainData:
         return self._negs_host
 
     def negSampling(self) -> None:
-        """One uniform negative per interaction, re-drawn while (user, item) is a train interaction (DataHandler.py:164-176).  Rejection
-        rounds run four at a time as masked re-draws on the device (a round re-draws every slot and keeps the draw only where the current
-        negative is a train positive: the same distribution as re-drawing the rejected ones) with ONE host check per four rounds --
-        a check per round was a device -> host round trip each (3-4 per epoch)."""
+        """One uniform negative per interaction that is not a train interaction of its user (DataHandler.py:164-176).  On the GPU: dmm_neg_sample --
+        the r-th non-positive item of the user for a uniform r, the distribution the reference's rejection loop samples, in ONE launch with no
+        host round trip (the rejection rounds below needed a device -> host check per four rounds: a drained queue at the start of every epoch).
+        Draws are Philox(seed, call counter): `neg_calls` is the sampler's whole state."""
         items = int(self.config.data.item_num)
         n = len(self.rows)
+        if self._rows_d.is_cuda and n:
+            from . import _lib as L
+            if self._pos_ptr is None:  # CSR of the sorted train positives per user (from the sorted keys user * items + item)
+                U = int(self.config.data.user_num)
+                uk = torch.unique(self._keys)  # (sorted; duplicate interactions count once, as in the reference's dok matrix)
+                self._pos_ptr = torch.searchsorted(uk, torch.arange(U + 1, device=self.device, dtype=torch.int64) * items).contiguous()
+                self._pos_col = (uk % items).to(torch.int32).contiguous()
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+            L.call("dmm_neg_sample", L.ptr(self._pos_ptr), L.ptr(self._pos_col), L.ptr(self._rows_d), n, items, int(self.config.base.seed) + 17, self.neg_calls * n,
+                   L.ptr(out), L.stream())
+            self.neg_calls += 1
+            self._negs_d, self._negs_host = out, None
+            return
         if self._rows64 is None:
             self._rows64 = self._rows_d.long() * items
         last = self._keys.numel() - 1

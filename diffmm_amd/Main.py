@@ -182,7 +182,7 @@ class Coach:
               "xT_calls": int(DE._xT_calls), "world": int(self.world),
               "best": {k: float(v) for k, v in self.best.items()}, "his_max": [float(v) for v in self.his_max],
               "gen": {"train_loader": h.trainLoader.gen.get_state(), "diffusion_loader": h.diffusionLoader.gen.get_state(),
-                      "neg_sampler": h.trainData.gen.get_state(), "torch_cpu": torch.get_rng_state(),
+                      "neg_sampler": h.trainData.gen.get_state(), "neg_calls": int(h.trainData.neg_calls), "torch_cpu": torch.get_rng_state(),
                       "torch_device": torch.cuda.get_rng_state(self.device)}}  # the timestep draws use the global device generator
         if DE.t_gen is not None:
             sd["gen"]["timesteps"] = DE.t_gen.get_state()
@@ -214,8 +214,10 @@ class Coach:
         DE.w16_train_step = [-1] * DE.M  # ... and the training step's
         J._plans.clear()
         J._emb16_step = -1  # ... and so is the embedding table's bf16 gather copy
+        self._reg_cache = None  # ... and the cached sum(i_embs^2)
         h.trainLoader.gen.set_state(sd["gen"]["train_loader"].cpu()); h.diffusionLoader.gen.set_state(sd["gen"]["diffusion_loader"].cpu())
         h.trainData.gen.set_state(sd["gen"]["neg_sampler"].cpu())
+        h.trainData.neg_calls = int(sd["gen"].get("neg_calls", 0))
         torch.set_rng_state(sd["gen"]["torch_cpu"].cpu()); torch.cuda.set_rng_state(sd["gen"]["torch_device"].cpu(), self.device)
         if DE.t_gen is not None and "timesteps" in sd["gen"]:
             DE.t_gen.set_state(sd["gen"]["timesteps"].cpu())
@@ -253,7 +255,8 @@ class Coach:
         else:
             feats = [J.feat[m] if ish is None else J.feat[m][ish.i0:ish.i1] for m in range(M)]
         i_embs = J.i_embs  # (2D: one all-gather of the replicas' slices) -- does not move in this phase either
-        reg_term = DE.reg_term(i_embs)
+        cached = getattr(self, "_reg_cache", None)  # (step of the joint model it was computed at, value): read with the previous epoch's results
+        reg_term = cached[1] if (cached is not None and cached[0] == J.P.step and draws is None) else DE.reg_term(i_embs)
         dl = [0.0] * M
         step_means = []
         diff_batches = h.diffusionLoader.index_batches()  # index tensors only; rows are densified per batch, for the users this replica owns
@@ -271,14 +274,9 @@ class Coach:
                                   host_means=prec != 1)
             step_means.append(means)
         DE.end_phase()
-        if step_means and isinstance(step_means[0], torch.Tensor):  # bf16 mode: the steps left their means on the device -- one read for the whole phase
-            step_means = torch.stack(step_means).tolist()
-        for means in step_means:  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
-            tot = sum(means)
-            for m in range(M):
-                dl[m] += means[m]
-            for m in range(M):
-                dl[m] /= tot
+        # (bf16 mode: the steps left their loss means on the device; they are only logged, so they are read with the epoch's other results at the end
+        # -- no host round trip between the diffusion phase and the rebuild)
+        means_dev = torch.stack(step_means) if (step_means and isinstance(step_means[0], torch.Tensor)) else None
         t_diff = time.perf_counter()
 
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
@@ -324,7 +322,27 @@ class Coach:
             part = acc[nT + 1:nT + 3] if not getattr(J, "replicated_items", True) else acc[nT + 1:nT + 2]  # the items are sharded as well
             comm.all_reduce(part, group=self.group)
             acc = torch.cat([acc[:nT + 1], acc[nT + 1:nT + 2] + acc[nT + 2:nT + 3]])
-        a = acc.cpu().numpy()
+        # ONE transfer for everything the host wants of this epoch: the joint phase's loss sums, the diffusion phase's deferred loss means and
+        # sum(i_embs^2), which the NEXT epoch's diffusion phase needs as a host value (i_embs does not move until then)
+        parts = [acc]
+        if means_dev is not None:
+            parts.append(means_dev.reshape(-1).double())
+        reg_next = getattr(J, "replicated_items", True) and draws is None
+        if reg_next:
+            parts.append(DE.reg_term_launch(J.i_embs).double())
+        host = torch.cat(parts).cpu().numpy()
+        a = host[:acc.numel()]
+        if means_dev is not None:
+            step_means = host[acc.numel():acc.numel() + means_dev.numel()].reshape(-1, M).tolist()
+        if reg_next:
+            reg = float(DE.hp["reg"])
+            self._reg_cache = (J.P.step, reg * reg * float(host[-1]))
+        for means in step_means:  # logging quirk of Main.py:155,177-179: add, then divide the running sums by this batch's total
+            tot = sum(means)
+            for m in range(M):
+                dl[m] += means[m]
+            for m in range(M):
+                dl[m] /= tot
         if lay is not None:
             self.check_replicas()
         self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]

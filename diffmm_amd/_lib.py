@@ -139,6 +139,7 @@ _SIGS = {
     "dmm_mul_sigmoid_fwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "dmm_gate_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "dmm_tanh_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
+    "dmm_neg_sample": (C.c_int, [_P, _P, _P, _I, _I, _U64, _U64, _P, _P]),
     "dmm_tanh_bwd_fused": (C.c_int, [_P, _I, _I, _I, _I, _P]),
     "dmm_add_inplace": (C.c_int, [_P, _P, _F, _L, _P]),
     "dmm_colsum": (C.c_int, [_P, _L, _I, _I, _P, _P]),

@@ -640,6 +640,39 @@ extern "C" int dmm_colsum_add(const float* x, int64_t ldx, int rows, int cols, f
   return colsum_launch("dmm_colsum_add", x, ldx, rows, cols, out, false, stream);
 }
 
+// One uniform negative per interaction, exactly uniform over the items the user has NOT interacted with (TrainData.negSampling, DataHandler.py:159-169:
+// the distribution the reference's rejection loop samples), in one pass and without rejection: with the user's k positives p_0 < ... < p_{k-1}, draw
+// r uniformly from [0, I - k) and return the r-th non-positive item r + #{j : p_j - j <= r} (p_j - j, the number of non-positives below p_j, is
+// non-decreasing: a binary search).  Philox4x32-10 keyed by (seed, offset + slot): no generator state, no host round trip.
+__global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const int32_t* __restrict__ users,
+                                                          int n, int I, unsigned long long seed, unsigned long long offset, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int u = users[i];
+  const int64_t b = ptr[u];
+  const int k = (int)(ptr[u + 1] - b);
+  const int m = I - k;
+  if (m <= 0) { out[i] = 0; return; }  // (a user who interacted with every item has no negative: the reference would loop forever)
+  const uint4 rnd = dmm::philox4(seed, offset + (unsigned long long)i, 0x6e65u);
+  const unsigned long long wide = ((unsigned long long)rnd.x << 32) | rnd.y;
+  const int r = (int)(((unsigned __int128)wide * (unsigned long long)m) >> 64);  // uniform in [0, m) (bias < 2^-32)
+  int lo = 0, hi = k;  // first j with col[b + j] - j > r
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[b + mid] - mid <= r) lo = mid + 1; else hi = mid;
+  }
+  out[i] = r + lo;
+}
+
+extern "C" int dmm_neg_sample(const int64_t* ptr, const int32_t* col_sorted, const int32_t* users, int n, int items, uint64_t seed, uint64_t offset, int32_t* out,
+                              void* stream) {
+  DMM_CHECK_ARG(ptr && col_sorted && users && out && n > 0 && items > 0, "dmm_neg_sample: bad arguments");
+  hipLaunchKernelGGL(neg_sample_kernel, dim3(dmm::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ptr, col_sorted, users, n, items, (unsigned long long)seed,
+                     (unsigned long long)offset, out);
+  DMM_LAUNCH_CHECK("dmm_neg_sample");
+  return 0;
+}
+
 extern "C" int dmm_fill_zero(void* p, int64_t bytes, void* stream) {
   DMM_CHECK_ARG(p && bytes >= 0, "dmm_fill_zero: bad arguments");
   hipError_t err = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);

@@ -1181,6 +1181,15 @@ class DiffusionEngine:
             P.grad[:n0].copy_(buf[m, :n0])
             P.g("in_layers.0.weight")[:, I:I + te].copy_(buf[m, n0:].view(H, te))
 
+    def reg_term_launch(self, i_embs: Tensor) -> Tensor:
+        """The sum of squares behind reg_term() launched into a device scalar WITHOUT reading it: Main.Coach reads it with the epoch's other
+        results (one transfer) and hands reg * reg * value to the next epoch's diffusion phase -- i_embs does not move in between."""
+        if not hasattr(self, "_reg_buf"):
+            self._reg_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            self._reg_scratch = torch.zeros(int(L.lib().dmm_sumsq_scratch(i_embs.numel())), dtype=torch.float32, device=self.dev)
+        ops.sumsq(i_embs.reshape(-1), 1.0, self._reg_buf, self._reg_scratch)
+        return self._reg_buf
+
     def reg_term(self, i_embs: Tensor) -> float:
         """l2_reg_loss(reg, [i_embs]) * reg (Model.py:421,425) as a host value.  i_embs does not move during the diffusion phase (only the
         Denoise optimisers step there, Main.py:187-192), so the trainer computes this once per epoch."""

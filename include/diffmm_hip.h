@@ -369,6 +369,11 @@ int dmm_mul_sigmoid_fwd(const float* proj, const float* gate_pre_sig /*sigmoid a
                         void* stream); /* out = proj * gate */
 int dmm_gate_bwd(const float* dout, const float* proj, const float* gate, float* dproj /*out: dout*gate*/,
                  float* dgate_pre /*out: dout*proj*gate*(1-gate)*/, int64_t n, void* stream);
+/* TrainData.negSampling (DataHandler.py:159-169): out[i] = an item drawn uniformly from those user users[i] has no train interaction with -- the
+ * distribution of the reference's rejection loop, sampled without rejection (the r-th non-positive item by binary search over the user's sorted
+ * positives ptr / col_sorted, CSR over all users) from Philox4x32-10(seed, offset + i): one launch, no host round trip, no generator state. */
+int dmm_neg_sample(const int64_t* ptr, const int32_t* col_sorted, const int32_t* users, int n, int items, uint64_t seed, uint64_t offset, int32_t* out,
+                   void* stream);
 int dmm_tanh_bwd(const float* dh, const float* h, float* dpre, int64_t n, void* stream); /* dpre = dh * (1 - h^2) */
 /* The same product as the operands the layer-1 weight-gradient GEMMs want, in ONE pass over dh and h for up to 4 problems (the modalities of a
  * diffusion-training step): dpre = dh * (1 - h^2) is written only as bf16 rows d16 [rows, cols], as its bf16 transpose dT16 [cols, rows_pad]
