@@ -374,7 +374,7 @@ class DataHandler:
         # local blocks, fp32)
         self.spmm_vec = graph.spmm_operand_vec(U + I, int(cfg.base.latdim))
         self.torchBiAdj = None if sharded else graph.make_adjacency(g.trn_rows, g.trn_cols, U, I, int(cfg.base.latdim), dev, vec=self.spmm_vec,
-                                                                    task_len=graph.spmm_task_len(self.spmm_vec))
+                                                                    task_len=graph.spmm_task_len(self.spmm_vec), seg_mult=graph.BASE_SEG_MULT)
         self.trainData = TrainData(g.trn_rows, g.trn_cols, cfg, dev)
         self.trainLoader = BatchLoader(self.trainData, int(cfg.train.batch), True, dev, seed=int(cfg.base.seed) + 1)
         self.testData = TestData(g.tst_rows, g.tst_cols, g.trn_rows, g.trn_cols, U, I, dev)

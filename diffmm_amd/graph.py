@@ -76,7 +76,11 @@ def hub_keys(rowptr: np.ndarray, col: np.ndarray) -> np.ndarray:
     return key
 
 
-def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False, full: bool = False, row_key: Optional[np.ndarray] = None):
+BASE_SEG_MULT = 4  # the base graph's in-workgroup row limit (plan_tasks: seg_mult)
+
+
+def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool = False, full: bool = False, row_key: Optional[np.ndarray] = None,
+               seg_mult: int = 2):
     """Work list for dmm_spmm_csr_f32.
 
     A workgroup of the kernel holds G = 1024 / D task groups.  Rows with at most `task_len` non-zeros are one task.  Longer
@@ -86,6 +90,9 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
     one full workgroup each; the segment partials are added in order by a second pass.  Padding tasks have row = -1.
     row_key (optional, one integer per row): rows are scheduled in ascending key order (ties: row order) instead of row order -- any order
     is valid, a task names its row; see hub_keys.
+    seg_mult: a row stays inside ONE workgroup up to seg_mult G task_len non-zeros (default 2, the device planner's constant: dmm_graph_build
+    plans the rebuilt graphs bit-identically).  The BASE graph is planned on the host only and takes 4: at TikTok shape its longest rows (users of
+    degree 513-521 incl. the self loop) then need no segments -- and its launches no second (fix-up) launch, 4 of the joint step's 6.
     """
     G = 1024 // D
     if G * D != 1024 or D % 4:
@@ -93,7 +100,7 @@ def plan_tasks(rowptr: np.ndarray, D: int, task_len: int = 32, return_head: bool
     rp = np.asarray(rowptr, dtype=np.int64)
     n = rp.shape[0] - 1
     length = rp[1:] - rp[:-1]
-    seg_len = 2 * G * task_len
+    seg_len = int(seg_mult) * G * task_len
     k = np.maximum(1, -(-length // task_len))
     k = np.minimum(k, G)
     giant = np.flatnonzero(length > seg_len)
@@ -286,20 +293,20 @@ def spmm_task_len(vec: int) -> int:
 
 
 def make_adjacency(rows: np.ndarray, cols: np.ndarray, users: int, items: int, D: int, device, task_len: int = TASK_LEN,
-                   keep_host: bool = False, vec: int = 4, hub_order: bool = False) -> Adjacency:
-    """hub_order: schedule the rows by their hub (hub_keys) instead of by row id."""
+                   keep_host: bool = False, vec: int = 4, hub_order: bool = False, seg_mult: int = 2) -> Adjacency:
+    """hub_order: schedule the rows by their hub (hub_keys) instead of by row id.  seg_mult: plan_tasks."""
     rowptr, col, val = normalized_bipartite_csr(rows, cols, users, items)
-    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host, vec, row_key=hub_keys(rowptr, col) if hub_order else None)
+    return adjacency_from_csr(rowptr, col, val, D, device, task_len, keep_host, vec, row_key=hub_keys(rowptr, col) if hub_order else None, seg_mult=seg_mult)
 
 
 def adjacency_from_csr(rowptr, col, val, D: int, device, task_len: int = TASK_LEN, keep_host: bool = False, vec: int = 4,
-                       row_key: Optional[np.ndarray] = None) -> Adjacency:
+                       row_key: Optional[np.ndarray] = None, seg_mult: int = 2) -> Adjacency:
     """vec = 8 plans the work list for bf16 operands: a lane owns 8 columns, so a workgroup holds 2048 / D task groups -- the plan of
     width D / 2.  row_key: schedule the rows in key order (plan_tasks)."""
     if vec not in (4, 8):
         raise ValueError("vec must be 4 (fp32 operands) or 8 (bf16 operands)")
     Dp = D * 4 // vec
-    plan = plan_tasks(rowptr, Dp, task_len, full=True, row_key=row_key)
+    plan = plan_tasks(rowptr, Dp, task_len, full=True, row_key=row_key, seg_mult=seg_mult)
     tasks, head = plan.tasks, plan.head
     check_plan(rowptr, tasks, Dp)
     assert col.size == 0 or (col.min() >= 0 and col.max() < rowptr.shape[0] - 1), "column id out of range"
