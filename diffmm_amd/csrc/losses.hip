@@ -519,6 +519,19 @@ __device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // The other rows' log-sum-exp values (pass 1, interior tiles) are read by INLINE ASSEMBLY, up front: as C++ loads from the dynamic LDS array that
+  // also holds the LDS-DMA ring, the compiler cannot rule out that they alias an LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of them --
+  // every tile of the walk then drained the three-tiles-ahead prefetch (found in the round-4 disassembly).  Their wait is explicit, below.
+  typedef __attribute__((address_space(3))) const void* lds_cp;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v lv0 = {0.f, 0.f, 0.f, 0.f}, lv1 = lv0, lv2 = lv0, lv3 = lv0;
+  if (!own_lse && !CHECK) {
+    const unsigned la = (unsigned)(uintptr_t)(lds_cp)(ls_lds + k0 + 4 * fh);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(lv0) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(lv1) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(lv2) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(lv3) : "v"(la));
+  }
 #pragma unroll
   for (int ks = 0; ks < D / 16; ++ks) {
     const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
@@ -534,12 +547,10 @@ __device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[
   if (own_lse) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) l2[r] = l2_own;
-  } else if (!CHECK) {  // accumulator registers 4g .. 4g+3 hold four consecutive other rows: one 16-byte LDS read each
+  } else if (!CHECK) {  // accumulator registers 4g .. 4g+3 hold four consecutive other rows: one 16-byte LDS read each (issued above)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lv0), "+v"(lv1), "+v"(lv2), "+v"(lv3)::"memory");
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = *reinterpret_cast<const float4*>(ls_lds + k0 + 8 * g + 4 * fh);
-      l2[4 * g] = v.x; l2[4 * g + 1] = v.y; l2[4 * g + 2] = v.z; l2[4 * g + 3] = v.w;
-    }
+    for (int j = 0; j < 4; ++j) { l2[j] = lv0[j]; l2[4 + j] = lv1[j]; l2[8 + j] = lv2[j]; l2[12 + j] = lv3[j]; }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
