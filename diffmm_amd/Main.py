@@ -244,7 +244,13 @@ class Coach:
         dd = h.diffusionData
 
         import time
+        # phase boundaries as events on the stream (the host no longer waits at them: the diffusion phase's results are read with the epoch's last
+        # transfer), turned into phase_seconds after that transfer
+        cuda = dev.type == "cuda"
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if cuda else None
+        mark = (lambda i: ev[i].record()) if cuda else (lambda i: None)
         t_start = time.perf_counter()
+        mark(0)
         # ---- phase 1: diffusion training (Main.py:145-192) ----
         J._project(prec)  # Linear_m(E_m): constant during this phase (the encoder is not stepped here)
         ish = self.item_shard
@@ -278,6 +284,7 @@ class Coach:
         # -- no host round trip between the diffusion phase and the rebuild)
         means_dev = torch.stack(step_means) if (step_means and isinstance(step_means[0], torch.Tensor)) else None
         t_diff = time.perf_counter()
+        mark(1)
 
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
         if modal_adj_override is None:
@@ -311,6 +318,7 @@ class Coach:
         self.audio_adj = adjs[2] if M == 3 else None
         J.set_adjacency(self.base_adj, adjs)
         t_reb = time.perf_counter()
+        mark(2)
 
         # ---- phase 3: joint training (Main.py:292-377) ----
         acc = torch.zeros(J.loss_parts.numel(), dtype=torch.float64, device=dev)
@@ -330,6 +338,7 @@ class Coach:
         reg_next = getattr(J, "replicated_items", True) and draws is None
         if reg_next:
             parts.append(DE.reg_term_launch(J.i_embs).double())
+        mark(3)
         host = torch.cat(parts).cpu().numpy()
         a = host[:acc.numel()]
         if means_dev is not None:
@@ -345,7 +354,10 @@ class Coach:
                 dl[m] /= tot
         if lay is not None:
             self.check_replicas()
-        self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]
+        if cuda:  # GPU time between the boundaries (the stream is drained: the transfer above waited for it)
+            self.phase_seconds = [ev[i].elapsed_time(ev[i + 1]) * 1e-3 for i in range(3)]
+        else:
+            self.phase_seconds = [t_diff - t_start, t_reb - t_diff, time.perf_counter() - t_reb]
         cl, bpr, reg = float(a[:nT].sum()), float(a[nT]), float(a[nT + 1])
         result = {"Loss": (bpr + reg + cl) / train_steps, "BPR Loss": bpr / train_steps, "reg loss": reg / train_steps, "CL loss": cl / train_steps}
         for m, n in enumerate(modality_names(M)):

@@ -84,6 +84,7 @@ _SIGS = {
     "dmm_last_error_string": (C.c_char_p, []),
     "dmm_spmm_tasks_per_block": (C.c_int, [_I]),
     "dmm_spmm_csr_f32": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
+    "dmm_spmm_csr_bf16_hotlds": (C.c_int, [C.POINTER(SpmmProblem), _P, _I, _P, _I, _P]),
     "dmm_spmm_tasks_per_block_bf16": (C.c_int, [_I]),
     "dmm_spmm_csr_bf16": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),
     "dmm_spmm_epilogue_rows": (C.c_int, [C.POINTER(SpmmProblem), _I, _I, _P]),

@@ -322,6 +322,101 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const SpmmBatch batch) 
   spmm_fix_row<D>(P, blockIdx.x, part);
 }
 
+// ---- EXPERIMENT (round 4, VERDICT r3 item 9: "the LDS-staged ... variant north_star names, once, in-kernel, at 1M x 500k"): hot X rows in LDS --------
+// A column-BLOCKED pass (stage a block of X rows, sweep the rows that reference it) multiplies the Y traffic by the number of blocks at this density
+// (1e-5: priced in DESIGN 4.1, ~10 GB against 2.8 GB) -- what CAN be staged is the HEAD of the reference distribution: the n_hot most-referenced X rows
+// (Zipf items, heavy users) are copied into each persistent workgroup's LDS once; `col` carries them as -1 - slot, every other gather goes to global
+// memory as before.  1024-thread workgroups (four 256-thread quarters, each the original kernel's workgroup), one per CU (the hot table is 112 KiB);
+// bf16 operands, d = 64, plain problems (y = A x) only.  Measured at 1M x 500k (profiles/r4_spmm_hot_lds.txt): see DESIGN 4.1.
+constexpr int HOT_MAX = 896;
+__global__ __launch_bounds__(1024) void spmm_hot_lds_kernel(const dmm_spmm_problem P, const int32_t* __restrict__ hot_ids, int n_hot,
+                                                            const int32_t* __restrict__ col_hot, int nblocks) {
+  constexpr int D = 64, VEC = 8, LANES = D / VEC, G = 256 / LANES;  // 8 lanes per task, 32 tasks per quarter
+  extern __shared__ __attribute__((aligned(16))) char hsm[];
+  uint4* const hot = reinterpret_cast<uint4*>(hsm);                                   // [n_hot][8] 16-byte pieces
+  float* const part_all = reinterpret_cast<float*>(hsm + (size_t)HOT_MAX * D * 2);     // [4][256 * VEC]
+  const int quarter = threadIdx.x >> 8, tq = threadIdx.x & 255;
+  float* const part = part_all + quarter * 256 * VEC;
+  const int g = tq / LANES, l = tq % LANES;
+  const char* __restrict__ xlo = reinterpret_cast<const char*>(P.x_lo);
+  constexpr size_t ROWB = (size_t)D * 2;
+  for (int s = threadIdx.x / LANES; s < n_hot; s += 1024 / LANES) hot[s * LANES + l] = reinterpret_cast<const uint4*>(xlo + (size_t)hot_ids[s] * ROWB)[l];
+  __syncthreads();
+  const float* __restrict__ val = P.val;
+  for (int it = blockIdx.x; it * 4 < nblocks; it += gridDim.x) {
+    const int lb = it * 4 + quarter;
+    const bool live_q = lb < nblocks;
+    int4 task = make_int4(-1, 0, 0, 1);
+    if (live_q) task = reinterpret_cast<const int4*>(P.tasks)[lb * G + g];
+    const int row = task.x, beg = task.y, end = task.z;
+    const int run_len = task.w & 0xffff, run_pos = task.w >> 16;
+    Acc<VEC> acc;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
+    if (row >= 0) {
+      for (int base = beg; base < end; base += LANES) {
+        const int cnt = min(LANES, end - base);
+        int myc = 0;
+        float myv = 0.f;
+        if (l < cnt) { myc = col_hot[base + l]; myv = val[base + l]; }
+        uint4 x[8];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = __shfl(myc, j, LANES);
+          v[j] = __shfl(myv, j, LANES);
+          x[j] = make_uint4(0u, 0u, 0u, 0u);
+          if (j < cnt) x[j] = c < 0 ? hot[(-1 - c) * LANES + l] : reinterpret_cast<const uint4*>(xlo + (size_t)c * ROWB)[l];
+          else v[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned w[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            acc.v[2 * k] = fmaf(v[j], __uint_as_float(w[k] << 16), acc.v[2 * k]);
+            acc.v[2 * k + 1] = fmaf(v[j], __uint_as_float(w[k] & 0xffff0000u), acc.v[2 * k + 1]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part[j * 256 + tq] = acc.v[j];
+    __syncthreads();
+    if (row >= 0 && run_pos == 0) {
+      for (int t = 1; t < run_len; ++t) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc.v[j] += part[j * 256 + (g + t) * LANES + l];
+      }
+      if (lb < P.n_partial_blocks) store_f32<VEC>(P.partial + (size_t)lb * D + VEC * l, acc);
+      else store_f32<VEC>(P.y + (size_t)row * D + VEC * l, acc);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int dmm_spmm_csr_bf16_hotlds(const dmm_spmm_problem* prob, const int32_t* hot_ids, int n_hot, const int32_t* col_hot, int grid, void* stream) {
+  DMM_CHECK_ARG(prob && hot_ids && col_hot && n_hot >= 0 && n_hot <= dmm::HOT_MAX && grid > 0, "dmm_spmm_csr_bf16_hotlds: bad arguments (n_hot <= %d)", dmm::HOT_MAX);
+  const dmm_spmm_problem& p = *prob;
+  DMM_CHECK_ARG(p.tasks && p.val && p.x_lo && p.y && !p.x_hi && !p.c1 && !p.c2 && !p.y_pert && !p.raw && p.alpha == 1.0f && p.n_tasks % 32 == 0,
+                "dmm_spmm_csr_bf16_hotlds: one plain problem y = A x (bf16 x, fp32 y), d = 64");
+  DMM_CHECK_ARG(p.n_partial_blocks == 0 || (p.partial && p.fix && p.n_fix > 0), "dmm_spmm_csr_bf16_hotlds: giant rows need partial + fix buffers");
+  const size_t lds = (size_t)dmm::HOT_MAX * 64 * 2 + 4 * 256 * 8 * sizeof(float);
+  static bool once = [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dmm::spmm_hot_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return true; }();
+  (void)once;
+  hipLaunchKernelGGL(dmm::spmm_hot_lds_kernel, dim3(grid), dim3(1024), lds, (hipStream_t)stream, p, hot_ids, n_hot, col_hot, p.n_tasks / 32);
+  if (p.n_fix > 0) {
+    dmm::SpmmBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = 1; b.p[0] = p; b.p[0].fix_count = nullptr;
+    hipLaunchKernelGGL(dmm::spmm_fixup_kernel<64>, dim3(p.n_fix, 1), dim3(256), 0, (hipStream_t)stream, b);
+  }
+  DMM_LAUNCH_CHECK("dmm_spmm_csr_bf16_hotlds");
+  return 0;
+}
+}  // namespace dmm  (re-opened below)
+namespace dmm {
+
 template <int D, int VEC>
 static int launch(const SpmmBatch& b, int blocks, hipStream_t s) {
   // Measured at 1M users x 500k items, d = 64 (profiles/README.md): fp32 operands are bound by the bytes that miss L2 (450-465 us in

@@ -99,6 +99,11 @@ int dmm_spmm_csr_f32(const dmm_spmm_problem* probs /*host*/, int n_probs, int D,
  * same determinism; the in-kernel Philox draws are the ones dmm_spmm_csr_f32 makes. */
 int dmm_spmm_tasks_per_block_bf16(int D);
 int dmm_spmm_csr_bf16(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
+/* EXPERIMENT (not on the product path; tools/spmm_scale.py --variants bf16_x_hot): dmm_spmm_csr_bf16 for ONE plain problem y = A x at D = 64 with the
+ * n_hot (<= 896) most-referenced X rows staged in every persistent workgroup's LDS -- north_star's "LDS-staged embedding tiles" in the only form
+ * that does not multiply the Y traffic at this density.  hot_ids [n_hot]: the staged rows; col_hot [nnz]: the column array with row hot_ids[s]
+ * written as -1 - s; grid: persistent workgroups (1024 threads, one per CU).  Giant rows: partial + fix as usual (second launch). */
+int dmm_spmm_csr_bf16_hotlds(const dmm_spmm_problem* prob /*host*/, const int32_t* hot_ids, int n_hot, const int32_t* col_hot, int grid, void* stream);
 /* epilogue of the rows >= raw_from from the (all-reduced) raw partial rows; problems with raw == NULL are skipped */
 int dmm_spmm_epilogue_rows(const dmm_spmm_problem* probs /*host*/, int n_probs, int D, void* stream);
 

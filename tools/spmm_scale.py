@@ -20,6 +20,36 @@ def measure(g, D, dev, variant, reps=10, task_len=graph.TASK_LEN, order="row"):
         adj = graph.make_adjacency(g.trn_rows, g.trn_cols, g.users, g.items, D, dev, vec=vec, task_len=task_len, hub_order=order == "hub")
     X = torch.randn(adj.n, D, device=dev)
     Y = torch.empty_like(X)
+    if variant == "bf16_x_hot":  # EXPERIMENT: the n_hot most-referenced X rows staged in LDS (dmm_spmm_csr_bf16_hotlds); everything else as bf16_x
+        import ctypes as C
+        n_hot = int(os.environ.get("HOT_ROWS", 896))
+        col = adj.col.cpu().numpy()
+        refs = np.bincount(col, minlength=adj.n)
+        hot = np.argsort(-refs, kind="stable")[:n_hot].astype(np.int32)
+        slot = np.full(adj.n, -1, dtype=np.int64); slot[hot] = np.arange(n_hot)
+        col_hot = np.where(slot[col] >= 0, -1 - slot[col], col).astype(np.int32)
+        share = float(refs[hot].sum()) / float(refs.sum())
+        hot_d, col_d = torch.from_numpy(hot).to(dev), torch.from_numpy(col_hot).to(dev)
+        X16 = X.bfloat16()
+        op = ops.SpmmOp(adj, X16, y=Y)
+        if adj.n_partial_blocks:
+            op.p.partial = L.ptr(adj.partial_buffer(0))
+        grid = int(os.environ.get("HOT_GRID", 256))
+        run = lambda: L.call("dmm_spmm_csr_bf16_hotlds", C.byref(op.p), L.ptr(hot_d), n_hot, L.ptr(col_d), grid, L.stream())
+        run(); torch.cuda.synchronize()
+        ref = torch.empty_like(Y)
+        ops.spmm_batched([ops.SpmmOp(adj, X16, y=ref)]); torch.cuda.synchronize()
+        assert torch.equal(Y, ref), "hot-LDS variant must reproduce dmm_spmm_csr_bf16 bit for bit (same products, same order)"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        alg = adj.nnz * 8 + (adj.n + 1) * 4 + adj.n * D * (2 + 4)
+        return dict(variant=variant, hot_rows=n_hot, grid=grid, share_of_gathers_from_lds=share, users=g.users, items=g.items, nnz=adj.nnz, d=D,
+                    us_per_launch=t * 1e6, algorithmic_bytes=alg, algorithmic_GBps=alg / t / 1e9, frac_of_8TBps=alg / t / 8e12,
+                    gather_bytes=adj.nnz * D * 2, gather_GBps=adj.nnz * D * 2 / t / 1e9)
     if variant == "f32":
         op, s_x, s_y = ops.SpmmOp(adj, X, y=Y), 4, 4
     elif variant == "bf16_x":      # bf16 operand, fp32 output (what a layer followed by fp32 consumers writes)
