@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DMM_VERSION 300
+#define DMM_VERSION 400
 #define DMM_ERR_INVALID_ARG (-1)
 #define DMM_ERR_UNSUPPORTED (-2)
 #define DMM_SPMM_MAX_BATCH 4

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libdiffmm_hip.so does not export {name}"
     assert declared == set(L.exported_symbols()), f"ctypes table and header disagree: {declared ^ set(L.exported_symbols())}"
-    assert lib.dmm_version() == 300
+    assert lib.dmm_version() == 400
 
 
 def test_argument_validation_without_gpu():
