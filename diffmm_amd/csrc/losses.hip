@@ -5,6 +5,8 @@
 // InfoNCE never materialises the B x B logit matrix: one wave owns one anchor row, keeps its own normalised
 // row in LDS, streams the other view's rows out of L2 and folds them into an online log-sum-exp (forward) or
 // into a probability row held in LDS (backward).  [v1: fp32 VALU dot products; the MFMA tiling is the next step.]
+#include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -235,6 +237,18 @@ __global__ void infonce_bwd_kernel(const float* __restrict__ zhat, const float* 
 // place, is directly the A operand (X^T B form) of the MFMA that accumulates d(own) = sum_k P[k][own] * other[k][:] --
 // no LDS, no cross-lane traffic.  PREC = 3 adds the hi*lo + lo*hi products (operands split as hi + lo bf16).
 // ---------------------------------------------------------------------------------------------
+// XCD-aware unit mapping of the MFMA kernels below.  A "unit" is one walk target -- a term (forward) or a (term, pass) of the backward -- whose
+// workgroups all stream the same "other" view.  Workgroups go to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), each XCD with its own
+// 4 MB L2; with the natural (row block, term, pass) grid every XCD had all terms in flight at once -- 8 views of 1 MB each against 4 MB of L2, and the
+// walk ran at the Infinity Cache's rate (round 4: 512 MB of LDS-DMA per backward launch in 95-115 us).  Here unit u lives on XCD u % 8: the
+// workgroups resident on an XCD walk ONE view (two while a unit drains), which stays in that L2.
+struct UnitMap { int unit, sub; };
+__device__ __forceinline__ UnitMap xcd_unit(int per_unit) {
+  const int id = blockIdx.x, q = id >> 3;
+  return UnitMap{(q / per_unit) * 8 + (id & 7), q % per_unit};
+}
+static inline unsigned xcd_grid(int n_units, int per_unit) { return 8u * (unsigned)((n_units + 7) / 8) * (unsigned)per_unit; }
+
 // fragment (ks, h) of row r of a 32-row tile in the row-fragment order
 template <int D>
 __device__ __forceinline__ size_t frag_off(int slot, int tiles, int tile, int ks, int h, int r) {
@@ -262,14 +276,16 @@ __device__ __forceinline__ f32x16 logits_tile(const __bf16* __restrict__ hi, con
 }
 
 template <int D, int PREC>
-__global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, TermTable T, int B, float* __restrict__ lse,
+__global__ __launch_bounds__(256) void infonce_fwd_mfma_kernel(Bf16Pack pk, TermTable T, int n_terms, int B, float* __restrict__ lse,
                                                                 float* __restrict__ row_loss) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
   // One workgroup = 32 own rows; its 4 waves walk different quarters of the other view and merge their (max, sum, diagonal) through
   // LDS -- 4x the waves of a one-wave-per-row-block layout (which left one wave per SIMD, nothing to overlap its load latency with).
   __shared__ float part[4][32][3];
-  const int t = blockIdx.y;
-  const int i0 = blockIdx.x * 32;
+  const UnitMap um = xcd_unit((B + 31) >> 5);  // unit = term, sub = block of 32 own rows
+  if (um.unit >= n_terms) return;
+  const int t = um.unit;
+  const int i0 = um.sub * 32;
   const dmm_infonce_term term = T.t[t];
   const int Bp = pk.Bp;
   const int tiles = Bp >> 5;
@@ -509,48 +525,114 @@ __device__ __forceinline__ void inb_wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // conservative for shapes without a dedicated immediate
 }
 
-// One 32-row tile of the other view (LDS image S) against the wave's 32 own rows: logits (transposed: other index in the accumulator
-// registers, own index on the lane), probabilities minus the identity, and their product with the other rows added into `out`.
+// One 32-row tile of the other view (LDS image S) against the wave's 32 own rows, in two halves so that the walk can run them one tile apart
+// (the logits of tile k + 1 are on the matrix pipe while the VALU turns tile k's into probabilities):
+//  * tile_logits: logits, transposed (other index in the accumulator registers, own index on the lane);
+//  * inb_apply:   probabilities minus the identity and their product with the other rows, added into `out`.
 // CHECK = false drops the per-element bounds and diagonal tests (two compares and two selects per element of a VALU-bound loop).
-template <int D, int PREC, bool CHECK>
-__device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16], f32x16 (&out)[D / 32], int k0,
-                                         int oidx, int B, float c1, bool own_lse, float l2_own, const float* ls_lds, int fr, int fh) {
+// The LDS fragments of a tile as values, so that a step can read ALL of them right behind its barrier -- one LDS round trip per step instead of
+// five (round-4 ablation: with the exponentials AND every MFMA removed the backward still took 82 of its 92 us; without the LDS reads 23 us: the
+// walk was bound by the latency of its serial LDS round trips, not by the matrix or the transcendental rate).
+template <int D, int PREC>
+struct SFrags { bf16x8 h[D / 16], l[PREC == 3 ? D / 16 : 1]; };        // row-fragment blocks: the logits' A operand
+template <int D, int PREC>
+struct TFrags { bf16x8 h[2][D / 32], l[PREC == 3 ? 2 : 1][D / 32]; };  // k-packed transposed blocks: the product's B operand
+template <int D, int PREC, int LO = 2>  // LO: index of the `lo` block within the tile image
+__device__ __forceinline__ SFrags<D, PREC> load_sfrags(const __bf16* S, int fr, int fh) {
   constexpr int BLK = 32 * D;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // The other rows' log-sum-exp values (pass 1, interior tiles) are read by INLINE ASSEMBLY, up front: as C++ loads from the dynamic LDS array that
-  // also holds the LDS-DMA ring, the compiler cannot rule out that they alias an LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of them --
-  // every tile of the walk then drained the three-tiles-ahead prefetch (found in the round-4 disassembly).  Their wait is explicit, below.
-  typedef __attribute__((address_space(3))) const void* lds_cp;
-  typedef float f32x4v __attribute__((ext_vector_type(4)));
-  f32x4v lv0 = {0.f, 0.f, 0.f, 0.f}, lv1 = lv0, lv2 = lv0, lv3 = lv0;
-  if (!own_lse && !CHECK) {
-    const unsigned la = (unsigned)(uintptr_t)(lds_cp)(ls_lds + k0 + 4 * fh);
-    asm volatile("ds_read_b128 %0, %1" : "=v"(lv0) : "v"(la));
-    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(lv1) : "v"(la));
-    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(lv2) : "v"(la));
-    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(lv3) : "v"(la));
-  }
+  SFrags<D, PREC> f;
 #pragma unroll
   for (int ks = 0; ks < D / 16; ++ks) {
     const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
-    const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(S + fo);
-    if (PREC == 3) {
-      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(S + 2 * BLK + fo);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, own_h[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_l[ks], acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_h[ks], acc, 0, 0, 0);
+    f.h[ks] = *reinterpret_cast<const bf16x8*>(S + fo);
+    if (PREC == 3) f.l[ks] = *reinterpret_cast<const bf16x8*>(S + LO * BLK + fo);
   }
+  return f;
+}
+template <int D, int PREC>
+__device__ __forceinline__ TFrags<D, PREC> load_tfrags(const __bf16* S, int fr, int fh) {
+  constexpr int BLK = 32 * D;
+  TFrags<D, PREC> f;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb) {
+      const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
+      f.h[s2][cb] = *reinterpret_cast<const bf16x8*>(S + BLK + to);
+      if (PREC == 3) f.l[s2][cb] = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
+    }
+  return f;
+}
+template <int D, int PREC>
+__device__ __forceinline__ f32x16 logits_from(const SFrags<D, PREC>& f, const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    if (PREC == 3) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l[ks], own_h[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h[ks], own_l[ks], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h[ks], own_h[ks], acc, 0, 0, 0);
+  }
+  return acc;
+}
+template <int D, int PREC, int LO = 2>
+__device__ __forceinline__ f32x16 tile_logits(const __bf16* S, const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16], int fr, int fh) {
+  return logits_from<D, PREC>(load_sfrags<D, PREC, LO>(S, fr, fh), own_h, own_l);
+}
+// P (16 probabilities per lane, accumulator order) times the tile's other rows, added into `out`
+template <int D, int PREC>
+__device__ __forceinline__ void product_from(const TFrags<D, PREC>& f, const float (&p)[16], f32x16 (&out)[D / 32]) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {  // k-step s2 of the output MFMA covers tile rows 16 s2 .. 16 s2 + 15 in accumulator order
+    bf16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ph[j] = (__bf16)p[8 * s2 + j];
+      if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb) {
+      if (PREC == 3) {
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, f.h[s2][cb], out[cb], 0, 0, 0);
+        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, f.l[s2][cb], out[cb], 0, 0, 0);
+      }
+      out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, f.h[s2][cb], out[cb], 0, 0, 0);
+    }
+  }
+}
+
+// The other rows' log-sum-exp values (pass 1, interior tiles) are read by INLINE ASSEMBLY: as C++ loads from the dynamic LDS array that also holds
+// the LDS-DMA ring, the compiler cannot rule out that they alias an LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of them -- every tile of
+// the walk then drained the prefetch (found in the round-4 disassembly).  lse_issue starts the reads, lse_wait is their explicit wait.
+// `ls_lds` is indexed by the other row (the caller passes the split's vector shifted so that the view's row index applies).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+struct LseRegs { f32x4v v0, v1, v2, v3; };
+__device__ __forceinline__ LseRegs lse_issue(const float* ls_lds, int k0, int fh) {
+  typedef __attribute__((address_space(3))) const void* lds_cp;
+  LseRegs r;
+  const unsigned la = (unsigned)(uintptr_t)(lds_cp)(ls_lds + k0 + 4 * fh);
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r.v0) : "v"(la));
+  asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(r.v1) : "v"(la));
+  asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(r.v2) : "v"(la));
+  asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(r.v3) : "v"(la));
+  return r;
+}
+__device__ __forceinline__ void lse_wait(LseRegs& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3)::"memory"); }
+
+// probabilities minus the identity, times the other rows (fragments `tf`), added into `out`; `lr`: lse_issue's registers (plain pass-1 tiles only)
+template <int D, int PREC, bool CHECK, bool own_lse>
+__device__ __forceinline__ void inb_apply(const TFrags<D, PREC>& tf, const f32x16& acc, f32x16 (&out)[D / 32], int k0, int oidx, int B, float c1,
+                                          float l2_own, const float* ls_lds, const LseRegs& lr, int fh) {
   float p[16], l2[16];
   if (own_lse) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) l2[r] = l2_own;
-  } else if (!CHECK) {  // accumulator registers 4g .. 4g+3 hold four consecutive other rows: one 16-byte LDS read each (issued above)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lv0), "+v"(lv1), "+v"(lv2), "+v"(lv3)::"memory");
+  } else if (!CHECK) {  // accumulator registers 4g .. 4g+3 hold four consecutive other rows: one 16-byte LDS read each (waited for by the caller)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { l2[j] = lv0[j]; l2[4 + j] = lv1[j]; l2[8 + j] = lv2[j]; l2[12 + j] = lv3[j]; }
+    for (int j = 0; j < 4; ++j) { l2[j] = lr.v0[j]; l2[4 + j] = lr.v1[j]; l2[8 + j] = lr.v2[j]; l2[12 + j] = lr.v3[j]; }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -564,42 +646,34 @@ __device__ __forceinline__ void inb_tile(const __bf16* S, const bf16x8 (&own_h)[
     p[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c1, -l2[r]));
     if (CHECK) p[r] = kidx < B ? p[r] - (kidx == oidx ? 1.f : 0.f) : 0.f;
   }
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {  // k-step s2 of the output MFMA covers tile rows 16 s2 .. 16 s2 + 15 in accumulator order
-    bf16x8 ph, pl;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ph[j] = (__bf16)p[8 * s2 + j];
-      if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
-    }
-#pragma unroll
-    for (int cb = 0; cb < D / 32; ++cb) {
-      const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
-      const bf16x8 t_h = *reinterpret_cast<const bf16x8*>(S + BLK + to);
-      if (PREC == 3) {
-        const bf16x8 t_l = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
-        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, t_h, out[cb], 0, 0, 0);
-        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_l, out[cb], 0, 0, 0);
-      }
-      out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_h, out[cb], 0, 0, 0);
-    }
-  }
+  product_from<D, PREC>(tf, p, out);
 }
 
+// R = own 32-row tiles per wave.  R = 2 (d <= 64, one bf16 pass): every LDS fragment, lse value, LDS-DMA piece and barrier of a step serves 2048
+// logits per wave instead of 1024 -- the walk is bound by its per-step latencies (barrier across four SIMDs, LDS round trip, the dependent MFMA
+// chain: round-4 stamps and ablations in DESIGN 4.3), not by the matrix, transcendental or LDS rates, so the lever is more work per step.
 template <int D, int PREC>
-__global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int B,
+struct InbRows { static constexpr int R = (D <= 64 && PREC == 1) ? 2 : 1; };
+
+template <int D, int PREC>
+__global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const float* __restrict__ lse, TermTable T, int n_terms, int n_pass, int B,
                                                                float* __restrict__ dzhat, int pass_base, int ksplit) {
   using Sh = InbShape<D, PREC>;
-  constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS;
+  constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS, R = InbRows<D, PREC>::R;
   static_assert(TILE % (8 * 256) == 0, "tile must split into whole 16-byte pieces per lane");
   extern __shared__ __attribute__((aligned(16))) __bf16 sm_oth[];  // [NS][TILE]
   typedef __attribute__((address_space(3))) void* lds_p;
   typedef const __attribute__((address_space(1))) void* gbl_p;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
-  // blockIdx.z = pass * ksplit + split: a split walks its share of the other view's tiles (the probabilities are normalised by lse, so the
-  // splits' partial products simply add: one more atomicAdd per output element and split, twice the waves in flight per SIMD)
-  const int t = blockIdx.y, pass = (int)blockIdx.z / ksplit + pass_base, split = (int)blockIdx.z % ksplit;
-  const int o0 = (blockIdx.x * 4 + wave) * 32;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  // (wave index through readfirstlane: the walk's counters, the own tile's index and the LDS-DMA source block are then scalar -- as a vector
+  // value the compiler ran the walk under exec-mask control flow)
+  // unit = pass * n_terms + term (one per XCD at a time, see xcd_unit), sub = split * row blocks + row block; a split walks its share of the other
+  // view's tiles (the probabilities are normalised by lse, so the splits' partial products simply add: one more atomicAdd per output element and split)
+  const int nblk = (B + 128 * R - 1) / (128 * R);
+  const UnitMap um = xcd_unit(nblk * ksplit);
+  if (um.unit >= n_terms * n_pass) return;  // (whole workgroups, before the first barrier)
+  const int t = um.unit % n_terms, pass = um.unit / n_terms + pass_base, split = um.sub / nblk;
+  const int o0 = ((um.sub % nblk) * 4 + wave) * 32 * R;
   const bool active = o0 < B;
   const dmm_infonce_term term = T.t[t];
   const int own_slot = pass == 0 ? term.a : term.b, oth_slot = pass == 0 ? term.b : term.a;
@@ -607,89 +681,180 @@ __global__ __launch_bounds__(256) void infonce_bwd_lds_kernel(Bf16Pack pk, const
   const int kt_beg = (int)((long long)tiles * split / ksplit), kt_end = (int)((long long)tiles * (split + 1) / ksplit);
   const size_t oth_base = (size_t)oth_slot * tiles * BLK;
 
-  // piece i of a tile: 16 bytes per lane, pieces of one wave-instruction contiguous (what LDS-DMA writes: base + 16 * lane)
+  // piece i of a tile: 16 bytes per lane, pieces of one wave-instruction contiguous (what LDS-DMA writes: base + 16 * lane); a wave's 64 chunks lie in
+  // one block (64 | BLK / 8), so the source of piece i is a wave-uniform base (chosen once, outside the walk) + k * BLK + 8 * lane
+  const __bf16* srcb[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c0 = i * 256 + wave * 64, blk = c0 / (BLK / 8);
+    srcb[i] = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)(c0 % (BLK / 8)) * 8;
+  }
   auto issue = [&](int kt, int stage) {
     const int k = kt < tiles ? kt : tiles - 1;  // past the end: a redundant copy of the last tile (keeps the DMA count per iteration fixed)
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c0 = i * 256 + wave * 64;        // first chunk of this wave-instruction
-      const int c = c0 + lane, blk = c / (BLK / 8), w = c % (BLK / 8);
-      const __bf16* src = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)k * BLK + (size_t)w * 8;
-      __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(sm_oth + (size_t)stage * TILE + (size_t)c0 * 8), 16, 0, 0);
-    }
+    for (int i = 0; i < PER; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_p)(srcb[i] + (size_t)k * BLK + (size_t)lane * 8),
+                                       (lds_p)(sm_oth + (size_t)stage * TILE + (size_t)(i * 256 + wave * 64) * 8), 16, 0, 0);
   };
+  static_assert((BLK / 8) % 64 == 0, "a wave-instruction of the LDS-DMA must not straddle two blocks");
 
-  bf16x8 own_h[D / 16], own_l[D / 16];
+  // own tiles otile .. otile + R - 1 (a tile past the view: the last one again -- its rows are not written)
+  bf16x8 own_h[R][D / 16], own_l[R][D / 16];
   const int otile = active ? (o0 >> 5) : 0;
 #pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) {
-    const size_t o = frag_off<D>(own_slot, tiles, otile, ks, fh, fr);
-    own_h[ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
-    if (PREC == 3) own_l[ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
-  }
-  f32x16 out[D / 32];
+  for (int q = 0; q < R; ++q)
 #pragma unroll
-  for (int cb = 0; cb < D / 32; ++cb)
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const size_t o = frag_off<D>(own_slot, tiles, otile + q < tiles ? otile + q : tiles - 1, ks, fh, fr);
+      own_h[q][ks] = *reinterpret_cast<const bf16x8*>(pk.hi + o);
+      if (PREC == 3) own_l[q][ks] = *reinterpret_cast<const bf16x8*>(pk.lo + o);
+    }
+  f32x16 out[R][D / 32];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[cb][r] = 0.f;
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[q][cb][r] = 0.f;
   const float inv_t = 1.0f / term.temp;
   const float* __restrict__ ls = lse + (size_t)t * B;
-  const int oidx = o0 + fr;
-  const float lse_own = ls[oidx < B ? oidx : B - 1];
-  // pass 1 indexes the log-sum-exp by the OTHER row: the term's whole lse vector goes to LDS once, so that the walk issues no
-  // register loads (a waited register load would drain the LDS-DMA queue: vector-memory operations retire in order)
-  float* const ls_lds = reinterpret_cast<float*>(sm_oth + (size_t)NS * TILE);
   constexpr float LOG2E = 1.4426950408889634f;
-  const float c1 = inv_t * LOG2E, l2_own = lse_own * LOG2E;  // p = exp(s / temp - lse) = exp2(s * c1 - lse * log2 e): one fma + one v_exp
+  const float c1 = inv_t * LOG2E;  // p = exp(s / temp - lse) = exp2(s * c1 - lse * log2 e): one fma + one v_exp
+  int oidx[R];
+  float l2_own[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    oidx[q] = o0 + 32 * q + fr;
+    l2_own[q] = ls[oidx[q] < B ? oidx[q] : B - 1] * LOG2E;
+  }
+  // pass 1 indexes the log-sum-exp by the OTHER row: the rows this split walks go to LDS once, so that the walk issues no register loads (a
+  // waited register load would drain the LDS-DMA queue: vector-memory operations retire in order); indexed by the view's row through a shifted base
+  float* const ls_lds = reinterpret_cast<float*>(sm_oth + (size_t)NS * TILE) - (size_t)kt_beg * 32;
   if (pass == 1)
-    for (int i = tid; i < B; i += 256) ls_lds[i] = ls[i] * LOG2E;
+    for (int i = kt_beg * 32 + tid; i < kt_end * 32; i += 256) ls_lds[i] = ls[i < B ? i : B - 1] * LOG2E;
   // the register loads above are out of the counted window, and the LDS stores have landed before the first (raw) barrier
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j) issue(kt_beg + j, j);
-  for (int kt = kt_beg; kt < kt_end; ++kt) {
-    const int rel = kt - kt_beg;
-    inb_wait_vmcnt<(NS - 2) * PER>();  // this wave's pieces of tile kt have landed (the NS - 2 younger tiles stay in flight)
-    asm volatile("s_barrier" ::: "memory");  // ... every wave's pieces; and every wave is done reading tile kt - 1
-    issue(kt + NS - 1, (rel + NS - 1) % NS);  // into the stage tile kt - 1 occupied
-    const __bf16* S = sm_oth + (size_t)(rel % NS) * TILE;
-    if (active) {
-      // bounds / diagonal handling only where it can matter: the tile that holds the wave's own rows and the (padded) last tile
-      if (kt == otile || kt == tiles - 1) inb_tile<D, PREC, true>(S, own_h, own_l, out, kt * 32, oidx, B, c1, pass == 0, l2_own, ls_lds, fr, fh);
-      else inb_tile<D, PREC, false>(S, own_h, own_l, out, kt * 32, oidx, B, c1, pass == 0, l2_own, ls_lds, fr, fh);
+  // One step of the walk.  Every wave of the workgroup runs the same NUMBER of steps (the raw barrier counts them), each in the form its own
+  // rows need.  Bounds / diagonal handling only where it can matter -- the tiles that hold the wave's own rows and the (padded) last tile -- and as
+  // SEPARATE loops: with `if (special) tile<true> else tile<false>` inside one loop the compiler merged the two bodies (round-4 disassembly: the 64
+  // compares / selects of the checked form and a 48-instruction AGPR <-> VGPR shuffle of `out` ran on every tile, next to 16 v_exp + 16 fma).
+  // PIPE (ring of >= 3 stages): a step issues the logits MFMAs of tile kt + 1 and THEN turns tile kt's (formed one step earlier) into
+  // probabilities; EARLY: every LDS read of the step is issued right behind the barrier (one LDS round trip per step).
+  constexpr bool PIPE = NS >= 3;
+  constexpr bool EARLY = D <= 64;
+  auto walk = [&](auto own_lse) {  // own_lse: pass 0, the probabilities are normalised by the OWN row's log-sum-exp (a lane constant)
+    int kt = kt_beg;
+    f32x16 acc_a[R], acc_b[R];  // PIPE: logits of the current tile / of the next one (the roles alternate: no copy in the plain loop)
+    if (PIPE) {
+      inb_wait_vmcnt<(NS - 2) * PER>();
+      asm volatile("s_barrier" ::: "memory");
+      const SFrags<D, PREC> sf = load_sfrags<D, PREC>(sm_oth, fr, fh);
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc_a[q] = logits_from<D, PREC>(sf, own_h[q], own_l[q]);
     }
-  }
+    auto step = [&](auto checked, f32x16 (&cur)[R], f32x16 (&nxt)[R]) {
+      constexpr bool CHK = decltype(checked)::value, OWN = decltype(own_lse)::value;
+      const int rel = kt - kt_beg;
+      // this wave's pieces of tile kt (PIPE: kt + 1) have landed; the younger tiles stay in flight
+      inb_wait_vmcnt<(PIPE ? NS - 3 : NS - 2) * PER>();
+      asm volatile("s_barrier" ::: "memory");  // ... every wave's pieces; and every wave is done reading tile kt - 1
+      issue(kt + NS - 1, (rel + NS - 1) % NS);  // into the stage tile kt - 1 occupied
+      const __bf16* S = sm_oth + (size_t)(rel % NS) * TILE;
+      LseRegs lr{};
+      if (PIPE) {
+        // in the order of use: next tile's row fragments, the lse values, this tile's transposed fragments
+        const SFrags<D, PREC> sf = load_sfrags<D, PREC>(sm_oth + (size_t)((rel + 1) % NS) * TILE, fr, fh);
+        if (!OWN && !CHK) lr = lse_issue(ls_lds, kt * 32, fh);
+        const TFrags<D, PREC> tf = load_tfrags<D, PREC>(S, fr, fh);
+        if (EARLY) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < R; ++q) nxt[q] = logits_from<D, PREC>(sf, own_h[q], own_l[q]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+          if (!OWN && !CHK) lse_wait(lr);
+#pragma unroll
+          for (int q = 0; q < R; ++q) inb_apply<D, PREC, CHK, OWN>(tf, cur[q], out[q], kt * 32, oidx[q], B, c1, l2_own[q], ls_lds, lr, fh);
+        }
+      } else if (active) {
+        const SFrags<D, PREC> sf = load_sfrags<D, PREC>(S, fr, fh);
+        if (!OWN && !CHK) { lr = lse_issue(ls_lds, kt * 32, fh); lse_wait(lr); }
+        const TFrags<D, PREC> tf = load_tfrags<D, PREC>(S, fr, fh);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          cur[q] = logits_from<D, PREC>(sf, own_h[q], own_l[q]);
+          inb_apply<D, PREC, CHK, OWN>(tf, cur[q], out[q], kt * 32, oidx[q], B, c1, l2_own[q], ls_lds, lr, fh);
+        }
+      }
+      ++kt;
+    };
+    auto copy = [&] {
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc_a[q] = acc_b[q];
+    };
+#pragma unroll 1
+    for (int phase = 0; phase <= R; ++phase) {
+      // phases 0 .. R - 1: plain tiles up to own tile `phase`, then that tile checked (a split that starts behind it checks its first tile instead:
+      // harmless); phase R: plain tiles up to the last tile of the view, then that one checked if this split holds it
+      const int special = phase < R ? otile + phase : tiles - 1;
+      const int upto = special < kt ? kt : (special > kt_end ? kt_end : special);
+#pragma unroll 1
+      while (kt + 1 < upto) {
+        step(std::false_type{}, acc_a, acc_b);
+        step(std::false_type{}, acc_b, acc_a);
+      }
+      if (kt < upto) {
+        step(std::false_type{}, acc_a, acc_b);
+        copy();
+      }
+      if (kt < kt_end) {
+        step(std::true_type{}, acc_a, acc_b);
+        copy();
+      }
+    }
+  };
+  if (pass == 0) walk(std::true_type{});
+  else walk(std::false_type{});
+  // (every wave has taken kt_end - kt_beg steps: the last phase ends at min(max(tiles - 1, kt), kt_end) and its checked step takes the last tile if it
+  // is in range)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing redundant copies have landed before the workgroup's LDS goes away
   if (!active) return;
   const float coef = term.weight * inv_t / (float)B;
 #pragma unroll
-  for (int cb = 0; cb < D / 32; ++cb)
+  for (int q = 0; q < R; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = o0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (row < B) atomicAdd(dzhat + ((size_t)own_slot * B + row) * D + cb * 32 + fr, out[cb][r] * coef);
-    }
+    for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = o0 + 32 * q + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row < B) atomicAdd(dzhat + ((size_t)own_slot * B + row) * D + cb * 32 + fr, out[q][cb][r] * coef);
+      }
 }
 
-constexpr int INB_MAX_B = 8192;  // the term's lse vector (4 B per batch row) sits in LDS behind the ring: 32 KiB at most
+constexpr int INB_MAX_B = 8192;  // the lse values of a split's rows (4 B per batch row) sit in LDS behind the ring: 32 KiB at most
 template <int D, int PREC>
-static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat, int pass_base = 0) {
-  // walk splits per (term, pass): 1 / 2 / 4 / 8 measured 123.5 / 117.6 / 113.8 / ~125 us at B = 4096, 8 terms (more waves per SIMD against more atomics)
-  // (B = 8192, d = 256, 8 terms, where the launch has 1024 workgroups without any split: 1 / 2 / 4 / 8 -> 2277 / 2315 / 2395 / 2558 us: the split is
-  // sized to about 1024 workgroups per launch)
+static void inb_launch(int n_terms, int n_pass, hipStream_t s, Bf16Pack pk, const float* lse, const TermTable& T, int B, float* dzhat, int pass_base = 0) {
+  // walk splits per (term, pass).  Before the XCD-aware unit mapping: 1 / 2 / 4 / 8 measured 123.5 / 117.6 / 113.8 / ~125 us at B = 4096, 8 terms.
+  // Now a unit's workgroups should fill the XCD that owns it once: row blocks x splits = what the XCD holds.
   static const int forced = [] { const char* e = getenv("DMM_INFONCE_LDS_KSPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
-  const int wgs = (int)(grid.x * grid.y * grid.z);
-  const int ksplit = forced ? forced : (wgs >= 1024 ? 1 : (wgs > 512 ? 2 : 4));  // (grid = [B / 128, terms, 2 passes]: 512 at the bench shape)
-  grid.z *= ksplit;
+  constexpr int R = InbRows<D, PREC>::R;
+  const int nblk = cdiv(B, 128 * R), tiles = (B + 31) >> 5;
+  // workgroups an XCD holds at once: 32 CUs x min(registers: 4 / R, LDS: ring + ~a quarter of the lse vector)
+  const int per_cu = std::max(1, std::min(4 / R, (int)((160 * 1024) / (InbShape<D, PREC>::LDS_BYTES + (size_t)cdiv(tiles, 4) * 128))));
+  int ksplit = forced ? forced : (16 * per_cu + nblk / 2) / nblk;  // (B = 4096, d = 64: 1 / 2 / 3 / 4 / 6 splits -> 100 / 88 / 93 / 99 / 109 us)
+  ksplit = ksplit < 1 ? 1 : (ksplit > 8 ? 8 : ksplit);
+  if (ksplit > tiles) ksplit = tiles;
   static const bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_bwd_lds_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               InbShape<D, PREC>::LDS_BYTES + INB_MAX_B * 4);
     return true;
   }();
   (void)once;
-  const size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES + (size_t)((B + 3) & ~3) * 4;
-  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, lse, T, B, dzhat, pass_base, ksplit);
+  const size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES + (size_t)cdiv(tiles, ksplit) * 32 * 4;  // ring + the lse values of one split's rows
+  hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, PREC>), dim3(xcd_grid(n_terms * n_pass, nblk * ksplit)), dim3(256), lds_bytes, s, pk, lse, T, n_terms,
+                     n_pass, B, dzhat, pass_base, ksplit);
 }
 
 // ---- forward + the anchor-side backward in one walk (unit-norm rows) -------------------------------------------------------------------
@@ -698,24 +863,22 @@ static void inb_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* lse, 
 // the forward's output), the raw diagonal logit (-> row_loss_i), and N_i = sum_k p'_ik other_k (the MFMA product the backward's pass 0
 // accumulates) -> d anchor_i = (N_i / L_i - other_i) w / (temp B): the forward kernel and HALF of the backward (its pass 0 recomputed every
 // logit and exponential) become one kernel; the backward keeps only pass 1 (gradient w.r.t. the other view, which needs lse_i first).
-template <int D, int PREC, bool CHECK>
-__device__ __forceinline__ void inf_tile(const __bf16* S, const bf16x8 (&own_h)[D / 16], const bf16x8 (&own_l)[D / 16], f32x16 (&out)[D / 32], int k0,
-                                         int oidx, int B, float c1, float& lsum, float& diag, int fr, int fh) {
-  constexpr int BLK = 32 * D;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) {
-    const int fo = ((ks * 2 + fh) * 32 + fr) * 8;
-    const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(S + fo);
-    if (PREC == 3) {
-      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(S + 2 * BLK + fo);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, own_h[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_l[ks], acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, own_h[ks], acc, 0, 0, 0);
-  }
+// PRODUCT = false is the forward alone (lse, row loss): the same walk without the product, over tiles that hold only the row-fragment blocks.
+template <int D, int PREC, bool PRODUCT>
+struct WalkShape {
+  static constexpr int NB = (PRODUCT ? 2 : 1) * (PREC == 3 ? 2 : 1);  // PRODUCT: hi, hiT (, lo, loT) as InbShape; else hi (, lo)
+  static constexpr int BLK = 32 * D;
+  static constexpr int LO = PRODUCT ? 2 : 1;      // block index of `lo`
+  static constexpr int TILE = NB * BLK;
+  static constexpr int PER = TILE / 8 / 256;
+  static constexpr int NS = TILE * 2 * 4 <= 131072 ? 4 : (TILE * 2 * 3 <= 131072 ? 3 : 2);
+  static constexpr int LDS_BYTES = NS * TILE * 2;
+  static constexpr bool OK = TILE % (8 * 256) == 0 && NS >= 3;  // whole LDS-DMA pieces per lane, and a ring deep enough for the pipelined walk
+};
+
+template <int D, int PREC, bool CHECK, bool PRODUCT>
+__device__ __forceinline__ void inf_apply(const TFrags<D, PREC>& tf, const f32x16& acc, f32x16 (&out)[D / 32], int k0, int oidx, int B, float c1, float& lsum,
+                                          float& diag, int fh) {
   float p[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -727,53 +890,41 @@ __device__ __forceinline__ void inf_tile(const __bf16* S, const bf16x8 (&own_h)[
     }
     lsum += p[r];
   }
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    bf16x8 ph, pl;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ph[j] = (__bf16)p[8 * s2 + j];
-      if (PREC == 3) pl[j] = (__bf16)(p[8 * s2 + j] - (float)ph[j]);
-    }
-#pragma unroll
-    for (int cb = 0; cb < D / 32; ++cb) {
-      const int to = ((s2 * 2 + fh) * D + cb * 32 + fr) * 8;
-      const bf16x8 t_h = *reinterpret_cast<const bf16x8*>(S + BLK + to);
-      if (PREC == 3) {
-        const bf16x8 t_l = *reinterpret_cast<const bf16x8*>(S + 3 * BLK + to);
-        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, t_h, out[cb], 0, 0, 0);
-        out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_l, out[cb], 0, 0, 0);
-      }
-      out[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, t_h, out[cb], 0, 0, 0);
-    }
-  }
+  if (PRODUCT) product_from<D, PREC>(tf, p, out);
 }
 
-template <int D, int PREC>
-__global__ __launch_bounds__(256) void infonce_fused_kernel(Bf16Pack pk, const float* __restrict__ zhat, TermTable T, int B, float* __restrict__ lse,
-                                                            float* __restrict__ row_loss, float* __restrict__ dzhat) {
-  using Sh = InbShape<D, PREC>;
+template <int D, int PREC, bool PRODUCT>
+__global__ __launch_bounds__(256) void infonce_walk_kernel(Bf16Pack pk, const float* __restrict__ zhat, TermTable T, int n_terms, int B,
+                                                           float* __restrict__ lse, float* __restrict__ row_loss, float* __restrict__ dzhat) {
+  using Sh = WalkShape<D, PREC, PRODUCT>;
   constexpr int BLK = Sh::BLK, TILE = Sh::TILE, PER = Sh::PER, NS = Sh::NS;
+  static_assert(Sh::OK, "shape not supported by the pipelined walk");
   extern __shared__ __attribute__((aligned(16))) __bf16 sm_oth[];  // [NS][TILE]
   typedef __attribute__((address_space(3))) void* lds_p;
   typedef const __attribute__((address_space(1))) void* gbl_p;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
-  const int t = blockIdx.y;
-  const int o0 = (blockIdx.x * 4 + wave) * 32;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const UnitMap um = xcd_unit((B + 127) >> 7);  // unit = term, sub = block of 128 own rows
+  if (um.unit >= n_terms) return;
+  const int t = um.unit;
+  const int o0 = (um.sub * 4 + wave) * 32;
   const bool active = o0 < B;
   const dmm_infonce_term term = T.t[t];
   const int own_slot = term.a, oth_slot = term.b;
   const int tiles = pk.Bp >> 5;
   const size_t oth_base = (size_t)oth_slot * tiles * BLK;
+  const __bf16* srcb[PER];  // wave-uniform source of piece i (see infonce_bwd_lds_kernel)
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c0 = i * 256 + wave * 64, blk = c0 / (BLK / 8);
+    const __bf16* base = PRODUCT ? (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) : (blk == 0 ? pk.hi : pk.lo);
+    srcb[i] = base + oth_base + (size_t)(c0 % (BLK / 8)) * 8;
+  }
   auto issue = [&](int kt, int stage) {
     const int k = kt < tiles ? kt : tiles - 1;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c0 = i * 256 + wave * 64;
-      const int c = c0 + lane, blk = c / (BLK / 8), w = c % (BLK / 8);
-      const __bf16* src = (blk == 0 ? pk.hi : blk == 1 ? pk.hiT : blk == 2 ? pk.lo : pk.loT) + oth_base + (size_t)k * BLK + (size_t)w * 8;
-      __builtin_amdgcn_global_load_lds((gbl_p)src, (lds_p)(sm_oth + (size_t)stage * TILE + (size_t)c0 * 8), 16, 0, 0);
-    }
+    for (int i = 0; i < PER; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_p)(srcb[i] + (size_t)k * BLK + (size_t)lane * 8),
+                                       (lds_p)(sm_oth + (size_t)stage * TILE + (size_t)(i * 256 + wave * 64) * 8), 16, 0, 0);
   };
   bf16x8 own_h[D / 16], own_l[D / 16];
   const int otile = active ? (o0 >> 5) : 0;
@@ -795,14 +946,43 @@ __global__ __launch_bounds__(256) void infonce_fused_kernel(Bf16Pack pk, const f
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j) issue(j, j);
-  for (int kt = 0; kt < tiles; ++kt) {
-    inb_wait_vmcnt<(NS - 2) * PER>();
+  // the pipelined walk of infonce_bwd_lds_kernel: a step issues the logits of tile kt + 1, then works on tile kt's
+  int kt = 0;
+  f32x16 acc_a, acc_b;
+  inb_wait_vmcnt<(NS - 2) * PER>();
+  asm volatile("s_barrier" ::: "memory");
+  acc_a = tile_logits<D, PREC, Sh::LO>(sm_oth, own_h, own_l, fr, fh);
+  constexpr bool EARLY = D <= 64;
+  auto step = [&](auto checked, f32x16& cur, f32x16& nxt) {
+    inb_wait_vmcnt<(NS - 3) * PER>();
     asm volatile("s_barrier" ::: "memory");
     issue(kt + NS - 1, (kt + NS - 1) % NS);
-    const __bf16* S = sm_oth + (size_t)(kt % NS) * TILE;
-    if (active) {
-      if (kt == otile || kt == tiles - 1) inf_tile<D, PREC, true>(S, own_h, own_l, out, kt * 32, oidx, B, c1, lsum, diag, fr, fh);
-      else inf_tile<D, PREC, false>(S, own_h, own_l, out, kt * 32, oidx, B, c1, lsum, diag, fr, fh);
+    // every LDS read of the step up front (see infonce_bwd_lds_kernel)
+    const SFrags<D, PREC> sf = load_sfrags<D, PREC, Sh::LO>(sm_oth + (size_t)((kt + 1) % NS) * TILE, fr, fh);
+    TFrags<D, PREC> tf;
+    if (PRODUCT) tf = load_tfrags<D, PREC>(sm_oth + (size_t)(kt % NS) * TILE, fr, fh);
+    if (EARLY) __builtin_amdgcn_sched_barrier(0);
+    nxt = logits_from<D, PREC>(sf, own_h, own_l);
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) inf_apply<D, PREC, decltype(checked)::value, PRODUCT>(tf, cur, out, kt * 32, oidx, B, c1, lsum, diag, fh);
+    ++kt;
+  };
+#pragma unroll 1
+  for (int phase = 0; phase < 2; ++phase) {  // (separate loops for the plain and the checked tiles: see infonce_bwd_lds_kernel)
+    const int special = phase == 0 ? otile : tiles - 1;
+    const int upto = special < kt ? kt : special;
+#pragma unroll 1
+    while (kt + 1 < upto) {
+      step(std::false_type{}, acc_a, acc_b);
+      step(std::false_type{}, acc_b, acc_a);
+    }
+    if (kt < upto) {
+      step(std::false_type{}, acc_a, acc_b);
+      acc_a = acc_b;
+    }
+    if (kt < tiles) {
+      step(std::true_type{}, acc_a, acc_b);
+      acc_a = acc_b;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -815,6 +995,7 @@ __global__ __launch_bounds__(256) void infonce_fused_kernel(Bf16Pack pk, const f
     lse[(size_t)t * B + oidx] = l;
     row_loss[(size_t)t * B + oidx] = (l - dg * inv_t) * (term.weight / (float)B);
   }
+  if (!PRODUCT) return;
   const float invL = 1.0f / L;
   const float coef = term.weight * inv_t / (float)B;
 #pragma unroll
@@ -833,16 +1014,28 @@ __global__ __launch_bounds__(256) void infonce_fused_kernel(Bf16Pack pk, const f
   }
 }
 
+// PRODUCT = true: forward + anchor-side backward; false: forward alone (dzhat unused)
+template <int D, int PREC, bool PRODUCT>
+static void walk_launch(int n_terms, hipStream_t s, Bf16Pack pk, const float* zhat, const TermTable& T, int B, float* lse, float* row_loss, float* dzhat) {
+  if constexpr (WalkShape<D, PREC, PRODUCT>::OK) {
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_walk_kernel<D, PREC, PRODUCT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WalkShape<D, PREC, PRODUCT>::LDS_BYTES);
+      return true;
+    }();
+    (void)once;
+    constexpr size_t lds_bytes = WalkShape<D, PREC, PRODUCT>::LDS_BYTES;
+    hipLaunchKernelGGL((infonce_walk_kernel<D, PREC, PRODUCT>), dim3(xcd_grid(n_terms, cdiv(B, 128))), dim3(256), lds_bytes, s, pk, zhat, T, n_terms, B, lse,
+                       row_loss, dzhat);
+  }
+}
 template <int D, int PREC>
-static void inf_launch(dim3 grid, hipStream_t s, Bf16Pack pk, const float* zhat, const TermTable& T, int B, float* lse, float* row_loss, float* dzhat) {
-  static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_fused_kernel<D, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              InbShape<D, PREC>::LDS_BYTES);
-    return true;
-  }();
-  (void)once;
-  constexpr size_t lds_bytes = InbShape<D, PREC>::LDS_BYTES;
-  hipLaunchKernelGGL((infonce_fused_kernel<D, PREC>), grid, dim3(256), lds_bytes, s, pk, zhat, T, B, lse, row_loss, dzhat);
+static void inf_launch(int n_terms, hipStream_t s, Bf16Pack pk, const float* zhat, const TermTable& T, int B, float* lse, float* row_loss, float* dzhat) {
+  walk_launch<D, PREC, true>(n_terms, s, pk, zhat, T, B, lse, row_loss, dzhat);
+}
+static bool walk_ok(int D, int precision, bool product) {  // WalkShape<>::OK of the instantiations the dispatch below can reach
+  if (product) return !(D == 256 && precision == 3);
+  return D >= 64;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -992,7 +1185,8 @@ extern "C" int dmm_infonce_fwd(const float* zhat, const void* bf16_pack, int n_s
   if (bf16_pack && precision != 0 && mfma_ok(D)) {
     DMM_CHECK_ARG(precision == 1 || precision == 3, "dmm_infonce_fwd: precision must be 0 (fp32 VALU), 1 or 3");
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
-    DISPATCH_MFMA(D, precision, infonce_fwd_mfma_kernel, dim3(cdiv(B, 32), n_terms), dim3(256), 0, (hipStream_t)stream, pk, T, B, lse, row_loss);
+    DISPATCH_MFMA(D, precision, infonce_fwd_mfma_kernel, dim3(xcd_grid(n_terms, cdiv(B, 32))), dim3(256), 0, (hipStream_t)stream, pk, T, n_terms, B, lse,
+                  row_loss);
     DMM_LAUNCH_CHECK("dmm_infonce_fwd(mfma)");
     return 0;
   }
@@ -1014,13 +1208,12 @@ extern "C" int dmm_infonce_bwd(const float* zhat, const void* bf16_pack, int n_s
     const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
     static const int ks_env = [] { const char* e = getenv("DMM_INFONCE_KSPLIT"); return e ? atoi(e) : 0; }();  // tuning knob: > 0 = the per-wave walk
     if (ks_env <= 0 && B <= INB_MAX_B) {  // default: the LDS-shared walk
-      const dim3 grid(cdiv(B, 128), n_terms, 2);
       hipStream_t st = (hipStream_t)stream;
       switch (D) {
-        case 32: if (precision == 3) inb_launch<32, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<32, 1>(grid, st, pk, lse, T, B, dzhat); break;
-        case 64: if (precision == 3) inb_launch<64, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<64, 1>(grid, st, pk, lse, T, B, dzhat); break;
-        case 128: if (precision == 3) inb_launch<128, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<128, 1>(grid, st, pk, lse, T, B, dzhat); break;
-        case 256: if (precision == 3) inb_launch<256, 3>(grid, st, pk, lse, T, B, dzhat); else inb_launch<256, 1>(grid, st, pk, lse, T, B, dzhat); break;
+        case 32: if (precision == 3) inb_launch<32, 3>(n_terms, 2, st, pk, lse, T, B, dzhat); else inb_launch<32, 1>(n_terms, 2, st, pk, lse, T, B, dzhat); break;
+        case 64: if (precision == 3) inb_launch<64, 3>(n_terms, 2, st, pk, lse, T, B, dzhat); else inb_launch<64, 1>(n_terms, 2, st, pk, lse, T, B, dzhat); break;
+        case 128: if (precision == 3) inb_launch<128, 3>(n_terms, 2, st, pk, lse, T, B, dzhat); else inb_launch<128, 1>(n_terms, 2, st, pk, lse, T, B, dzhat); break;
+        case 256: if (precision == 3) inb_launch<256, 3>(n_terms, 2, st, pk, lse, T, B, dzhat); else inb_launch<256, 1>(n_terms, 2, st, pk, lse, T, B, dzhat); break;
       }
       DMM_LAUNCH_CHECK("dmm_infonce_bwd(mfma, lds)");
       return 0;
@@ -1043,30 +1236,38 @@ extern "C" int dmm_infonce_fwd_bwd(const float* zhat, const void* bf16_pack, int
   TermTable T;
   if (int e = fill_terms(terms, n_terms, T)) return e;
   DMM_CHECK_ARG(zhat && lse && row_loss && dzhat && B > 0 && D % 4 == 0 && D > 0, "dmm_infonce_fwd_bwd: bad arguments");
-  bool fused = bf16_pack && (precision == 1 || precision == 3) && mfma_ok(D) && B <= INB_MAX_B;
-  for (int i = 0; i < n_terms && fused; ++i) fused = terms[i].temp >= 0.024f;  // exp2((s - 1) log2(e) / temp) must not underflow for s in [-1, 1]
-  // Measured (B = 4096, d = 64, 8 terms): the one-walk kernel 97 us + the other-view pass alone 103 us = 200 us, against 40 us (forward) +
-  // 123 us (both backward passes in ONE launch) = 163 us for the two-kernel path -- a walk is a serial MFMA -> exp -> MFMA chain per wave, and with
-  // 1024 waves per launch (one per SIMD) nothing hides it; the two-pass launch has 2048.  Off by default (DMM_INFONCE_FUSED=1 enables); what
-  // would make it pay is a K split with a deferred normalisation.
-  static const int allow = [] { const char* e = getenv("DMM_INFONCE_FUSED"); return e ? atoi(e) : 0; }();
-  if (!fused || !allow) {  // the two-kernel path (any arithmetic mode, any temperature)
+  bool unit = bf16_pack && (precision == 1 || precision == 3) && mfma_ok(D) && B <= INB_MAX_B;
+  for (int i = 0; i < n_terms && unit; ++i) unit = terms[i].temp >= 0.024f;  // exp2((s - 1) log2(e) / temp) must not underflow for s in [-1, 1]
+  // Three forms (B = 4096, d = 64, 8 terms, round 4; kernel times under rocprofv3):
+  //  * default: the per-wave forward (running maximum: any temperature, rows of any norm) 37 us + the two-pass backward 88-92 us;
+  //  * DMM_INFONCE_FUSED=1: one walk gives lse, the row loss and the anchor-side gradient (75 us: 256 workgroups = one wave per SIMD), the backward
+  //    keeps pass 1 only (~50 us) -- the same total, so the default stays the form whose forward is bit-identical to dmm_infonce_fwd's;
+  //  * DMM_INFONCE_WALK_FWD=1: the walk as forward alone (48 us, again one wave per SIMD) + the two-pass backward.
+  static const int allow_fused = [] { const char* e = getenv("DMM_INFONCE_FUSED"); return e ? atoi(e) : 0; }();
+  static const int allow_walk = [] { const char* e = getenv("DMM_INFONCE_WALK_FWD"); return e ? atoi(e) : 0; }();
+  const bool fused = unit && allow_fused && walk_ok(D, precision, true);
+  const bool walk_fwd = unit && !fused && allow_walk && walk_ok(D, precision, false);
+  if (!fused && !walk_fwd) {  // the two-kernel path (any arithmetic mode, any temperature)
     if (int e = dmm_infonce_fwd(zhat, bf16_pack, n_slots, precision, terms, n_terms, B, D, lse, row_loss, stream)) return e;
     return dmm_infonce_bwd(zhat, bf16_pack, n_slots, precision, lse, terms, n_terms, B, D, dzhat, stream);
   }
   const Bf16Pack pk = make_pack(const_cast<void*>(bf16_pack), n_slots, B, D);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g1(cdiv(B, 128), n_terms), g2(cdiv(B, 128), n_terms, 1);
-  switch (D) {
-    case 32: if (precision == 3) { inf_launch<32, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<32, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
-             else { inf_launch<32, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<32, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
-    case 64: if (precision == 3) { inf_launch<64, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<64, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
-             else { inf_launch<64, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<64, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
-    case 128: if (precision == 3) { inf_launch<128, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<128, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
-              else { inf_launch<128, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<128, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
-    case 256: if (precision == 3) { inf_launch<256, 3>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<256, 3>(g2, st, pk, lse, T, B, dzhat, 1); }
-              else { inf_launch<256, 1>(g1, st, pk, zhat, T, B, lse, row_loss, dzhat); inb_launch<256, 1>(g2, st, pk, lse, T, B, dzhat, 1); } break;
+#define DMM_WALK(DD, PP)                                                                       \
+  if (fused) {                                                                                 \
+    walk_launch<DD, PP, true>(n_terms, st, pk, zhat, T, B, lse, row_loss, dzhat);              \
+    inb_launch<DD, PP>(n_terms, 1, st, pk, lse, T, B, dzhat, 1);                               \
+  } else {                                                                                     \
+    walk_launch<DD, PP, false>(n_terms, st, pk, zhat, T, B, lse, row_loss, dzhat);             \
+    inb_launch<DD, PP>(n_terms, 2, st, pk, lse, T, B, dzhat);                                  \
   }
+  switch (D) {
+    case 32: if (precision == 3) { DMM_WALK(32, 3) } else { DMM_WALK(32, 1) } break;
+    case 64: if (precision == 3) { DMM_WALK(64, 3) } else { DMM_WALK(64, 1) } break;
+    case 128: if (precision == 3) { DMM_WALK(128, 3) } else { DMM_WALK(128, 1) } break;
+    case 256: if (precision == 3) { DMM_WALK(256, 3) } else { DMM_WALK(256, 1) } break;
+  }
+#undef DMM_WALK
   DMM_LAUNCH_CHECK("dmm_infonce_fwd_bwd");
   return 0;
 }

@@ -15,11 +15,18 @@ zhat, znorm = torch.zeros(S, B, D, device=dev), torch.zeros(S, B, device=dev)
 pack = ops.infonce_pack(S, B, D, dev)
 ops.gather_normalize(slots, B, D, zhat, znorm, pack)
 lse, rl, dz = torch.zeros(8, B, device=dev), torch.zeros(8, B, device=dev), torch.zeros(S, B, D, device=dev)
-f = lambda: ops.infonce_fwd_bwd(zhat, terms, 8, B, D, lse, rl, dz, pack=pack, n_slots=S, precision=1)
-f(); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(10): f()
-e1.record(); torch.cuda.synchronize()
-t = e0.elapsed_time(e1) / 10 * 1e-3
-print(json.dumps(dict(B=B, D=D, ksplit=os.environ.get("DMM_INFONCE_LDS_KSPLIT", "default"), us=round(t * 1e6, 1), TFLOPs=round(8 * B * B * D * 2 * 4 / t / 1e12, 1))))
+def timed(f, n=20):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / n * 1e3, 1)
+kw = dict(pack=pack, n_slots=S, precision=int(os.environ.get("PREC", "1")))
+out = dict(B=B, D=D, ksplit=os.environ.get("DMM_INFONCE_LDS_KSPLIT", "default"), fused=os.environ.get("DMM_INFONCE_FUSED", "0"),
+           fwd_us=timed(lambda: ops.infonce_fwd(zhat, terms, 8, B, D, lse, rl, **kw)),
+           bwd_us=timed(lambda: ops.infonce_bwd(zhat, lse, terms, 8, B, D, dz, **kw)),
+           fwd_bwd_us=timed(lambda: ops.infonce_fwd_bwd(zhat, terms, 8, B, D, lse, rl, dz, **kw)))
+# logits per second of the backward (every logit of a term is formed twice: once per pass)
+out["bwd_Tlogit_s"] = round(8 * 2 * B * B / out["bwd_us"] / 1e6, 2)
+print(json.dumps(out))
