@@ -155,6 +155,7 @@ _SIGS = {
     "dmm_item_project": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_item_project_batched": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _I, _I, _P]),
     "dmm_item_project_batched_x16": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _P]),
+    "dmm_item_project_batched_xb": (C.c_int, [C.POINTER(ProjectProblem), _I, _I, _I, _I, _P]),
     "dmm_item_expand": (C.c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_item_expand_fused": (C.c_int, [C.POINTER(ExpandFusedArgs), _I, _I, _P]),
     "dmm_graph_build_scratch_bytes": (C.c_int, [_I, _I, _L, _I, _P]),

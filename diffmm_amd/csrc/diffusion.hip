@@ -621,52 +621,56 @@ __device__ __forceinline__ unsigned long long topk_comb(float v, int col) {  // 
 }
 template <int MAXQ>  // 16-byte pieces per lane: rows up to MAXQ * 1024 columns
 __device__ __forceinline__ void topk_small_row(const float* __restrict__ r, int cols, int k, int32_t* __restrict__ out) {
-  __shared__ unsigned long long best_w[4];
+  __shared__ unsigned long long best_w[2][4];  // (two sets: a round writes the one the previous round's readers are not using -- one barrier per round)
   __shared__ int picked[TOPK_SMALL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 v[MAXQ];
   const int nq = (cols + 1023) / 1024;
+  // (r4) the order-preserving keys are formed ONCE (they were re-derived in every round), and a round re-scans only in the wave that held the previous
+  // winner: every other lane's best candidate is still below that winner and still its best (3.5 x fewer VALU instructions at the mean k of 5).
+  uint32_t key[MAXQ][4];
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
     const int c = (q * 256 + (int)threadIdx.x) * 4;
-    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < nq) {
-      if (c + 3 < cols) v[q] = *reinterpret_cast<const float4*>(r + c);
+      if (c + 3 < cols) v = *reinterpret_cast<const float4*>(r + c);
       else {
-        if (c < cols) v[q].x = r[c];
-        if (c + 1 < cols) v[q].y = r[c + 1];
-        if (c + 2 < cols) v[q].z = r[c + 2];
+        if (c < cols) v.x = r[c];
+        if (c + 1 < cols) v.y = r[c + 1];
+        if (c + 2 < cols) v.z = r[c + 2];
       }
     }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) key[q][j] = (q < nq && c + j < cols) ? fkey(e[j]) : 0u;  // 0: below every float's key, never picked (k <= cols)
   }
-  unsigned long long prev = ~0ull;  // every candidate is strictly below it
-  for (int round = 0; round < k; ++round) {
+  const uint32_t lo0 = 0xffffffffu - (unsigned)threadIdx.x * 4u;  // low word of element (q, j): lo0 - (q * 1024 + j) = ~column
+  auto scan = [&](unsigned long long prev) {  // the lane's best candidate strictly below `prev` in the order (value descending, column ascending)
     unsigned long long best = 0ull;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      if (q < nq) {
-        const int c = (q * 256 + (int)threadIdx.x) * 4;
-        const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+    for (int q = 0; q < MAXQ; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned long long cb = c + j < cols ? topk_comb(e[j], c + j) : 0ull;
-          if (cb < prev && cb > best) best = cb;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const unsigned long long cb = key[q][j] ? (((unsigned long long)key[q][j] << 32) | (unsigned long long)(lo0 - (unsigned)(q * 1024 + j))) : 0ull;
+        if (cb < prev && cb > best) best = cb;
       }
-    }
+    return best;
+  };
+  unsigned long long mine = scan(~0ull);
+  for (int round = 0; round < k; ++round) {
+    unsigned long long best = mine;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long other = __shfl_xor(best, o, 64);
       best = other > best ? other : best;
     }
-    __syncthreads();  // the previous round's best_w has been read by every wave
-    if (lane == 0) best_w[wave] = best;
-    __syncthreads();
-    unsigned long long b = best_w[0];
+    if (lane == 0) best_w[round & 1][wave] = best;
+    __syncthreads();  // (the set written two rounds ago was read before the previous round's barrier)
+    unsigned long long b = best_w[round & 1][0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) b = best_w[w] > b ? best_w[w] : b;
-    prev = b;
+    for (int w = 1; w < 4; ++w) b = best_w[round & 1][w] > b ? best_w[round & 1][w] : b;
     if (threadIdx.x == 0) picked[round] = (int)(0xffffffffu - (unsigned)(b & 0xffffffffull));
+    if (best == b && round + 1 < k) mine = scan(b);  // wave-uniform: the wave that held the winner; its other lanes find their old candidate again
   }
   __syncthreads();
   if (threadIdx.x == 0) {  // ascending column order, like the radix path's ordered compaction

@@ -655,6 +655,10 @@ extern "C" int dmm_item_project_batched(const dmm_project_problem* p, int n, int
 extern "C" int dmm_item_project_batched_x16(const dmm_project_problem* p, int n, int D, void* stream) {
   return project_batched(p, n, D, 0, 1, true, stream);
 }
+extern "C" int dmm_item_project_batched_xb(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, void* stream) {
+  DMM_CHECK_ARG((f_transposed != 0) != (out_transposed != 0), "dmm_item_project_batched_xb: the forms built are (F transposed, out plain) and (F plain, out transposed)");
+  return project_batched(p, n, D, f_transposed, out_transposed, true, stream);
+}
 static int project_batched(const dmm_project_problem* p, int n, int D, int f_transposed, int out_transposed, bool x_bf16, void* stream) {
   DMM_CHECK_ARG(p && n >= 1 && n <= 4, "dmm_item_project_batched: 1..4 problems per launch");
   DMM_CHECK_ARG(D == 64 || D == 128 || D == 256, "dmm_item_project_batched: D=%d unsupported (64, 128 or 256)", D);
@@ -682,7 +686,11 @@ static int project_batched(const dmm_project_problem* p, int n, int D, int f_tra
     ks = std::max(ks, (q.K + kchunk - 1) / kchunk);
   }
   hipStream_t s = (hipStream_t)stream;
-  if (x_bf16) {
+  if (x_bf16 && f_transposed && !out_transposed) {
+    if (D == 64) hipLaunchKernelGGL((item_project_kernel<64, 1, true, false, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+    else if (D == 128) hipLaunchKernelGGL((item_project_kernel<128, 1, true, false, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((item_project_kernel<256, 1, true, false, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
+  } else if (x_bf16) {
     if (D == 64) hipLaunchKernelGGL((item_project_kernel<64, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
     else if (D == 128) hipLaunchKernelGGL((item_project_kernel<128, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);
     else hipLaunchKernelGGL((item_project_kernel<256, 1, false, true, ProjBatch, true>), dim3(rb, ks, n), dim3(256), 0, s, b);

@@ -177,6 +177,11 @@ class JointEngine:
         self.feat = [self._feat_block[m] for m in range(M)]
         # E_m^T [F_m, round_up(I, 32)] (constant): the weight gradient dW_m = dfeat_m^T E_m runs as E_m^T x dfeat_m on the item-space kernel
         self._featsT = None
+        self._feats16_c = self._featsT16_c = None
+        # DMM_FEAT_X16=1: the projection kernels take the constant features as bf16 copies (same result: they round X to bf16 themselves; half the
+        # bytes).  Off by default: at the TikTok shape the two launches gain 0.05 ms per epoch (the fp32 features sit in the Infinity Cache) and the
+        # diffusion phase, whose buffers land elsewhere once the copies exist, lost 0.25 ms in the same runs (round 4, bench_phases, two pairs).
+        self._feat_x16 = os.environ.get("DMM_FEAT_X16", "0") != "0"
         self._x16_bufs = None
         self._emb16_step = -1  # Adam step at which the embedding table's bf16 gather copy was last made (bf16 gather operands only)
         self._nf_block, self._fnorm_block = z(M, items, D), z(M, items)  # blocks: the modalities' row normalisation is one launch
@@ -267,13 +272,25 @@ class JointEngine:
                 self._featsT.append(t)
         return self._featsT
 
+    def _feats16(self) -> List[Tensor]:
+        """bf16 copies of the raw modality features [I, F_m] (constants) for the item-space projection kernels: what those kernels round X to anyway."""
+        if self._feats16_c is None:
+            self._feats16_c = [f.to(torch.bfloat16).contiguous() for f in self.feats]
+        return self._feats16_c
+
+    def _features_T16(self) -> List[Tensor]:
+        if self._featsT16_c is None:
+            self._featsT16_c = [t.to(torch.bfloat16) for t in self._features_T()]
+        return self._featsT16_c
+
     def _project(self, precision: int, zeroed: bool = False):
         """zeroed: the caller has just cleared the whole accumulation arena (step()), the projections' block included."""
         names = modality_names(self.M)
         if self._feat_kernels(precision):  # skinny products (N = d): the item-space MFMA kernel, 64 rows per workgroup, all modalities in one launch
             if not zeroed:
                 ops.zero_(self._feat_block)
-            ops.item_project_batched([dict(X=self.feats[m], F=self.P.view(f"{n}_layer.weight"), out=self.feat[m], bias=self.P.view(f"{n}_layer.bias"),
+            X = self._feats16() if self._feat_x16 else self.feats
+            ops.item_project_batched([dict(X=X[m], F=self.P.view(f"{n}_layer.weight"), out=self.feat[m], bias=self.P.view(f"{n}_layer.bias"),
                                            K=self.feats[m].shape[1]) for m, n in enumerate(names)], self.D, f_transposed=True)
         else:  # Linear_m(E_m) of every modality in ONE launch of the generic GEMM
             ops.gemm_batched([dict(A=self.feats[m], B=self.P.view(f"{n}_layer.weight"), out=self.feat[m], trans_b=True, bias=self.P.view(f"{n}_layer.bias"),
@@ -467,7 +484,7 @@ class JointEngine:
                                  for m, n in enumerate(names)])
         # dW_m = dfeat_m^T E_m: 64 x F outputs with K = I the parallel axis; one launch for all m
         if self._feat_kernels(precision):  # as E_m^T [F_m, I] x dfeat_m [I, d], stored transposed into the [d, F_m] gradient
-            FT = self._features_T()
+            FT = self._features_T16() if self._feat_x16 else self._features_T()
             ops.item_project_batched([dict(X=FT[m], F=self.dfeat[m], out=self.P.g(f"{n}_layer.weight"), K=self.I) for m, n in enumerate(names)], D,
                                      out_transposed=True)
         else:  # generic GEMM, K split 128 (32 / 64 / 128 / 256 measured)

@@ -774,12 +774,13 @@ def item_project_batched(problems: Sequence[dict], D: int, f_transposed: bool = 
     """Up to 4 problems  out[r, c] += sum_k X[r, k] Fm(k, c) (+ bias[c])  in one launch (dicts: X [rows, >= round_up(K, 32)], F, out, optional bias,
     K).  f_transposed: F is [D, K] (an nn.Linear weight); out_transposed: the result goes to out[c, r].  `out` holds the value to add to."""
     arr = (L.ProjectProblem * len(problems))()
+    xb = all(p["X"].dtype == torch.bfloat16 for p in problems)  # a constant X cast once (dmm_item_project_batched_xb: same result, half the bytes)
     for a, p in zip(arr, problems):
         X, F, out, K = p["X"], p["F"], p["out"], int(p["K"])
         rows = int(p.get("rows", X.shape[0]))
         for t in (X, F, out):
-            if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
-                raise ValueError("item_project_batched: 2-D fp32 tensors with unit inner stride")
+            if t.dtype != (torch.bfloat16 if (xb and t is X) else torch.float32) or t.dim() != 2 or t.stride(1) != 1:
+                raise ValueError("item_project_batched: 2-D fp32 tensors with unit inner stride (X: all fp32 or all bf16)")
         fk, fd = (F.shape[1], F.shape[0]) if f_transposed else (F.shape[0], F.shape[1])
         orr, oc = (out.shape[1], out.shape[0]) if out_transposed else (out.shape[0], out.shape[1])
         if fk < K or fd < D or orr < rows or oc < D or X.shape[0] < rows or X.shape[1] < ((K + 31) & ~31):
@@ -787,7 +788,10 @@ def item_project_batched(problems: Sequence[dict], D: int, f_transposed: bool = 
         a.X, a.ldx, a.F, a.ldf, a.out, a.ldo, a.rows, a.K = L.ptr(X), X.stride(0), L.ptr(F), F.stride(0), L.ptr(out), out.stride(0), rows, K
         if p.get("bias") is not None:
             a.bias = L.ptr(_f32c(p["bias"], "bias"))
-    L.call("dmm_item_project_batched", arr, len(problems), D, int(f_transposed), int(out_transposed), L.stream())
+    if xb:
+        L.call("dmm_item_project_batched_xb", arr, len(problems), D, int(f_transposed), int(out_transposed), L.stream())
+    else:
+        L.call("dmm_item_project_batched", arr, len(problems), D, int(f_transposed), int(out_transposed), L.stream())
 
 
 def item_expand(P: Tensor, F: Tensor, R: Tensor, Y: Tensor, I: int) -> None:

@@ -469,6 +469,10 @@ int dmm_item_project_batched(const dmm_project_problem* p /*host array*/, int n,
 /* the out_transposed form with X given in bf16 ([rows, ldx] bf16 elements, ldx % 8 == 0; the X pointer of the problem struct is read as such):
  * a transposed bf16 weight copy that exists anyway as the long operand, e.g. (F^T W2)[d, H] from W2^T[H, I] in bf16 (Model.py:413 folded) */
 int dmm_item_project_batched_x16(const dmm_project_problem* p /*host array*/, int n, int D, void* stream);
+/* The same product with X given in bf16 (a constant operand cast once: the raw modality features of Model.py:34-42's Linear layers and their
+ * transpose in the joint step) -- bit-identical to the fp32-X forms at precision 1, which round X to bf16 inside the kernel, at half the bytes.
+ * Forms: (f_transposed = 1, out_transposed = 0) and (0, 1). */
+int dmm_item_project_batched_xb(const dmm_project_problem* p /*host array*/, int n, int D, int f_transposed, int out_transposed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Rebuild, second half: the modality graph of Main.py:232-253 (coo_matrix of the top-k edges -> DataHandler.makeTorchAdj,

@@ -1348,3 +1348,37 @@ def test_tanh_bwd_fused_equals_the_four_passes(dev, B, H, M):
         assert torch.equal(probs[m]["d16"], want[m][0]), "bf16 rows"
         assert torch.equal(probs[m]["dT16"][:, :Bp], want[m][1]) and float(probs[m]["dT16"][:, Bp:].float().min()) == 7.0, "bf16 transpose, zero pad, nothing beyond rows_pad"
         close(probs[m]["csum"], want[m][2], rtol=1e-5, atol=1e-4, what="column sums")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [64, 128])
+def test_item_project_bf16_x_is_bit_identical(dev, D):
+    """dmm_item_project_batched_xb (X cast to bf16 once by the caller) against dmm_item_project_batched (X rounded inside the kernel): the same
+    bf16 operand, the same K slicing -- both forms the joint step uses, three problems of unequal shapes as the modalities have them.  The forward
+    form has at most two K slices (one commutative addition): bit-identical; the transposed form adds many slices with atomics: 1e-6 of scale."""
+    from diffmm_amd import ops
+    rng = np.random.default_rng(5)
+    I, Fs = 700, [128, 64, 256]
+    X = [T(rng.standard_normal((I, f)).astype(np.float32)).to(dev) for f in Fs]
+    W = [T(rng.standard_normal((D, f)).astype(np.float32) * 0.1).to(dev) for f in Fs]
+    bias = [T(rng.standard_normal(D).astype(np.float32)).to(dev) for _ in Fs]
+    outs = []
+    for cast in (False, True):
+        out = [torch.zeros(I, D, device=dev) for _ in Fs]
+        ops.item_project_batched([dict(X=(X[m].to(torch.bfloat16) if cast else X[m]), F=W[m], out=out[m], bias=bias[m], K=Fs[m]) for m in range(3)], D,
+                                 f_transposed=True)
+        outs.append(out)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    Ip = (I + 31) & ~31
+    XT = [torch.zeros(f, Ip, device=dev) for f in Fs]
+    for m in range(3):
+        XT[m][:, :I] = X[m].t()
+    dfeat = [T(rng.standard_normal((I, D)).astype(np.float32)).to(dev) for _ in Fs]
+    outs = []
+    for cast in (False, True):
+        out = [torch.zeros(D, f, device=dev) for f in Fs]
+        ops.item_project_batched([dict(X=(XT[m].to(torch.bfloat16) if cast else XT[m]), F=dfeat[m], out=out[m], K=I) for m in range(3)], D, out_transposed=True)
+        outs.append(out)
+    for a, b in zip(*outs):
+        close(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-6 * float(b.abs().max()), what="transposed form")
