@@ -65,16 +65,30 @@ class BatchLoader:
             perm = torch.arange(n, device=self.device)
         return [perm[s:s + self.batch_size] for s in range(0, n, self.batch_size)]
 
-    def __iter__(self) -> Iterator:
+    def _perm(self) -> torch.Tensor:
         n = len(self.dataset)
         if self.fixed_perm is not None:
-            perm = self.fixed_perm.to(self.device)
-        elif self.shuffle:
-            perm = torch.randperm(n, device=self.device, generator=self.gen)
-        else:
-            perm = torch.arange(n, device=self.device)
+            return self.fixed_perm.to(self.device)
+        if self.shuffle:
+            return torch.randperm(n, device=self.device, generator=self.gen)
+        return torch.arange(n, device=self.device)
+
+    def prefetch(self) -> bool:
+        """Draw the next epoch's permutation and gather its records NOW, on the current stream (Coach.trainEpoch: a side stream under the rebuild's
+        reverse chain -- a dozen small sort / gather launches that otherwise sit between the rebuild and the first joint step); the next __iter__
+        hands them out.  The same draw from the same generator as __iter__ would make.  False: this dataset has no whole-epoch gather."""
+        if not hasattr(self.dataset, "epoch"):
+            return False
+        self._prefetched = self.dataset.epoch(self._perm())
+        return True
+
+    def __iter__(self) -> Iterator:
+        n = len(self.dataset)
+        pre = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        perm = self._perm() if pre is None else None
         if hasattr(self.dataset, "epoch"):  # gather the whole epoch once (3 launches), then hand out contiguous slices: no per-batch index kernels
-            cols = self.dataset.epoch(perm)
+            cols = self.dataset.epoch(perm) if pre is None else pre
             for s in range(0, n, self.batch_size):
                 yield tuple(c[s:s + self.batch_size] for c in cols)
             return

@@ -286,6 +286,23 @@ class Coach:
         t_diff = time.perf_counter()
         mark(1)
 
+        # DMM_LOADER_PREFETCH=1: the joint phase's shuffled epoch (one permutation draw, three gathers) made on a side stream under the rebuild
+        # instead of between the rebuild and the first joint step.  Off by default -- measured neutral (round 4, 2 x 20 epochs each way: 17.92 / 18.02 ms
+        # per epoch with it, 17.91 / 17.83 without): the joint phase loses 0.2 ms and the rebuild gains them; with the rebuild's own side streams the
+        # process has more streams than the runtime has hardware queues, and the extra stream's launches queue up behind the chain's.
+        prefetched = None
+        if cuda and os.environ.get("DMM_LOADER_PREFETCH", "0") != "0":
+            if getattr(self, "_prep_stream", None) is None:
+                self._prep_stream = torch.cuda.Stream(device=dev)
+            main_s = torch.cuda.current_stream(dev)
+            e0 = torch.cuda.Event(); e0.record(main_s)
+            self._prep_stream.wait_event(e0)
+            with torch.cuda.stream(self._prep_stream):
+                if h.trainLoader.prefetch():
+                    for t_ in h.trainLoader._prefetched:
+                        t_.record_stream(main_s)
+                    prefetched = torch.cuda.Event(); prefetched.record(self._prep_stream)
+
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
         if modal_adj_override is None:
             sstep = int(cfg.hyper.sampling_step)
@@ -296,7 +313,7 @@ class Coach:
                 else:
                     reb_batches, init = [torch.arange(min(int(lim), int(cfg.data.user_num)), device=dev)], dd.col32
                 edges = DE.rebuild_edges(dd.rows, reb_batches, dd.deg_ptr32, int(dd.ptr[-1]), precision=prec, sampling_step=sstep,
-                                         csr=(dd.ptr, dd.col32, 0), init_cols=init)
+                                         csr=(dd.ptr, dd.col32, 0), init_cols=init, defer_join=True)
                 if getattr(self, "graph_builder", None) is None:  # CSR + SpMM work list are built on the device (no D2H of the edges)
                     self.graph_builder = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, int(cfg.base.latdim), vec=self.base_adj.vec,
                                                                   task_len=graph.spmm_task_len(self.base_adj.vec),
@@ -310,7 +327,9 @@ class Coach:
                 init = None if lim is None else dd.col32[int(dd.ptr[lay.u0]):int(dd.ptr[lay.u1])]
                 edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
                                          sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0), init_cols=init)
-            adjs = self.graph_builder.build_all(edges)  # (reads the graphs' sizes back: the host is synchronised here)
+            ready = getattr(DE, "edges_ready", None) if lay is None else None
+            adjs = self.graph_builder.build_all(edges, **({"ready": ready} if ready is not None else {}))  # (reads the graphs' sizes back: the host is synchronised here)
+            DE.edges_ready = None
             DE.check_chain_error()  # a timed-out group barrier of dmm_latent_chain invalidates these graphs: raise BEFORE any Adam step uses them
         else:
             adjs = list(modal_adj_override)
@@ -322,6 +341,8 @@ class Coach:
 
         # ---- phase 3: joint training (Main.py:292-377) ----
         acc = torch.zeros(J.loss_parts.numel(), dtype=torch.float64, device=dev)
+        if prefetched is not None:
+            torch.cuda.current_stream(dev).wait_event(prefetched)
         for users, pos, neg in h.trainLoader:  # the same shuffled minibatches on every replica (identically seeded loader generator)
             noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
             acc += J.step(users, pos, neg, noise=noise, precision=prec)

@@ -47,6 +47,10 @@ class LatentChainArgs(C.Structure):
                 ("ldh", C.c_int64), ("bias_t", C.c_void_p), ("ldbt", C.c_int64)]
 
 
+class CsrGatherProblem(C.Structure):
+    _fields_ = [("Wt", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("z", C.c_void_p), ("ldz", C.c_int64), ("out16", C.c_void_p), ("ldo", C.c_int64)]
+
+
 class TanhBwdFusedArgs(C.Structure):
     _fields_ = [("dh", C.c_void_p), ("ld_dh", C.c_int64), ("h", C.c_void_p), ("ld_h", C.c_int64), ("d16", C.c_void_p), ("ld16", C.c_int64),
                 ("dT16", C.c_void_p), ("ldT", C.c_int64), ("csum", C.c_void_p)]
@@ -93,6 +97,8 @@ _SIGS = {
     "dmm_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmBf16Args), _P]),
     "dmm_gemm_bf16_nt_batched": (C.c_int, [C.POINTER(GemmBf16Args), _I, _P]),
     "dmm_latent_chain": (C.c_int, [C.POINTER(LatentChainArgs), _I, _I, _I, _I, _P, C.c_float, _P, _I, _P]),
+    "dmm_latent_chain_part": (C.c_int, [C.POINTER(LatentChainArgs), _I, _I, _I, _I, _P, C.c_float, _P, _I, _I, _P]),
+    "dmm_latent_chain_groups_per_launch": (C.c_int, [_I]),
     "dmm_latent_chain_supported": (C.c_int, [_I]),
     "dmm_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "dmm_transpose_cast_bf16": (C.c_int, [_P, _L, _P, _L, _I, _I, _I, _P]),
@@ -134,6 +140,7 @@ _SIGS = {
     "dmm_bias_tanh_rows": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "dmm_csr_gather_sum_bf16": (C.c_int, [_P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _L, _P]),
     "dmm_csr_gather_sum_latent": (C.c_int, [_P, _P, _P, _I, _P, _L, _P, _I, _P, _L, _P, _L, _P]),
+    "dmm_csr_gather_sum_latent_batched": (C.c_int, [_P, _P, _P, _I, C.POINTER(CsrGatherProblem), _I, _I, _P]),
     "dmm_csr_add_rows": (C.c_int, [_P, _P, _P, _I, _I, _F, _P, _L, _P, _L, _P]),
     "dmm_rows_axpby": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _P]),
     "dmm_temb_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),

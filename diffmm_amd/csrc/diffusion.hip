@@ -97,11 +97,16 @@ __global__ __launch_bounds__(256) void csr_dense_rows_kernel(const long long* __
   }
 }
 
+// (up to 4 problems per launch, blockIdx.y: the same rows against several operand tables -- the M modalities' chain starts -- so that the heavy
+// users' long gather loops of one problem run under the others' instead of three latency-bound launches in a row)
+struct CsrGatherP { const __bf16* Wt; long long ldw; const float* bias; __bf16* out16; long long ldo; float* z; long long ldz; };
+struct CsrGatherBatch { CsrGatherP p[4]; };
 template <int ACT>
 __global__ __launch_bounds__(256) void csr_gather_sum_kernel(const long long* __restrict__ ptr, const int32_t* __restrict__ col,
-                                                             const long long* __restrict__ rows, const __bf16* __restrict__ Wt, long long ldw,
-                                                             const float* __restrict__ bias, __bf16* __restrict__ out16, long long ldo, int H,
-                                                             float* __restrict__ z, long long ldz) {
+                                                             const long long* __restrict__ rows, const CsrGatherBatch batch, int H) {
+  const CsrGatherP& P = batch.p[blockIdx.y];
+  const __bf16* __restrict__ Wt = P.Wt; const float* __restrict__ bias = P.bias; __bf16* __restrict__ out16 = P.out16; float* __restrict__ z = P.z;
+  const long long ldw = P.ldw, ldo = P.ldo, ldz = P.ldz;
   const int b = blockIdx.x;
   const long long u = rows[b], beg = ptr[u], end = ptr[u + 1];
   for (int h0 = threadIdx.x * 4; h0 < H; h0 += 1024) {  // 4 columns (8 bytes of bf16) per thread per pass
@@ -1059,13 +1064,29 @@ static int csr_gather_sum_launch(const char* who, const int64_t* ptr, const int3
                 "%s: bad arguments (H, ldw, ldo multiples of 4)", who);
   DMM_CHECK_ARG(!z || (ldz >= H && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "%s: z must be 16-byte aligned with ldz >= H, ldz %% 4 == 0", who);
   DMM_CHECK_ARG(act == DMM_ACT_NONE || act == DMM_ACT_TANH, "%s: act must be NONE or TANH", who);
+  CsrGatherBatch batch;
+  memset(&batch, 0, sizeof(batch));
+  batch.p[0] = CsrGatherP{(const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, z, (long long)ldz};
   if (act == DMM_ACT_TANH)
-    hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows,
-                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H, z, (long long)ldz);
+    hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, batch, H);
   else
-    hipLaunchKernelGGL(csr_gather_sum_kernel<0>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows,
-                       (const __bf16*)Wt, (long long)ldw, bias, (__bf16*)out16, (long long)ldo, H, z, (long long)ldz);
+    hipLaunchKernelGGL(csr_gather_sum_kernel<0>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, batch, H);
   DMM_LAUNCH_CHECK(who);
+  return 0;
+}
+extern "C" int dmm_csr_gather_sum_latent_batched(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const dmm_csr_gather_problem* p, int n,
+                                                 int H, void* stream) {
+  DMM_CHECK_ARG(ptr && col && rows && p && n >= 1 && n <= 4 && B > 0 && H > 0 && H % 4 == 0, "dmm_csr_gather_sum_latent_batched: bad arguments (1..4 problems)");
+  CsrGatherBatch batch;
+  memset(&batch, 0, sizeof(batch));
+  for (int i = 0; i < n; ++i) {
+    DMM_CHECK_ARG(p[i].Wt && p[i].bias && p[i].out16 && p[i].z && p[i].ldw >= H && p[i].ldw % 4 == 0 && p[i].ldo >= H && p[i].ldo % 4 == 0 && p[i].ldz >= H &&
+                      p[i].ldz % 4 == 0 && ((uintptr_t)p[i].z & 15) == 0,
+                  "dmm_csr_gather_sum_latent_batched: problem %d: operands must be set, leading dimensions multiples of 4 >= H, z 16-byte aligned", i);
+    batch.p[i] = CsrGatherP{(const __bf16*)p[i].Wt, (long long)p[i].ldw, p[i].bias, (__bf16*)p[i].out16, (long long)p[i].ldo, p[i].z, (long long)p[i].ldz};
+  }
+  hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3(B, n), dim3(256), 0, (hipStream_t)stream, (const long long*)ptr, col, (const long long*)rows, batch, H);
+  DMM_LAUNCH_CHECK("dmm_csr_gather_sum_latent_batched");
   return 0;
 }
 extern "C" int dmm_csr_gather_sum_bf16(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias,

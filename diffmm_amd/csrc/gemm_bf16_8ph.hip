@@ -970,7 +970,19 @@ static int latent_chain_v2_per_cu() {
   return occ;
 }
 
-int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
+// part < 0: every launch of the chain; part >= 0: only that launch (groups part * per .. ): the host then places other work between two launches
+// (DiffusionEngine.rebuild_edges runs the finished modalities' last GEMM and top-k under the NEXT launch, which leaves CUs idle).
+// latent_chain_groups_per_launch: `per`, 0 if the persistent form cannot run.
+static int latent_chain_per(int H) {
+  static const int form = [] { const char* e = getenv("DMM_LATENT_FORM"); return e ? atoi(e) : 1; }();
+  const int cus = latent_chain_cus(), nt = H / 256;
+  if (nt < 1 || cus < 8 * nt) return 0;
+  if (form == 2 && latent_chain_v2_per_cu() >= 2) return 0;  // (the second form keeps its own slicing: no per-launch calls)
+  return (cus / nt) & ~7;
+}
+int latent_chain_groups_per_launch(int H) { return latent_chain_supported(H) ? latent_chain_per(H) : 0; }
+
+int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s, int part) {
   latent_chain_attrs();
   // write-through h' stores and no release fence (default; rebuild 5.57 -> 5.20 ms at the bench shape) or plain stores + agent release (0)
   static const int wt = [] { const char* e = getenv("DMM_LATENT_WT"); return e ? atoi(e) : 1; }();
@@ -1007,7 +1019,9 @@ int launch_latent_chain_8ph(const LatentBatch& base, int n_mod, hipStream_t s) {
   }
   const int per = (cus / nt) & ~7;  // groups per launch: every member workgroup gets a CU of its own
   const int total = n_mod * base.rbs;
-  for (int g0 = 0; g0 < total; g0 += per) {
+  if (part >= 0 && (long long)part * per >= total) return -2;
+  for (int g0 = part >= 0 ? part * per : 0; g0 < total; g0 += per) {
+    if (part >= 0 && g0 != part * per) break;
     LatentBatch b = base;
     b.g0 = g0;
     b.n_groups = std::min(per, total - g0);
@@ -1054,8 +1068,20 @@ void launch_gemm_bf16_8ph(const GemmBf16Batch& b, hipStream_t s) {
 
 }  // namespace dmm
 
+static int latent_chain_call(const dmm_latent_chain_args* a, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
+                             int flags_len, int part, void* stream);
 extern "C" int dmm_latent_chain(const dmm_latent_chain_args* a, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
                                 int flags_len, void* stream) {
+  return latent_chain_call(a, n_mod, rows, H, T, coef, s_init, flags, flags_len, -1, stream);
+}
+extern "C" int dmm_latent_chain_part(const dmm_latent_chain_args* a, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
+                                     int flags_len, int part, void* stream) {
+  DMM_CHECK_ARG(part >= 0, "dmm_latent_chain_part: part must be >= 0");
+  return latent_chain_call(a, n_mod, rows, H, T, coef, s_init, flags, flags_len, part, stream);
+}
+extern "C" int dmm_latent_chain_groups_per_launch(int H) { return dmm::latent_chain_groups_per_launch(H); }
+static int latent_chain_call(const dmm_latent_chain_args* a, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
+                             int flags_len, int part, void* stream) {
   using namespace dmm;
   DMM_CHECK_ARG(a && coef && flags && n_mod >= 1 && n_mod <= GB_MAX_BATCH && rows > 0 && T >= 1, "dmm_latent_chain: bad arguments");
   DMM_CHECK_ARG(H >= 256 && H % 256 == 0 && H <= 2048, "dmm_latent_chain: H=%d must be a multiple of 256 in 256..2048", H);
@@ -1073,7 +1099,8 @@ extern "C" int dmm_latent_chain(const dmm_latent_chain_args* a, int n_mod, int r
     P.ha = (__bf16*)a[i].h_a; P.hb = (__bf16*)a[i].h_b; P.ldh = a[i].ldh; P.bias_t = a[i].bias_t; P.ldbt = a[i].ldbt;
   }
   b.coef = coef; b.flags = flags; b.s_init = s_init; b.rows = rows; b.H = H; b.T = T; b.rbs = (rows + 255) / 256; b.err_at = flags_len - 1;
-  const int rc = launch_latent_chain_8ph(b, n_mod, (hipStream_t)stream);
+  const int rc = launch_latent_chain_8ph(b, n_mod, (hipStream_t)stream, part);
+  if (rc == -2) { dmm::set_error("dmm_latent_chain_part: part %d is past the chain's last launch", part); return DMM_ERR_INVALID_ARG; }
   if (rc == -1) {
     dmm::set_error("dmm_latent_chain: this device cannot keep the %d workgroups of a launch slice co-resident (dmm_latent_chain_supported(%d) == 0): "
                    "run the chain as one dmm_gemm_bf16_nt launch per step", 8 * (H / 256), H);

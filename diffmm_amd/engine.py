@@ -1451,8 +1451,20 @@ class DiffusionEngine:
                              "use rebuild_edges, which forms and consumes them in row chunks")
         return self._latent_views(h0, 0, B, mods)
 
-    def _latent_h0(self, rows: Optional[CsrRows] = None, xT=None, B: Optional[int] = None, mods: Optional[Sequence[int]] = None):
-        """The latent chain down to h_0 (bf16 [B, H] per modality; see generate_views_latent).  Returns ({m: h_0}, B)."""
+    def _chain_parts(self, B: int, n_mods: int) -> List[int]:
+        """Launches of the persistent chain over n_mods modalities of B rows -> for every launch, how many modalities are COMPLETE once it has run
+        (modality-major groups of 256 rows, ops.latent_chain_groups_per_launch groups per launch).  [] when the chain is not launched in parts."""
+        per = ops.latent_chain_groups_per_launch(self.H) if self._latent_fused() else 0
+        rbs = -(-B // 256)
+        total = n_mods * rbs
+        if per <= 0 or total <= per:
+            return []
+        return [min(n_mods, ((p + 1) * per) // rbs) if (p + 1) * per < total else n_mods for p in range(-(-total // per))]
+
+    def _latent_h0(self, rows: Optional[CsrRows] = None, xT=None, B: Optional[int] = None, mods: Optional[Sequence[int]] = None, parts: bool = False):
+        """The latent chain down to h_0 (bf16 [B, H] per modality; see generate_views_latent).  Returns ({m: h_0}, B).
+        parts (CSR start): instead of running the chain, returns ({m: h_0}, B, segments): one recorded launch segment per launch of the persistent
+        chain (the first one holds the chain's start as well), for rebuild_edges to replay with other work between them."""
         mods = list(range(self.M)) if mods is None else list(mods)
         T, I, H = self.T, self.I, self.H
         self._latent_alloc()
@@ -1464,7 +1476,7 @@ class DiffusionEngine:
             if B > self.chain_rows:
                 raise ValueError(f"latent chain: {B} rows > chain_rows = {self.chain_rows}")
             self._csr_users[:B].copy_(rows.users)
-            key = ("latent-csr", B, rows.ptr.data_ptr(), rows.col.data_ptr(), tuple(mods))
+            key = ("latent-csr", B, rows.ptr.data_ptr(), rows.col.data_ptr(), tuple(mods), bool(parts))
         else:
             if self.ishard is not None:
                 raise ValueError("item-sharded Denoise: the rebuild starts from CSR rows (sampling_step = 0); a dense x_T would need all item columns")
@@ -1482,15 +1494,22 @@ class DiffusionEngine:
                 h, h2 = {m: self.ch16[m][:B] for m in mods}, {m: lat["hb"][m][:B] for m in mods}
                 if rows is not None:
                     users = self._csr_users[:B]
-                    for m in mods:
-                        ops.csr_gather_sum_latent(rows.ptr, rows.col, users, self._chain_w1T(m), self.bias_t[m][T - 1], z[m], h[m])
+                    for k in range(0, len(mods), 4):  # all modalities' starts in one launch (heavy users' gather loops overlap across the problems)
+                        ops.csr_gather_sum_latent_batched(rows.ptr, rows.col, users, [dict(Wt=self._chain_w1T(m), bias=self.bias_t[m][T - 1], z=z[m], out16=h[m])
+                                                                                      for m in mods[k:k + 4]])
                 else:
                     for m in mods:
                         ops.cast_bf16(self.cxb[m][:B], self.cxa16[m][:B], cols=I, cols_pad=self.Kp)  # temb / pad columns zero: temb enters through bias_t
                     ops.gemm_bf16_nt_batched([dict(A=self.cxa16[m][:B], B=self.w1_16[m], out=z[m], out_bf16=h[m], bias2=self.bias_t[m][T - 1]) for m in mods])
                 if self._latent_fused():  # all T - 1 steps inside one persistent launch sequence, z in registers (dmm_latent_chain)
-                    ops.latent_chain([dict(G=lat["G16"][m], g=lat["g"][m], z=z[m], h_a=h[m], h_b=h2[m], bias_t=self.bias_t[m]) for m in mods],
-                                     rows=B, T=T, coef=lat["coef"], s_init=lat["s_init"], flags=lat["flags"])
+                    chain = [dict(G=lat["G16"][m], g=lat["g"][m], z=z[m], h_a=h[m], h_b=h2[m], bias_t=self.bias_t[m]) for m in mods]
+                    if parts:
+                        cuts = [len(plan)]  # plan[: cuts[0]] = the start; then one entry per launch
+                        for p in range(len(self._chain_parts(B, len(mods)))):
+                            ops.latent_chain(chain, rows=B, T=T, coef=lat["coef"], s_init=lat["s_init"], flags=lat["flags"], part=p)
+                            cuts.append(len(plan))
+                    else:
+                        ops.latent_chain(chain, rows=B, T=T, coef=lat["coef"], s_init=lat["s_init"], flags=lat["flags"])
                     if (T - 1) % 2:
                         h, h2 = h2, h
                 else:
@@ -1499,7 +1518,11 @@ class DiffusionEngine:
                         z, z2, h, h2 = z2, z, h2, h
             if len(self._chain_plans) > 16:
                 self._chain_plans.clear()
+            if parts:
+                plan = [plan[(0 if i == 0 else cuts[i]):cuts[i + 1]] for i in range(len(cuts) - 1)]  # segments; the first carries the start
             entry = self._chain_plans[key] = (plan, h)
+        if parts:
+            return entry[1], B, entry[0]
         L.replay(entry[0])
         return entry[1], B
 
@@ -1508,7 +1531,7 @@ class DiffusionEngine:
         first r1 - r0 rows of the view buffers (valid until the next call)."""
         n, I, lat = r1 - r0, self.I_chain, self._lat
         assert 0 < n <= self.view_rows
-        key = ("latent-view", n, tuple(mods), tuple(int(h0[m].data_ptr()) for m in mods), r0)
+        key = ("latent-view", n, tuple(mods), tuple(int(h0[m].data_ptr()) for m in mods), r0, L.stream())  # (a plan carries the stream it was recorded on)
         plan = self._view_plans.get(key)
         if plan is None:
             with L.Recorder() as plan:
@@ -1755,8 +1778,63 @@ class DiffusionEngine:
                 self._side_events[m].record(st)
             main.wait_event(self._side_events[m])
 
+    def _rebuild_overlapped(self, rows: CsrRows, ub: Tensor, deg_ptr: Tensor, out, cp: List[int], defer_join: bool) -> None:
+        """The CSR-started latent rebuild with the chain issued one launch at a time (DMM_REBUILD_OVERLAP, default on): the persistent chain fills
+        64 of its 111 row-block groups' slots in the first launch and 47 in the second (TikTok shape) -- 68 CUs idle for 1.3 ms.  A modality whose
+        groups are all done after a launch has its last item-sized GEMM and its top-k issued on a LOW-priority stream under the next launch; the
+        modalities the last launch finishes take the usual path (one batched GEMM, a top-k stream each).  self.edges_ready[m]: the event behind
+        modality m's top-k -- with defer_join the caller's stream is NOT joined to them (DeviceGraphBuilder.build_all(ready=...) waits per graph, so
+        that an early modality's graph build starts early as well)."""
+        M = self.M
+        h0, n, segs = self._latent_h0(rows=rows, parts=True)
+        ub32 = ub.to(torch.int32)
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_tail_streams"):
+            lo = torch.cuda.Stream.priority_range()[0]  # (least, greatest)
+            self._tail_streams = [torch.cuda.Stream(device=self.dev, priority=lo) for _ in range(M)]
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(M)]
+            self._side_events = [torch.cuda.Event() for _ in range(M + 1)]
+        ready: List[Optional[torch.cuda.Event]] = [None] * M
+        done = 0
+        for p, seg in enumerate(segs):
+            L.replay(seg)
+            upto = cp[p]
+            if upto <= done:
+                continue
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if p < len(segs) - 1:
+                for m in range(done, upto):
+                    st = self._tail_streams[m]
+                    st.wait_event(ev)
+                    with torch.cuda.stream(st):
+                        v = self._latent_views(h0, 0, n, [m])
+                        ops.topk_rows(v[0], ub32, deg_ptr, out[m], self.I_chain)
+                        ready[m] = torch.cuda.Event()
+                        ready[m].record(st)
+            else:
+                rest = list(range(done, M))
+                views = self._latent_views(h0, 0, n, rest)
+                ev2 = torch.cuda.Event()
+                ev2.record(main)
+                for v, m in zip(views, rest):
+                    st = self._side_streams[m]
+                    st.wait_event(ev2)
+                    with torch.cuda.stream(st):
+                        ops.topk_rows(v, ub32, deg_ptr, out[m], self.I_chain)
+                        ready[m] = torch.cuda.Event()
+                        ready[m].record(st)
+            done = upto
+        self.edges_ready = ready
+        if not defer_join:
+            for e in ready:
+                if e is not None:
+                    main.wait_event(e)
+            self.edges_ready = None
+
     def rebuild_edges(self, dense_rows, user_batches: Sequence[Tensor], deg_ptr: Tensor, n_edges: int, precision: int = 1,
-                      sampling_step: int = 0, csr: Optional[tuple] = None, init_cols: Optional[Tensor] = None) -> List[Tensor]:
+                      sampling_step: int = 0, csr: Optional[tuple] = None, init_cols: Optional[Tensor] = None, defer_join: bool = False) -> List[Tensor]:
         """Reverse chain over every user batch and modality, then per-user top-k (k = degree).  Returns per modality the
         int32 item ids laid out by deg_ptr (CSR of the user rows: out_idx[deg_ptr[u] : deg_ptr[u+1]]).  The ids in `user_batches`
         index deg_ptr and are what `dense_rows` receives (a user-sharded replica passes LOCAL ids and maps them itself).
@@ -1764,6 +1842,7 @@ class DiffusionEngine:
         sampling_step > 0 starts every modality's chain from its own noised x_T (Model.py:310-313), one chain at a time.
         init_cols (bounded samples of an epoch only: Coach.rebuild_limit): int32 items laid out by deg_ptr that the users NOT in `user_batches` keep
         -- their observed interactions -- so that a rebuild over a subset of the users still yields whole graphs."""
+        self.edges_ready = None
         if init_cols is not None:
             out = [init_cols[:max(1, n_edges)].to(torch.int32).clone() for _ in range(self.M)]
         else:
@@ -1785,6 +1864,13 @@ class DiffusionEngine:
                 continue
             if csr is not None and precision == 1 and sampling_step == 0:  # x_0 stays CSR: no dense [rows, I] operand is built
                 rows = CsrRows(csr[0], csr[1], ub + int(csr[2]))
+                cp = []
+                if latent and self.M > 1 and len(user_batches) == 1 and int(ub.numel()) <= self.view_rows and self.dev.type == "cuda" and self.ishard is None \
+                        and os.environ.get("DMM_REBUILD_OVERLAP", "1") != "0":
+                    cp = self._chain_parts(int(ub.numel()), self.M)
+                if len(cp) > 1 and cp[0] > 0:  # a modality is complete before the last launch: its tail runs under the next one
+                    self._rebuild_overlapped(rows, ub, deg_ptr, out, cp, defer_join)
+                    continue
                 if latent:  # the [rows, I] views are formed view_rows rows at a time and consumed by the top-k at once
                     h0, n = self._latent_h0(rows=rows)
                     ub32 = ub.to(torch.int32)

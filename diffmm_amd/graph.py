@@ -360,8 +360,10 @@ class DeviceGraphBuilder:
     def build(self, item_idx: torch.Tensor, validate: bool = False) -> Adjacency:
         return self.build_all([item_idx], validate)[0]
 
-    def build_all(self, item_lists, validate: bool = False):
-        """One graph per edge list (the M modality graphs of a rebuild): all launches first, then ONE read-back of the size records."""
+    def build_all(self, item_lists, validate: bool = False, ready=None):
+        """One graph per edge list (the M modality graphs of a rebuild): all launches first, then ONE read-back of the size records.
+        ready: per list an event (or None) behind the kernels that fill it on ANOTHER stream (DiffusionEngine.rebuild_edges(defer_join=True)): graph i's
+        stream waits for its own list only, so a modality whose edges are ready early is built early."""
         from . import _lib as L
         dev, N, nnz = self.dev, self.N, self.nnz
         metas = torch.zeros((len(item_lists), 8), dtype=torch.int32, device=dev)
@@ -388,6 +390,8 @@ class DeviceGraphBuilder:
             for i, item_idx in enumerate(item_lists):
                 st = self._streams[i]
                 st.wait_event(fork)
+                if ready is not None and ready[i] is not None:
+                    st.wait_event(ready[i])
                 rowptr, col, val, tasks, fix = outs[i]
                 with torch.cuda.stream(st):
                     L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,
@@ -396,6 +400,10 @@ class DeviceGraphBuilder:
                     done = torch.cuda.Event(); done.record(st)
                 main.wait_event(done)
         else:
+            if ready is not None:
+                for e in ready:
+                    if e is not None:
+                        torch.cuda.current_stream(dev).wait_event(e)
             for i, item_idx in enumerate(item_lists):
                 rowptr, col, val, tasks, fix = outs[i]
                 L.call("dmm_graph_build", L.ptr(self.user_ptr32), L.ptr(self.edge_user), L.ptr(item_idx), self.U, self.I, self.E, self.D, self.task_len,

@@ -242,10 +242,15 @@ def gemm_bf16_nt_batched(problems: Sequence[dict]) -> None:
     L.call("dmm_gemm_bf16_nt_batched", arr, len(problems), L.stream())
 
 
-def latent_chain(problems: Sequence[dict], rows: int, T: int, coef: Tensor, s_init: float, flags: Tensor) -> None:
+def latent_chain_groups_per_launch(H: int) -> int:
+    """Row-block groups (256 rows of one modality) a launch of the persistent chain holds; 0: it cannot run (or slices by itself)."""
+    return int(L.lib().dmm_latent_chain_groups_per_launch(int(H)))
+
+
+def latent_chain(problems: Sequence[dict], rows: int, T: int, coef: Tensor, s_init: float, flags: Tensor, part: Optional[int] = None) -> None:
     """All T - 1 latent-chain steps of up to 4 modalities in one persistent launch sequence (dmm_latent_chain).  problems: dicts with G (bf16
     [H, H]), g (fp32 [H]), z (fp32 [rows, H]: z_T), h_a / h_b (bf16 [rows, H]; h_a = h_{T-1} on entry), bias_t (fp32 [T, H]).  h_0 ends up in h_a when
-    T - 1 is even, else in h_b."""
+    T - 1 is even, else in h_b.  part: only that launch of the sequence (dmm_latent_chain_part; parts in order, on one stream)."""
     H = problems[0]["G"].shape[0]
     arr = (L.LatentChainArgs * len(problems))()
     for a, p in zip(arr, problems):
@@ -260,7 +265,10 @@ def latent_chain(problems: Sequence[dict], rows: int, T: int, coef: Tensor, s_in
             raise ValueError("latent_chain: h_a and h_b must share one leading dimension")
     if coef.dtype != torch.float32 or coef.numel() < 2 * T or flags.dtype != torch.int32 or not flags.is_contiguous():
         raise ValueError("latent_chain: coef must be fp32 [2 T], flags int32")
-    L.call("dmm_latent_chain", arr, len(problems), rows, H, T, L.ptr(coef), float(s_init), L.ptr(flags), flags.numel(), L.stream())
+    if part is None:
+        L.call("dmm_latent_chain", arr, len(problems), rows, H, T, L.ptr(coef), float(s_init), L.ptr(flags), flags.numel(), L.stream())
+    else:
+        L.call("dmm_latent_chain_part", arr, len(problems), rows, H, T, L.ptr(coef), float(s_init), L.ptr(flags), flags.numel(), int(part), L.stream())
 
 
 def cast_bf16(src: Tensor, dst: Tensor, cols: Optional[int] = None, cols_pad: Optional[int] = None) -> None:
@@ -621,6 +629,20 @@ def csr_gather_sum_latent(ptr: Tensor, col: Tensor, rows: Tensor, Wt: Tensor, bi
         raise ValueError("csr_gather_sum_latent: bad operands")
     L.call("dmm_csr_gather_sum_latent", p, c, r, B, L.ptr(Wt), Wt.stride(0), L.ptr(_f32c(bias, "bias")), H, L.ptr(z), z.stride(0), L.ptr(out16), out16.stride(0),
            L.stream())
+
+
+def csr_gather_sum_latent_batched(ptr: Tensor, col: Tensor, rows: Tensor, problems: Sequence[dict]) -> None:
+    """csr_gather_sum_latent for up to 4 operand tables (dicts Wt, bias, z, out16) over the same rows in one launch."""
+    p, c, r, B = _csr_args(ptr, col, rows)
+    H = problems[0]["bias"].numel()
+    arr = (L.CsrGatherProblem * len(problems))()
+    for a, q in zip(arr, problems):
+        Wt, bias, z, out16 = q["Wt"], q["bias"], q["z"], q["out16"]
+        if Wt.dtype != torch.bfloat16 or out16.dtype != torch.bfloat16 or Wt.stride(1) != 1 or out16.stride(1) != 1 or Wt.shape[1] < H or out16.shape[1] < H or \
+                out16.shape[0] < B or z.dtype != torch.float32 or z.stride(1) != 1 or z.shape[0] < B or z.shape[1] < H or bias.numel() != H:
+            raise ValueError("csr_gather_sum_latent_batched: bad operands")
+        a.Wt, a.ldw, a.bias, a.z, a.ldz, a.out16, a.ldo = L.ptr(Wt), Wt.stride(0), L.ptr(_f32c(bias, "bias")), L.ptr(z), z.stride(0), L.ptr(out16), out16.stride(0)
+    L.call("dmm_csr_gather_sum_latent_batched", p, c, r, B, arr, len(problems), H, L.stream())
 
 
 def csr_add_rows(ptr: Tensor, col: Tensor, rows: Tensor, I: int, c_: float, y: Optional[Tensor], y16: Optional[Tensor] = None) -> None:

@@ -180,6 +180,13 @@ int dmm_latent_chain(const dmm_latent_chain_args* a /*host array*/, int n_mod, i
  * its group barrier needs; 0 otherwise -- dmm_latent_chain then returns DMM_ERR_UNSUPPORTED without launching and the caller runs one
  * dmm_gemm_bf16_nt launch per step.  (Host query, no stream; DMM_LATENT_CUS=<n> overrides the CU count on a masked / partitioned device.) */
 int dmm_latent_chain_supported(int H);
+/* The chain one LAUNCH at a time.  dmm_latent_chain runs ceil(n_mod * ceil(rows / 256) / G) launches of G = dmm_latent_chain_groups_per_launch(H)
+ * row-block groups each (modality-major: launch p holds groups p G .. (p + 1) G - 1; 0 = the persistent form cannot run or slices by itself);
+ * dmm_latent_chain_part issues launch `part` alone, so that the host can put the finished modalities' last GEMM and top-k on another stream UNDER
+ * the next launch, which leaves CUs idle (111 groups at the TikTok shape = 64 + 47).  Parts must be issued in order on one stream. */
+int dmm_latent_chain_groups_per_launch(int H);
+int dmm_latent_chain_part(const dmm_latent_chain_args* a /*host array*/, int n_mod, int rows, int H, int T, const float* coef, float s_init, int32_t* flags,
+                          int flags_len, int part, void* stream);
 int dmm_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int cols_pad, void* stream);
 /* dst[c, r] = bf16(src[r, c]) for r < rows; dst[c, rows..rows_pad) = 0 (makes the K-contiguous operand of a TN / NN product) */
 int dmm_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols, int rows_pad, void* stream);
@@ -361,6 +368,15 @@ int dmm_csr_add_rows(const int64_t* ptr, const int32_t* col, const int64_t* rows
  * items(rows[b])} Wt[j, :H] (fp32, = x_0 W1x^T) and out16 = bf16(tanh(z + bias)), the first step's layer-1 activation */
 int dmm_csr_gather_sum_latent(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const void* Wt, int64_t ldw, const float* bias, int H,
                               float* z, int64_t ldz, void* out16, int64_t ldo, void* stream);
+/* The same start for up to 4 operand tables in ONE launch (the M modalities' chains start from the same rows). */
+typedef struct dmm_csr_gather_problem {
+  const void* Wt; int64_t ldw;   /* bf16 [I, >= H]: W1x^T */
+  const float* bias;             /* [H]: bias_t[T - 1] */
+  float* z; int64_t ldz;         /* fp32 [B, >= H] out: z_T */
+  void* out16; int64_t ldo;      /* bf16 [B, >= H] out: h_{T-1} = tanh(z_T + bias) */
+} dmm_csr_gather_problem;
+int dmm_csr_gather_sum_latent_batched(const int64_t* ptr, const int32_t* col, const int64_t* rows, int B, const dmm_csr_gather_problem* p /*host array*/, int n,
+                                      int H, void* stream);
 /* out[b, :I] = a_table[t_b] * x[b, :I] + c_table[t_b] * y[b, :I] (per-row timesteps): forward_cal_xt with explicit noise (Model.py:339-341)
  * and the posterior mean c1[t] * Denoise(x_t, t) + c2[t] * x_t of p_mean_variance (Model.py:375), for the reference-named Python API
  * (the training / rebuild engines fuse both into their GEMM operands and epilogues). */

@@ -91,3 +91,41 @@ def test_latent_chain_equals_the_cpu_oracle_chain(data, T, rows, train_iters):
           f"{share:.4f} of the oracle's {len(ref)} top-k edges; CPU oracle chain {cpu_s:.1f}s")
     assert err <= 2e-2, f"latent chain vs oracle.generate_view at T={T}: {err:.3e} of the output scale"
     assert share >= 0.97, f"T={T}: only {share:.4f} of the oracle's top-k edges"
+
+
+def test_rebuild_with_the_tail_under_the_next_chain_launch_gives_the_same_edges(data):
+    """DiffusionEngine.rebuild_edges at the bench shape (9308 users x 3 modalities = 111 row-block groups = two launches of the persistent chain):
+    with DMM_REBUILD_OVERLAP (default) the first modality's last GEMM and top-k run on a low-priority stream under the second launch
+    (dmm_latent_chain_part); without it the chain runs whole and the three modalities' GEMM is one batched launch.  Same kernels on the same inputs:
+    the edge lists must be bit-identical, the chain's error word clear, and the events handed to the graph builder (defer_join) must cover the lists."""
+    from diffmm_amd.engine import DiffusionEngine
+    from diffmm_amd import graph, ops
+    dev, g, dd, deg, _ = data
+    M, T = 3, 6
+    E = DiffusionEngine(I_, D_, H_, TE, M, T, HP, dev, 4096, chain_rows=g.users)
+    for m in range(M):
+        E.load_reference_state(m, _denoise_init(torch.Generator().manual_seed(7 + m)))
+    per = ops.latent_chain_groups_per_launch(H_)
+    assert per > 0 and E._chain_parts(g.users, M) == [min(M, per // (-(-g.users // 256))), M], "the bench shape is expected to take two launches"
+    users = torch.arange(g.users, device=dev)
+    args = (dd.rows, [users], dd.deg_ptr32, int(dd.ptr[-1]))
+    kw = dict(precision=1, csr=(dd.ptr, dd.col32, 0))
+    os.environ["DMM_REBUILD_OVERLAP"] = "0"
+    try:
+        plain = [e.clone() for e in E.rebuild_edges(*args, **kw)]
+    finally:
+        os.environ.pop("DMM_REBUILD_OVERLAP", None)
+    E.check_chain_error()
+    over = [e.clone() for e in E.rebuild_edges(*args, **kw)]  # (joined inside)
+    assert E.edges_ready is None
+    E.check_chain_error()
+    for m in range(M):
+        assert torch.equal(plain[m], over[m]), f"modality {m}: overlapped rebuild differs"
+    # deferred join: the caller's stream is not joined; the graph builder waits per list
+    deferred = E.rebuild_edges(*args, defer_join=True, **kw)
+    assert E.edges_ready is not None and all(e is not None for e in E.edges_ready)
+    gb = graph.DeviceGraphBuilder(dd.ptr, dd.users, dd.items, D_)
+    adjs = gb.build_all(deferred, ready=E.edges_ready)
+    ref = gb.build_all(plain)
+    for a, b in zip(adjs, ref):
+        assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col, b.col) and torch.equal(a.val, b.val)
