@@ -341,11 +341,18 @@ class Coach:
 
         # ---- phase 3: joint training (Main.py:292-377) ----
         acc = torch.zeros(J.loss_parts.numel(), dtype=torch.float64, device=dev)
+        in_kernel_acc = isinstance(getattr(J, "loss_acc", None), torch.Tensor)  # (the single-GPU engine: its loss reduction adds to fp64 sums itself)
+        if in_kernel_acc:
+            J.loss_acc.zero_()
         if prefetched is not None:
             torch.cuda.current_stream(dev).wait_event(prefetched)
         for users, pos, neg in h.trainLoader:  # the same shuffled minibatches on every replica (identically seeded loader generator)
             noise = [draws.rand((J.N, J.D)).to(dev) for _ in range(3)] if draws is not None else None
-            acc += J.step(users, pos, neg, noise=noise, precision=prec)
+            lp = J.step(users, pos, neg, noise=noise, precision=prec)
+            if not in_kernel_acc:
+                acc += lp
+        if in_kernel_acc:
+            acc = J.loss_acc.clone()
         nT = J.n_terms
         if lay is not None:  # [terms..., bpr, reg over the own users, reg over the items]: the user part is a partial sum -- the item part too when
             part = acc[nT + 1:nT + 3] if not getattr(J, "replicated_items", True) else acc[nT + 1:nT + 2]  # the items are sharded as well

@@ -131,6 +131,8 @@ _SIGS = {
     "dmm_segment_sum": (C.c_int, [_P, _I, _L, _F, _P, _P]),
     "dmm_sumsq_scratch": (C.c_int64, [_L]),
     "dmm_sumsq": (C.c_int, [_P, _L, _F, _P, _P, _P]),
+    "dmm_loss_reduce": (C.c_int, [_P, _I, _L, _F, _P, _P, _L, _F, _P, _P, _P, _I, _P]),
+    "dmm_zero_regions": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int64), _I, _P]),
     "dmm_adam_step": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P]),
     "dmm_adam_step_prefix": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L]),
     "dmm_adam_step_x16": (C.c_int, [_P, _P, _P, _P, _L, C.POINTER(_P), C.POINTER(_L), _I, _F, _F, _F, _F, _F, _I, _P, _L, _P, _L, _L]),

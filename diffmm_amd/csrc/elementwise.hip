@@ -250,6 +250,70 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
 }
 
+// The joint step's loss reductions in ONE launch (they were three: dmm_segment_sum, dmm_sumsq's two): blocks [0, n_seg) sum the row-loss segments
+// (fp64, fixed order), the other blocks form partial sums of squares of x and the LAST of them to arrive adds the partials in index order -- the same
+// values, the same order as the separate launches, so the result does not depend on which block is last.  `acc` (optional, fp64): the epoch's
+// running sums, acc[k] += out[k] by the one thread that writes out[k] (Coach.trainEpoch added loss_parts after every step with a torch launch).
+// counter: one int, zero before the first launch; the last block resets it.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ seg_in, int n_seg, int64_t len, float seg_scale, float* __restrict__ seg_out,
+                                                          const float* __restrict__ x, int64_t n, float x_scale, float* __restrict__ partial,
+                                                          int* __restrict__ counter, float* __restrict__ x_out, double* __restrict__ acc, int acc_x) {
+  __shared__ double smd[4];
+  __shared__ float smf[4];
+  __shared__ int last;
+  if ((int)blockIdx.x < n_seg) {
+    const float* p = seg_in + (size_t)blockIdx.x * len;
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < len; i += 256) a += (double)p[i];
+    a = block_sum_256d(a, smd);
+    if (threadIdx.x == 0) {
+      const float o = (float)(a * (double)seg_scale);
+      seg_out[blockIdx.x] = o;
+      if (acc) acc[blockIdx.x] += (double)o;
+    }
+    return;
+  }
+  const int bx = (int)blockIdx.x - n_seg, gx = (int)gridDim.x - n_seg;
+  float a = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n4; i += (int64_t)gx * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (bx == 0 && threadIdx.x < (n & 3)) {
+    const float v = x[(n4 << 2) + threadIdx.x];
+    a += v * v;
+  }
+  a = block_sum_256(a, smf);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + bx, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(counter, 1) == gx - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;
+  for (int i = threadIdx.x; i < gx; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = block_sum_256d(t, smd);
+  if (threadIdx.x == 0) {
+    const float o = (float)(t * (double)x_scale);
+    x_out[0] = o;
+    if (acc) acc[acc_x] += (double)o;
+    *counter = 0;
+  }
+}
+
+// up to 4 regions cleared by one launch (the joint step cleared its accumulation arena and the projections' weight gradients with two memsets)
+struct ZeroRegions { float4* p[4]; long long n16[4]; int cnt; };
+__global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegions Z) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < Z.cnt; ++r) {
+    float4* __restrict__ p = Z.p[r];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < Z.n16[r]; i += (long long)gridDim.x * 256) p[i] = z;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adam
 // ---------------------------------------------------------------------------------------------
@@ -562,6 +626,35 @@ extern "C" int dmm_sumsq(const float* x, int64_t n, float scale, float* scratch,
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
   hipLaunchKernelGGL(segment_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, (int64_t)grid, scale, out);
   DMM_LAUNCH_CHECK("dmm_sumsq");
+  return 0;
+}
+
+extern "C" int dmm_loss_reduce(const float* seg_in, int n_seg, int64_t len, float seg_scale, float* seg_out, const float* x, int64_t n, float x_scale,
+                               float* scratch, float* x_out, double* acc, int acc_x, void* stream) {
+  DMM_CHECK_ARG(seg_in && seg_out && n_seg > 0 && n_seg <= 65535 && len > 0 && x && scratch && x_out && n > 0 && ((uintptr_t)x & 15) == 0 && acc_x >= 0,
+                "dmm_loss_reduce: bad arguments");
+  const unsigned grid = grid_for(n / 4 + 1, 1024);  // scratch: dmm_sumsq_scratch(n) + 1 floats; the last one is the arrival counter (zero before the first call)
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid + n_seg), dim3(256), 0, (hipStream_t)stream, seg_in, n_seg, len, seg_scale, seg_out, x, n, x_scale, scratch,
+                     reinterpret_cast<int*>(scratch + grid), x_out, acc, acc_x);
+  DMM_LAUNCH_CHECK("dmm_loss_reduce");
+  return 0;
+}
+
+extern "C" int dmm_zero_regions(void* const* ptrs, const int64_t* bytes, int n, void* stream) {
+  DMM_CHECK_ARG(ptrs && bytes && n >= 1 && n <= 4, "dmm_zero_regions: 1..4 regions");
+  ZeroRegions Z;
+  memset(&Z, 0, sizeof(Z));
+  long long most = 0;
+  for (int i = 0; i < n; ++i) {
+    DMM_CHECK_ARG(ptrs[i] && bytes[i] >= 0 && bytes[i] % 16 == 0 && ((uintptr_t)ptrs[i] & 15) == 0, "dmm_zero_regions: region %d must be 16-byte aligned, whole 16-byte pieces", i);
+    Z.p[i] = reinterpret_cast<float4*>(ptrs[i]);
+    Z.n16[i] = bytes[i] / 16;
+    most = std::max(most, Z.n16[i]);
+  }
+  Z.cnt = n;
+  if (most == 0) return 0;
+  hipLaunchKernelGGL(zero_regions_kernel, dim3(grid_for(most, 2048)), dim3(256), 0, (hipStream_t)stream, Z);
+  DMM_LAUNCH_CHECK("dmm_zero_regions");
   return 0;
 }
 

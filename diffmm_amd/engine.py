@@ -197,7 +197,7 @@ class JointEngine:
         self.T = [z(N, D) for _ in range(M)]
         self.dfeat = [z(items, D) for _ in range(M)]
         self.mix_partials = z(int(L.lib().dmm_gcn_mix_partials(N * D)))
-        self.sumsq_scratch = z(int(L.lib().dmm_sumsq_scratch(N * D)))
+        self.sumsq_scratch = z(int(L.lib().dmm_sumsq_scratch(N * D)) + 1)  # (+ 1: dmm_loss_reduce's arrival counter)
         self.B_max = B_max
         self.n_slots = 2 + 2 * M + 4
         self.zhat = z(self.n_slots, B_max, D)
@@ -210,6 +210,8 @@ class JointEngine:
         self.lse = z(self.n_terms, B_max)
         self.row_loss = z(self.n_terms + 1, B_max)
         self.loss_parts = z(self.n_terms + 2)  # per-term InfoNCE, bpr, reg
+        # fp64 running sums of loss_parts over the steps since the caller last cleared it (Coach.trainEpoch: one epoch), added by dmm_loss_reduce
+        self.loss_acc = torch.zeros(self.n_terms + 2, dtype=torch.float64, device=self.dev)
         self.lr = float(hp["lr"])
         self.adj: Optional[Adjacency] = None
         self.modal_adj: List[Adjacency] = []
@@ -419,13 +421,18 @@ class JointEngine:
         if noise is None and update and self._philox_refs is None:
             return self._step_planned(users, pos, neg, precision)
         x16 = self._x16()
-        if x16 is None:
-            ops.zero_(self._zero_arena)  # gradient rows filled by scatter-adds, InfoNCE row gradients, K-sliced projections: one memset
+        ne_ = N * D
+        gtail = self.P.grad[ne_:self.P.offsets["modal_weight"]]  # the projections' weight / bias gradients: accumulated by K slices (atomics) at the end of the step
+        # gradient rows filled by scatter-adds, InfoNCE row gradients, K-sliced projections + the gradient tail above: ONE launch clears both regions
+        # graphs beyond the caches (bf16 gather operands): the (M + 3) N d scatter targets are NOT cleared by a pass over all rows.  dFin /
+        # dCl1 / dCl2 are zero outside the minibatch's rows and get those rows cleared again once they are consumed (below); the dZ_m are
+        # written, not accumulated into, by the mixing backward, and the CL gradients are scattered into them afterwards.
+        arena = self._zero_arena if x16 is None else self._zero_arena[(M + 3) * N * D:]
+        if gtail.numel() % 4 == 0 and arena.numel() % 4 == 0 and gtail.data_ptr() % 16 == 0 and arena.data_ptr() % 16 == 0:
+            ops.zero_regions([arena, gtail])
         else:
-            # graphs beyond the caches (bf16 gather operands): the (M + 3) N d scatter targets are NOT cleared by a pass over all rows.  dFin /
-            # dCl1 / dCl2 are zero outside the minibatch's rows and get those rows cleared again once they are consumed (below); the dZ_m are
-            # written, not accumulated into, by the mixing backward, and the CL gradients are scattered into them afterwards.
-            ops.zero_(self._zero_arena[(M + 3) * N * D:])
+            ops.zero_(arena)
+            ops.zero_(gtail)
         self.forward(noise=noise, with_cl=True, precision=precision, _arena_zeroed=True)
         slots, terms = self._slots_terms(users, pos)
         nT = self.n_terms
@@ -440,8 +447,9 @@ class JointEngine:
         ops.gather_normalize(slots, B, D, zhat, znorm, self.pack)
         ops.infonce_fwd_bwd(zhat, terms, nT, B, D, lse, row_loss, dzhat, **pk)  # (rows are unit-norm: forward + both gradient passes in one call)
         ops.bpr_fwd_bwd(self.Fin, users, pos, neg, U, row_loss[nT], self.dFin)
-        ops.segment_sum(row_loss, nT + 1, B, 1.0, self.loss_parts)
-        ops.sumsq(self.P.view("emb"), hp["reg"], self.loss_parts[nT + 1:], self.sumsq_scratch)
+        # row losses -> loss_parts[: nT + 1], the l2 term -> loss_parts[nT + 1], and both added to the epoch's fp64 sums loss_acc: one launch
+        ops.loss_reduce(row_loss, nT + 1, B, 1.0, self.loss_parts, self.P.view("emb"), hp["reg"], self.loss_parts[nT + 1:], self.sumsq_scratch,
+                        acc=self.loss_acc, acc_x=nT + 1)
         # ---- backward ----
         A = self.adj
         s = 1.0 + hp["residual_weight"]
@@ -476,9 +484,8 @@ class JointEngine:
         ops.spmm_batched(batch)
         names = modality_names(M)
         ne = self.N * D
-        # the projection weight gradients are accumulated by K slices (atomics): one memset for all of them (d(modal_weight), behind
-        # them in the flat buffer, was written by the mixing backward above and stays)
-        ops.zero_(self.P.grad[ne:self.P.offsets["modal_weight"]])
+        # (the projection weight gradients, accumulated by K slices with atomics, were cleared with the arena at the top of the step; d(modal_weight),
+        # behind them in the flat buffer, was written by the mixing backward above and stays)
         # backward of the normalisation + the projection biases' gradients (column sums, into the region zeroed above): one launch for all modalities
         ops.rownorm_bwd_batched([dict(dy=self.T[m][U:], y=self.nf[m], norm=self.fnorm[m], dx=self.dfeat[m], csum=self.P.g(f"{n}_layer.bias"))
                                  for m, n in enumerate(names)])
@@ -1811,6 +1818,7 @@ class DiffusionEngine:
                     with torch.cuda.stream(st):
                         v = self._latent_views(h0, 0, n, [m])
                         ops.topk_rows(v[0], ub32, deg_ptr, out[m], self.I_chain)
+                        ub32.record_stream(st)  # (this stream is not joined before ub32 goes out of scope: its block must not be handed out early)
                         ready[m] = torch.cuda.Event()
                         ready[m].record(st)
             else:
@@ -1823,6 +1831,7 @@ class DiffusionEngine:
                     st.wait_event(ev2)
                     with torch.cuda.stream(st):
                         ops.topk_rows(v, ub32, deg_ptr, out[m], self.I_chain)
+                        ub32.record_stream(st)
                         ready[m] = torch.cuda.Event()
                         ready[m].record(st)
             done = upto

@@ -535,6 +535,25 @@ def sumsq(x: Tensor, scale: float, out: Tensor, scratch: Optional[Tensor] = None
     L.call("dmm_sumsq", L.ptr(x), n, scale, L.ptr(scratch), L.ptr(out), L.stream())
 
 
+def loss_reduce(row_loss: Tensor, n_seg: int, seg_len: int, seg_scale: float, seg_out: Tensor, x: Tensor, x_scale: float, x_out: Tensor, scratch: Tensor,
+                acc: Optional[Tensor] = None, acc_x: int = 0) -> None:
+    """segment_sum(row_loss ...) and sumsq(x ...) in one launch (dmm_loss_reduce).  scratch: fp32 [dmm_sumsq_scratch(x.numel()) + 1], zero when first used;
+    acc: fp64 running sums (acc[k] += seg_out[k], acc[acc_x] += x_out[0])."""
+    n = x.numel()
+    if scratch.dtype != torch.float32 or scratch.numel() < int(L.lib().dmm_sumsq_scratch(n)) + 1 or (acc is not None and (acc.dtype != torch.float64 or acc.numel() <= max(acc_x, n_seg - 1))):
+        raise ValueError("loss_reduce: scratch too small / acc must be fp64 covering the outputs")
+    L.call("dmm_loss_reduce", L.ptr(row_loss), n_seg, seg_len, seg_scale, L.ptr(seg_out), L.ptr(x), n, x_scale, L.ptr(scratch), L.ptr(x_out),
+           L.ptr(acc) if acc is not None else None, acc_x, L.stream())
+
+
+def zero_regions(ts: Sequence[Tensor]) -> None:
+    """Up to 4 contiguous tensors cleared by one launch (dmm_zero_regions)."""
+    for t in ts:
+        if not t.is_contiguous() or (t.numel() * t.element_size()) % 16 or t.data_ptr() % 16:
+            raise ValueError("zero_regions: contiguous, 16-byte aligned tensors of whole 16-byte pieces")
+    L.call("dmm_zero_regions", (L._P * len(ts))(*[L.ptr(t) for t in ts]), (C.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts]), len(ts), L.stream())
+
+
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, extra: Sequence[Tensor] = (), extra_n: Sequence[int] = (),
               l2_coef: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, l2_n: Optional[int] = None,
               p16: Optional[Tensor] = None, p16_lo: int = 0) -> None:

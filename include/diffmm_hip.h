@@ -310,6 +310,14 @@ int dmm_segment_sum(const float* in, int n_seg, int64_t len, float scale, float*
 /* out[0] = scale * sum(x^2) (l2_reg_loss, Utils.py:45-54); scratch: dmm_sumsq_scratch(n) floats. */
 int64_t dmm_sumsq_scratch(int64_t n);
 int dmm_sumsq(const float* x, int64_t n, float scale, float* scratch, float* out, void* stream);
+/* dmm_segment_sum(seg_in ...) and dmm_sumsq(x ...) of the joint step (the InfoNCE / BPR row losses and the l2 term, Main.py:353-362) in ONE launch:
+ * seg_out[k] = seg_scale * sum(seg_in[k * len .. ]), x_out[0] = x_scale * sum(x^2) -- the same sums in the same order.  scratch: dmm_sumsq_scratch(n) + 1
+ * floats, the last one zero before the first call (an arrival counter the kernel resets).  acc (optional, device fp64): running sums over the steps
+ * of an epoch, acc[k] += seg_out[k], acc[acc_x] += x_out[0]. */
+int dmm_loss_reduce(const float* seg_in, int n_seg, int64_t len, float seg_scale, float* seg_out, const float* x, int64_t n, float x_scale, float* scratch,
+                    float* x_out, double* acc, int acc_x, void* stream);
+/* Up to 4 regions (16-byte aligned, whole 16-byte pieces) cleared by one launch. */
+int dmm_zero_regions(void* const* ptrs /*host*/, const int64_t* bytes /*host*/, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam defaults: betas 0.9/0.999, eps 1e-8, weight_decay 0; Main.py:92-110,189-192,377).
