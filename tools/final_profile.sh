@@ -3,10 +3,10 @@
 # roofline, fp32-like rate), rocprofv3 stats of the bench, stats + separate PMC passes of the isolated roofline launches.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-r2c}; O=gpurun_out/final_$TAG; mkdir -p $O
-timeout -k 10 700 python3 bench.py > $O/bench_full.log 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o ${TAG}_bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-roofline --no-fp32-like > $O/prof_bench.log 2>&1 || exit 1
+timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $O/bench_full.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o ${TAG}_bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-roofline --no-fp32-like --no-roofline > $O/prof_bench.log 2>&1 || exit 1
 T=$(find $O/prof_bench -name "${TAG}_bench_kernel_trace.csv" | head -1)
-python3 tools/trace_phases.py $T 18 16 > $O/phases.txt 2>&1
+python3 tools/trace_phases.py $T 18 > $O/phases.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain/trace -o t -- python3 tools/roofline_target.py > $O/log_trace.txt 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "8ph" --output-format csv -d $O/chain/fetch -o f -- python3 tools/roofline_target.py 4 > $O/log_f.txt 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "8ph" --output-format csv -d $O/chain/write -o w -- python3 tools/roofline_target.py 4 > $O/log_w.txt 2>&1 || exit 1
