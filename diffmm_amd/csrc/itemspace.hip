@@ -62,6 +62,91 @@ __global__ __launch_bounds__(256) void item_project_kernel(const BatchT batch) {
   for (int mt = 0; mt < MT; ++mt) xrow[mt] = X + (long long)min(row0 + mt * 16 + fr, B - 1) * ldx + kg * 8;
   const __bf16* xrow16 = reinterpret_cast<const __bf16*>(X) + (long long)min(row0 + fr, B - 1) * ldx + kg * 8;  // (XB)
 
+  // ---- MT == 1, d <= 128 (r4): the stages of a workgroup's K slice as a software pipeline.  A stage was: request X, barrier, load F piece by piece
+  // into LDS, barrier, 16 MFMAs -- a serial chain of two memory round trips, repeated per stage (the joint step's text modality: 3 stages; the
+  // folded products of the diffusion step: dozens).  Here the NEXT stage's X fragments and F pieces are requested into a second register set
+  // before the current stage is converted into LDS and multiplied; every load is unconditional (clamped address + select), so the compiler keeps
+  // counted waits and the younger set stays in flight across the barriers.  F transposed with K % 4 != 0 (an element-granular tail) keeps the loop below.
+  constexpr bool PIPE = MT == 1 && D <= 128;
+  if (PIPE && (!FT || (I & 3) == 0)) {
+    constexpr int NF = FT ? D * (KSG / 4) / 256 : KSG * (D / 4) / 256;  // 16-byte pieces of the F stage per thread
+    struct Stage { float4 xs[NSTEP][2]; float4 fv[NF]; };
+    auto request = [&](int k0, Stage& R) {
+      const int steps = min(KSG, (kend - k0 + 31) & ~31) / 32;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const int kq = k0 + min(s, steps - 1) * 32;
+        if (XB) R.xs[s][0] = *reinterpret_cast<const float4*>(xrow16 + kq);
+        else {
+          R.xs[s][0] = *reinterpret_cast<const float4*>(xrow[0] + kq);
+          R.xs[s][1] = *reinterpret_cast<const float4*>(xrow[0] + kq + 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        if (!FT) {  // F is [K, D]: row k of the stage
+          const int kk = idx / (D / 4), c4 = idx % (D / 4);
+          const int k = min(k0 + kk, kend - 1);
+          R.fv[j] = *reinterpret_cast<const float4*>(F + (long long)k * ldf + c4 * 4);
+        } else {    // F is [D, K]: four consecutive k of column c
+          const int c = idx / (KSG / 4), k4 = (idx % (KSG / 4)) * 4;
+          const int k = min(k0 + k4, kend - 4);  // (kend % 4 == 0 here: I % 4 == 0 and whole 32-item slices)
+          R.fv[j] = *reinterpret_cast<const float4*>(F + (long long)c * ldf + k);
+        }
+      }
+    };
+    auto to_lds = [&](int k0, const Stage& R) {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        float4 v = R.fv[j];
+        if (!FT) {
+          const int kk = idx / (D / 4), c4 = idx % (D / 4);
+          if (k0 + kk >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 0) * LDT + kk * 2) = (__bf16)v.x;
+          *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 1) * LDT + kk * 2) = (__bf16)v.y;
+          *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 2) * LDT + kk * 2) = (__bf16)v.z;
+          *reinterpret_cast<__bf16*>(ft + (c4 * 4 + 3) * LDT + kk * 2) = (__bf16)v.w;
+        } else {
+          const int c = idx / (KSG / 4), k4 = (idx % (KSG / 4)) * 4;
+          if (k0 + k4 >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<bf16x4v*>(ft + c * LDT + k4 * 2) = bf16x4v{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        }
+      }
+    };
+    auto multiply = [&](int k0, const Stage& R) {
+      const int steps = min(KSG, (kend - k0 + 31) & ~31) / 32;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s < steps) {
+          const bf16x8 fa = XB ? __builtin_bit_cast(bf16x8, R.xs[s][0]) : is_cvt8(R.xs[s][0], R.xs[s][1]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(ft + (nt * 16 + fr) * LDT + (s * 32 + kg * 8) * 2);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[0][nt], 0, 0, 0);
+          }
+        }
+      }
+    };
+    Stage A, Bq;  // static names: the loop is unrolled by two (runtime-indexed register arrays would go to scratch)
+    request(kbeg, A);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * KSG) {
+      const bool has1 = k0 + KSG < kend, has2 = k0 + 2 * KSG < kend;
+      if (has1) request(k0 + KSG, Bq);
+      __syncthreads();  // the previous stage's fragment reads are done
+      to_lds(k0, A);
+      __syncthreads();
+      multiply(k0, A);
+      if (!has1) break;
+      if (has2) request(k0 + 2 * KSG, A);
+      __syncthreads();
+      to_lds(k0 + KSG, Bq);
+      __syncthreads();
+      multiply(k0 + KSG, Bq);
+    }
+  } else
   for (int k0 = kbeg; k0 < kend; k0 += KSG) {
     const int steps = min(KSG, (kend - k0 + 31) & ~31) / 32;
     // MT == 1 (one 16-row tile per wave: two loads per lane and k-step would leave the loop latency-bound): the X fragments of the WHOLE stage
@@ -678,7 +763,8 @@ static int project_batched(const dmm_project_problem* p, int n, int D, int f_tra
     int want = std::max(1, std::min(64, (out_transposed ? wgs_bwd : wgs_fwd) / std::max(1, rows_all)));
     // the forward projections feed replicated state of the user-sharded engine: at most TWO slices, so that the atomic sum is a single
     // commutative addition and the result does not depend on arrival order (bit-identical on every replica)
-    if (!out_transposed) want = std::min(want, 2);
+    static const int fwd_slices = [] { const char* e = getenv("DMM_PROJ_FWD_SLICES"); return e ? atoi(e) : 2; }();  // (experiments: > 2 gives up the bit-identity)
+    if (!out_transposed) want = std::min(want, fwd_slices);
     int kchunk = (((q.K + want - 1) / want) + 31) & ~31;
     kchunk = std::max(kchunk, 32);
     b.p[i] = ProjP{q.X, (long long)q.ldx, q.F, (long long)q.ldf, q.out, (long long)q.ldo, q.bias, q.rows, q.K, kchunk};
