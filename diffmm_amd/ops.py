@@ -79,7 +79,10 @@ class SpmmOp:
         p.y16, p.y_pert16 = L.ptr(y16), L.ptr(y_pert16)
         p.n_rows = adj.n
         p.n_partial_blocks, p.n_fix = adj.n_partial_blocks, (int(adj.fix.shape[0]) if adj.fix is not None else 0)
-        p.fix = L.ptr(adj.fix) if adj.fix is not None else None
+        # (a persistent adjacency -- rebuilt in place, its launches replayed from recorded plans -- may have NO giant row when a plan is recorded and some
+        # after a later rebuild: the plan must hold the fix buffer's address even while the current slice of it is empty, and Tensor.data_ptr() of an
+        # empty tensor is null)
+        p.fix = (adj.fix.untyped_storage().data_ptr() + adj.fix.storage_offset() * adj.fix.element_size()) if adj.fix is not None else None
         p.partial = L.ptr(partial) if partial is not None else None
         self.adj = adj
         p.n_tasks = adj.n_tasks

@@ -1382,3 +1382,37 @@ def test_item_project_bf16_x_is_bit_identical(dev, D):
         outs.append(out)
     for a, b in zip(*outs):
         close(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-6 * float(b.abs().max()), what="transposed form")
+
+
+@pytest.mark.gpu
+def test_recorded_spmm_survives_a_rebuild_that_brings_giant_rows(dev):
+    """A graph rebuilt in place (DeviceGraphBuilder(reuse=True)) keeps its buffers and its Adjacency object; a launch recorded while the graph had NO giant
+    row must still be valid after a rebuild that has some -- engine.patch_spmm_sizes refreshes the sizes, the fix list's address has to be in the
+    recorded problem already (Tensor.data_ptr() of the then-empty slice is null: the round-4 failure of test_tiktok_shape_epochs_with_bf16_gather_operands,
+    where the first rebuilt graphs of a run had no row above 1024 entries and a later one did)."""
+    from diffmm_amd import graph, ops, _lib as L
+    from diffmm_amd.engine import plan_spmm_refs, patch_spmm_sizes
+    rng = np.random.default_rng(3)
+    users, n_items, D, task_len = 3000, 400, 32, 16
+    deg = np.full(users, 2)
+    ptr = np.concatenate([[0], np.cumsum(deg)])
+    flat = lambda lists: T(np.concatenate(lists).astype(np.int32), dev)
+    spread = [np.sort(rng.choice(np.arange(1, n_items), size=2, replace=False)) for _ in range(users)]           # no item above a few dozen users
+    hub = [np.array([0, int(rng.integers(1, n_items))]) for _ in range(users)]                                    # item 0 chosen by everyone: a giant row
+    gb = graph.DeviceGraphBuilder(T(ptr, dev), users, n_items, D, task_len, reuse=True)
+    adj = gb.build_all([flat(spread)])[0]
+    assert adj.persistent and adj.n_partial_blocks == 0
+    x = T(rng.standard_normal((users + n_items, D)).astype(np.float32), dev)
+    y = torch.zeros_like(x)
+    with L.Recorder() as plan:
+        ops.spmm_batched([ops.SpmmOp(adj, x, y=y)])
+    refs = plan_spmm_refs(plan, [adj])
+    L.replay(plan)
+    dense = lambda a: torch.sparse_csr_tensor(a.rowptr.long(), a.col.long(), a.val, (a.n, a.n)).to_dense()
+    close(y.cpu().numpy(), (dense(adj) @ x).cpu().numpy(), rtol=1e-5, atol=1e-5, what="before the rebuild")
+    adj2 = gb.build_all([flat(hub)])[0]
+    assert adj2 is adj and adj.n_partial_blocks > 0 and adj.fix.shape[0] > 0
+    patch_spmm_sizes(refs)
+    y.zero_()
+    L.replay(plan)  # (raised "giant rows need partial + fix buffers" before the fix)
+    close(y.cpu().numpy(), (dense(adj) @ x).cpu().numpy(), rtol=1e-5, atol=1e-5, what="after the rebuild")
