@@ -322,3 +322,12 @@ def test_tolerant_config_loading(tmp_path, caplog):
         for f in ("baby.toml", "test.toml"):
             with pytest.raises(TypeError):
                 load_config(os.path.join(ref_conf, f))
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() -- what the driver runs as its build check -- compiles (a no-op `make` when the library is current), loads the
+    library and agrees with include/diffmm_hip.h on the version (it once kept a stale literal after the header's version moved)."""
+    import importlib
+    sys.path.insert(0, REPO) if REPO not in sys.path else None
+    g = importlib.import_module("__graft_entry__")
+    g.build()
