@@ -328,6 +328,8 @@ def test_graft_entry_build_runs():
     """__graft_entry__.build() -- what the driver runs as its build check -- compiles (a no-op `make` when the library is current), loads the
     library and agrees with include/diffmm_hip.h on the version (it once kept a stale literal after the header's version moved)."""
     import importlib
-    sys.path.insert(0, REPO) if REPO not in sys.path else None
+    import sys
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
     g = importlib.import_module("__graft_entry__")
     g.build()
