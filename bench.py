@@ -43,7 +43,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # MI355X_MICROARCH.md, "Indexed rows": whole rows gathered by index read at 5.5-5.8 TB/s from a table far beyond the Infinity Cache (each row once)
 # and at 7.4-7.9 TB/s from a 151 MB table (uniformly random rows) -- the range the memory system gives row gathers
 GATHER_ROOFLINE_GBS = (5700.0, 7900.0)
-PMC_CHAIN_JSON = "r4_pmc_chain_gemm.json"  # committed PMC summary of tools/roofline_target.py (tools/final_profile.sh)
+PMC_CHAIN_JSON = "r4b_pmc_chain_gemm.json"  # committed PMC summary of tools/roofline_target.py (tools/final_profile.sh)
 
 
 def scale_graph(users: int, items: int, chunk: int = 1_250_000):
