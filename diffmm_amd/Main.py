@@ -286,22 +286,32 @@ class Coach:
         t_diff = time.perf_counter()
         mark(1)
 
-        # DMM_LOADER_PREFETCH=1: the joint phase's shuffled epoch (one permutation draw, three gathers) made on a side stream under the rebuild
-        # instead of between the rebuild and the first joint step.  Off by default -- measured neutral (round 4, 2 x 20 epochs each way: 17.92 / 18.02 ms
-        # per epoch with it, 17.91 / 17.83 without): the joint phase loses 0.2 ms and the rebuild gains them; with the rebuild's own side streams the
-        # process has more streams than the runtime has hardware queues, and the extra stream's launches queue up behind the chain's.
+        # DMM_LOADER_PREFETCH: the joint phase's shuffled epoch (one permutation draw, three gathers: a dozen small launches) made UNDER the rebuild's
+        # reverse chain instead of between the rebuild and the first joint step.  1 = on a stream of its own, forked here: measured neutral (round 4,
+        # 2 x 20 epochs each way: 17.92 / 18.02 ms per epoch with it, 17.91 / 17.83 without) -- with the rebuild's own side streams the process has
+        # more streams than the runtime has hardware queues, and the extra stream's launches queue up behind the chain's.  2 = behind the first
+        # modality's top-k on the rebuild's own low-priority stream (below), which runs under the chain's second launch anyway: neutral as well
+        # (17.69 / 17.53 against 17.78 / 17.49).  Default 0: the loop below draws the epoch, as before.
         prefetched = None
-        if cuda and os.environ.get("DMM_LOADER_PREFETCH", "0") != "0":
-            if getattr(self, "_prep_stream", None) is None:
-                self._prep_stream = torch.cuda.Stream(device=dev)
-            main_s = torch.cuda.current_stream(dev)
-            e0 = torch.cuda.Event(); e0.record(main_s)
-            self._prep_stream.wait_event(e0)
-            with torch.cuda.stream(self._prep_stream):
+        prefetch_mode = int(os.environ.get("DMM_LOADER_PREFETCH", "0")) if cuda else 0
+        main_s = torch.cuda.current_stream(dev) if cuda else None
+
+        def prefetch_on(stream):
+            with torch.cuda.stream(stream):
                 if h.trainLoader.prefetch():
                     for t_ in h.trainLoader._prefetched:
                         t_.record_stream(main_s)
-                    prefetched = torch.cuda.Event(); prefetched.record(self._prep_stream)
+                    e_ = torch.cuda.Event()
+                    e_.record(stream)
+                    return e_
+            return None
+
+        if prefetch_mode == 1:
+            if getattr(self, "_prep_stream", None) is None:
+                self._prep_stream = torch.cuda.Stream(device=dev)
+            e0 = torch.cuda.Event(); e0.record(main_s)
+            self._prep_stream.wait_event(e0)
+            prefetched = prefetch_on(self._prep_stream)
 
         # ---- phase 2: rebuild the modality graphs (Main.py:195-253) ----
         if modal_adj_override is None:
@@ -328,6 +338,8 @@ class Coach:
                 edges = DE.rebuild_edges(lambda loc: dd.rows(loc + lay.u0), [own_local], self.local_ptr32, int(self.local_ptr[-1]), precision=prec,
                                          sampling_step=sstep, csr=(dd.ptr, dd.col32, lay.u0), init_cols=init)
             ready = getattr(DE, "edges_ready", None) if lay is None else None
+            if prefetch_mode == 2 and ready is not None and ready[0] is not None and getattr(DE, "_tail_streams", None):
+                prefetched = prefetch_on(DE._tail_streams[0])  # (in stream order behind modality 0's last GEMM + top-k, i.e. under the chain's second launch)
             adjs = self.graph_builder.build_all(edges, **({"ready": ready} if ready is not None else {}))  # (reads the graphs' sizes back: the host is synchronised here)
             DE.edges_ready = None
             DE.check_chain_error()  # a timed-out group barrier of dmm_latent_chain invalidates these graphs: raise BEFORE any Adam step uses them
