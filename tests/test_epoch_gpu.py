@@ -110,6 +110,22 @@ def test_epochs_match_reference(fx):
     close(np.array(draws.checks), z["draw_checksum"], rtol=1e-12, what="the random draws must be the recorded ones")
 
 
+def test_loader_prefetch_on_a_side_stream_reproduces_the_reference_epoch(monkeypatch):
+    """DMM_LOADER_PREFETCH=1 (the joint phase's shuffled epoch gathered on a side stream under the rebuild; off by default, measured neutral) against the
+    reference's own epoch: the same permutation from the same generator, handed to the loop through the loader -- losses as in the default path."""
+    need_gpu()
+    monkeypatch.setenv("DMM_LOADER_PREFETCH", "1")
+    z = load("epoch_mid.npz")
+    coach, h, M = _coach(z)
+    draws = _Draws(z)
+    for ep in range(int(z["epochs"])):
+        h.trainData.set_negs(z[f"ep{ep}/negs"])
+        res = coach.trainEpoch(draws=draws)
+        assert getattr(h.trainLoader, "_prefetched", None) is None, "the loop must have consumed the prefetched epoch"
+        for k, v in res.items():
+            close(v, z[f"ep{ep}/train/{k}"], what=f"ep{ep} {k}", rtol=5e-3, atol=1e-5)
+
+
 @pytest.mark.parametrize("precision", [1, 3])
 def test_epoch_with_noised_chain_start(precision):
     """sampling_step > 0 (every modality's reverse chain starts from its own q_sample(x_0)): the epoch runs on both arithmetic modes
