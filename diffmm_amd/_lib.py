@@ -120,6 +120,7 @@ _SIGS = {
     "dmm_cast_batch_rows_bf16": (C.c_int, [C.POINTER(_P), C.POINTER(_P), _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "dmm_infonce_pack_bytes": (C.c_int64, [_I, _I, _I]),
     "dmm_gather_normalize": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
+    "dmm_gather_normalize_hi": (C.c_int, [C.POINTER(GatherDesc), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_infonce_fwd": (C.c_int, [_P, _P, _I, _I, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P]),
     "dmm_infonce_fwd_bwd": (C.c_int, [_P, _P, _I, _I, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P, _P, _P]),
     "dmm_infonce_bwd": (C.c_int, [_P, _P, _I, _I, _P, C.POINTER(InfoNCETerm), _I, _I, _I, _P, _P]),

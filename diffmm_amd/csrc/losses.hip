@@ -39,7 +39,9 @@ struct Bf16Pack {
   int Bp;
 };
 
-template <int D>
+// LO = false (dmm_gather_normalize_hi: the caller's InfoNCE launches run at precision 1): only the hi / hiT blocks of the pack are written -- the lo / loT
+// blocks, 5 of the 11 stores per lane, feed nothing but the split-precision kernels.
+template <int D, bool LO = true>
 __global__ __launch_bounds__(256) void gather_normalize_kernel(SlotTable S, int B, float* __restrict__ zhat, float* __restrict__ norm,
                                                                 Bf16Pack pk) {
   constexpr int LANES = D / 4, G = 256 / LANES;
@@ -70,14 +72,14 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(SlotTable S, int 
       // row-fragment order: columns c0..c0+3 share (ks, h) and are 4 consecutive elements
       const size_t o = ((((size_t)s * (pk.Bp >> 5) + tile) * (D / 16) + (c0 >> 4)) * 2 + ((c0 >> 3) & 1)) * 32 * 8 + (size_t)r * 8 + (c0 & 7);
       *reinterpret_cast<bf16x4*>(pk.hi + o) = bf16x4{h[0], h[1], h[2], h[3]};
-      *reinterpret_cast<bf16x4*>(pk.lo + o) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+      if (LO) *reinterpret_cast<bf16x4*>(pk.lo + o) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
       // k-packed transposed order
       const int r4 = r & 15, ss = r >> 4, hh = (r4 >> 2) & 1, e = ((r4 >> 3) << 2) | (r4 & 3);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const size_t ot = (((((size_t)s * (pk.Bp >> 5) + tile) * 2 + ss) * 2 + hh) * D + c0 + j) * 8 + e;
         pk.hiT[ot] = h[j];
-        pk.loT[ot] = lo[j];
+        if (LO) pk.loT[ot] = lo[j];
       }
     }
   }
@@ -1135,8 +1137,16 @@ static bool mfma_ok(int D) { return D == 32 || D == 64 || D == 128 || D == 256; 
 
 extern "C" int64_t dmm_infonce_pack_bytes(int n_slots, int B, int D) { return (int64_t)4 * n_slots * ((B + 31) & ~31) * D * 2; }
 
+static int gather_normalize(const dmm_gather_desc* slots, int n_slots, int B, int D, float* zhat, float* norm, void* bf16_pack, bool lo, void* stream);
 extern "C" int dmm_gather_normalize(const dmm_gather_desc* slots, int n_slots, int B, int D, float* zhat, float* norm, void* bf16_pack,
                                     void* stream) {
+  return gather_normalize(slots, n_slots, B, D, zhat, norm, bf16_pack, true, stream);
+}
+extern "C" int dmm_gather_normalize_hi(const dmm_gather_desc* slots, int n_slots, int B, int D, float* zhat, float* norm, void* bf16_pack,
+                                       void* stream) {
+  return gather_normalize(slots, n_slots, B, D, zhat, norm, bf16_pack, false, stream);
+}
+static int gather_normalize(const dmm_gather_desc* slots, int n_slots, int B, int D, float* zhat, float* norm, void* bf16_pack, bool lo, void* stream) {
   SlotTable S;
   if (int e = fill_slots(slots, n_slots, S)) return e;
   DMM_CHECK_ARG(zhat && norm && B > 0 && d_ok(D), "dmm_gather_normalize: bad arguments (B=%d D=%d)", B, D);
@@ -1145,7 +1155,8 @@ extern "C" int dmm_gather_normalize(const dmm_gather_desc* slots, int n_slots, i
   const int G = 1024 / D;
   const int rows = bf16_pack ? pk.Bp : B;
   dim3 grid(cdiv(rows, G) > 1024 ? 1024 : cdiv(rows, G), n_slots);
-  DISPATCH_D(D, hipLaunchKernelGGL(gather_normalize_kernel<DD>, grid, dim3(256), 0, (hipStream_t)stream, S, B, zhat, norm, pk));
+  if (lo || !bf16_pack) { DISPATCH_D(D, hipLaunchKernelGGL(gather_normalize_kernel<DD>, grid, dim3(256), 0, (hipStream_t)stream, S, B, zhat, norm, pk)); }
+  else { DISPATCH_D(D, hipLaunchKernelGGL((gather_normalize_kernel<DD, false>), grid, dim3(256), 0, (hipStream_t)stream, S, B, zhat, norm, pk)); }
   DMM_LAUNCH_CHECK("dmm_gather_normalize");
   return 0;
 }

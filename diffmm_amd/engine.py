@@ -444,7 +444,7 @@ class JointEngine:
         lse = self.lse.view(-1)[: nT * B].view(nT, B)
         row_loss = self.row_loss.view(-1)[: (nT + 1) * B].view(nT + 1, B)
         pk = dict(pack=self.pack, n_slots=self.n_slots, precision=precision) if self.mfma_cl else {}
-        ops.gather_normalize(slots, B, D, zhat, znorm, self.pack)
+        ops.gather_normalize(slots, B, D, zhat, znorm, self.pack, hi_only=(precision == 1))
         ops.infonce_fwd_bwd(zhat, terms, nT, B, D, lse, row_loss, dzhat, **pk)  # (rows are unit-norm: forward + both gradient passes in one call)
         ops.bpr_fwd_bwd(self.Fin, users, pos, neg, U, row_loss[nT], self.dFin)
         # row losses -> loss_parts[: nT + 1], the l2 term -> loss_parts[nT + 1], and both added to the epoch's fp64 sums loss_acc: one launch

@@ -479,8 +479,10 @@ def infonce_pack(n_slots: int, B: int, D: int, device) -> Tensor:
     return torch.zeros(int(L.lib().dmm_infonce_pack_bytes(n_slots, B, D)) // 2, dtype=torch.bfloat16, device=device)
 
 
-def gather_normalize(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, pack: Optional[Tensor] = None) -> None:
-    L.call("dmm_gather_normalize", slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm), L.ptr(pack), L.stream())
+def gather_normalize(slots: Slots, B: int, D: int, zhat: Tensor, norm: Tensor, pack: Optional[Tensor] = None, hi_only: bool = False) -> None:
+    """hi_only: the pack's lo / loT blocks are not written (the InfoNCE launches that read this pack run at precision 1)."""
+    L.call("dmm_gather_normalize_hi" if (hi_only and pack is not None) else "dmm_gather_normalize", slots.arr, slots.n, B, D, L.ptr(zhat), L.ptr(norm),
+           L.ptr(pack), L.stream())
 
 
 def infonce_fwd(zhat: Tensor, terms, n_terms: int, B: int, D: int, lse: Tensor, row_loss: Tensor, pack: Optional[Tensor] = None,

@@ -273,6 +273,9 @@ typedef struct dmm_infonce_term {
 int64_t dmm_infonce_pack_bytes(int n_slots, int B, int D);
 int dmm_gather_normalize(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, float* zhat /*[n_slots,B,D]*/,
                          float* norm /*[n_slots,B]*/, void* bf16_pack, void* stream);
+/* The same with only the hi / hiT blocks of the pack written: for callers whose InfoNCE launches run at precision 1 (the lo / loT blocks feed the
+ * split-precision kernels only; their contents are then undefined). */
+int dmm_gather_normalize_hi(const dmm_gather_desc* slots /*host*/, int n_slots, int B, int D, float* zhat, float* norm, void* bf16_pack, void* stream);
 int dmm_infonce_fwd(const float* zhat, const void* bf16_pack, int n_slots, int precision, const dmm_infonce_term* terms /*host*/,
                     int n_terms, int B, int D, float* lse /*[n_terms,B]*/, float* row_loss /*[n_terms,B], weight/B folded in*/,
                     void* stream);

@@ -1416,3 +1416,31 @@ def test_recorded_spmm_survives_a_rebuild_that_brings_giant_rows(dev):
     y.zero_()
     L.replay(plan)  # (raised "giant rows need partial + fix buffers" before the fix)
     close(y.cpu().numpy(), (dense(adj) @ x).cpu().numpy(), rtol=1e-5, atol=1e-5, what="after the rebuild")
+
+
+@pytest.mark.gpu
+def test_gather_normalize_hi_only_pack(dev):
+    """dmm_gather_normalize_hi writes zhat, the norms and the hi / hiT blocks exactly as dmm_gather_normalize does and leaves the lo / loT blocks alone;
+    the precision-1 InfoNCE launches on it give the results of the full pack bit for bit."""
+    from diffmm_amd import ops
+    torch.manual_seed(2)
+    B, D, S = 300, 64, 4
+    src = [torch.randn(500, D, device=dev) for _ in range(S)]
+    idx = torch.randint(0, 500, (B,), device=dev, dtype=torch.int32)
+    slots = ops.Slots([(src[s], idx, torch.zeros_like(src[s])) for s in range(S)])
+    terms = ops.make_terms([(0, 1, 0.2, 0.5), (2, 3, 0.5, 0.01), (0, 3, 0.3, 1.0)])
+    res = []
+    for hi_only in (False, True):
+        zhat, znorm = torch.zeros(S, B, D, device=dev), torch.zeros(S, B, device=dev)
+        pack = ops.infonce_pack(S, B, D, dev)
+        pack.fill_(7.0)
+        ops.gather_normalize(slots, B, D, zhat, znorm, pack, hi_only=hi_only)
+        lse, rl, dz = torch.zeros(3, B, device=dev), torch.zeros(3, B, device=dev), torch.zeros(S, B, D, device=dev)
+        ops.infonce_fwd(zhat, terms, 3, B, D, lse, rl, pack=pack, n_slots=S, precision=1)
+        res.append((zhat.clone(), znorm.clone(), pack.clone(), lse.clone(), rl.clone()))
+    (z0, n0, p0, l0, r0), (z1, n1, p1, l1, r1) = res
+    assert torch.equal(z0, z1) and torch.equal(n0, n1) and torch.equal(l0, l1) and torch.equal(r0, r1)
+    q = p0.numel() // 4  # blocks in the pack: hi, lo, hiT, loT (make_pack)
+    same = [bool(torch.equal(p0[i * q:(i + 1) * q], p1[i * q:(i + 1) * q])) for i in range(4)]
+    untouched = [bool((p1[i * q:(i + 1) * q] == 7.0).all()) for i in range(4)]
+    assert sum(same) == 2 and sum(untouched) == 2 and not any(a and b for a, b in zip(same, untouched)), (same, untouched)
