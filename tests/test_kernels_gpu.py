@@ -1444,3 +1444,63 @@ def test_gather_normalize_hi_only_pack(dev):
     same = [bool(torch.equal(p0[i * q:(i + 1) * q], p1[i * q:(i + 1) * q])) for i in range(4)]
     untouched = [bool((p1[i * q:(i + 1) * q] == 7.0).all()) for i in range(4)]
     assert sum(same) == 2 and sum(untouched) == 2 and not any(a and b for a, b in zip(same, untouched)), (same, untouched)
+
+
+@pytest.mark.gpu
+def test_loss_reduce_equals_the_separate_reductions(dev):
+    """dmm_loss_reduce (row-loss segment sums + the l2 term + the epoch's fp64 running sums in one launch) against dmm_segment_sum and dmm_sumsq: the same
+    sums in the same order (bit-identical outputs), the accumulator advanced by exactly the outputs, the arrival counter left at zero -- twice in a row."""
+    from diffmm_amd import ops, _lib as L
+    torch.manual_seed(0)
+    n_seg, B, n = 9, 4096, 16018 * 64 + 3
+    rl = torch.randn(n_seg, B, device=dev)
+    x = torch.randn(n + 1, device=dev)[:n]  # (n % 4 != 0: the tail path)
+    base = torch.zeros(1, device=dev)
+    want_seg, want_x = torch.zeros(n_seg, device=dev), torch.zeros(1, device=dev)
+    ops.segment_sum(rl, n_seg, B, 0.5, want_seg)
+    x16 = torch.zeros(n + 4, device=dev)  # a 16-byte aligned copy (dmm_sumsq / dmm_loss_reduce need it)
+    x16[:n] = x
+    xa = x16[:n]
+    ops.sumsq(xa, 1e-4, want_x)
+    scratch = torch.zeros(int(L.lib().dmm_sumsq_scratch(n)) + 1, device=dev)
+    acc = torch.zeros(n_seg + 1, dtype=torch.float64, device=dev)
+    for rep in range(2):
+        got_seg, got_x = torch.zeros(n_seg, device=dev), torch.zeros(1, device=dev)
+        ops.loss_reduce(rl, n_seg, B, 0.5, got_seg, xa, 1e-4, got_x, scratch, acc=acc, acc_x=n_seg)
+        assert torch.equal(got_seg, want_seg) and torch.equal(got_x, want_x), rep
+        assert int(scratch[-1:].view(torch.int32).item()) == 0, "arrival counter must be reset"
+    want_acc = 2.0 * torch.cat([want_seg.double(), want_x.double()])
+    assert torch.equal(acc, want_acc)
+
+
+@pytest.mark.gpu
+def test_zero_regions(dev):
+    from diffmm_amd import ops
+    a, b, c = torch.ones(1000, 64, device=dev), torch.ones(12, device=dev), torch.ones(4 * 77, dtype=torch.float64, device=dev)
+    big = torch.ones(3 * 1024 * 1024 + 4, device=dev)
+    ops.zero_regions([a, b[4:12], c, big[4:]])
+    assert float(a.abs().sum()) == 0 and float(c.abs().sum()) == 0 and float(big[4:].abs().sum()) == 0
+    assert torch.equal(b, torch.tensor([1.0] * 4 + [0.0] * 8, device=dev)) and float(big[:4].sum()) == 4.0
+    with pytest.raises(ValueError):
+        ops.zero_regions([b[1:5]])  # not 16-byte aligned
+
+
+@pytest.mark.gpu
+def test_csr_gather_sum_latent_batched_equals_single(dev):
+    """The chain's CSR start for several operand tables in one launch == one launch per table (bit-identical z_T and h_{T-1})."""
+    from diffmm_amd import ops
+    rng = np.random.default_rng(4)
+    U, I, H, Bn = 300, 500, 256, 120
+    deg = rng.integers(0, 40, size=U); deg[5] = 400
+    ptr = T(np.concatenate([[0], np.cumsum(deg)]).astype(np.int64), dev)
+    col = T(np.concatenate([np.sort(rng.choice(I, size=d, replace=False)) for d in deg]).astype(np.int32), dev)
+    rows = T(rng.choice(U, size=Bn, replace=False).astype(np.int64), dev)
+    Wt = [T(rng.standard_normal((I, H)).astype(np.float32), dev).to(torch.bfloat16) for _ in range(3)]
+    bias = [T(rng.standard_normal(H).astype(np.float32), dev) for _ in range(3)]
+    z1 = [torch.zeros(Bn, H, device=dev) for _ in range(3)]; h1 = [torch.zeros(Bn, H, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    z2 = [torch.zeros(Bn, H, device=dev) for _ in range(3)]; h2 = [torch.zeros(Bn, H, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    for m in range(3):
+        ops.csr_gather_sum_latent(ptr, col, rows, Wt[m], bias[m], z1[m], h1[m])
+    ops.csr_gather_sum_latent_batched(ptr, col, rows, [dict(Wt=Wt[m], bias=bias[m], z=z2[m], out16=h2[m]) for m in range(3)])
+    for m in range(3):
+        assert torch.equal(z1[m], z2[m]) and torch.equal(h1[m], h2[m]), m
