@@ -150,6 +150,16 @@ def patch_spmm_sizes(refs) -> None:
         p.n_fix = int(a.fix.shape[0]) if a.fix is not None else 0
 
 
+def chain_parts(per: int, rows: int, n_mods: int) -> List[int]:
+    """The persistent chain's launches: modality-major groups of 256 rows, `per` groups per launch (dmm_latent_chain_groups_per_launch).  Returns, for
+    every launch, how many modalities are complete once it has run -- [] when one launch takes everything (or the persistent form cannot run)."""
+    rbs = -(-rows // 256)
+    total = n_mods * rbs
+    if per <= 0 or total <= per:
+        return []
+    return [min(n_mods, ((p + 1) * per) // rbs) if (p + 1) * per < total else n_mods for p in range(-(-total // per))]
+
+
 def modality_names(M: int) -> Tuple[str, ...]:
     return MODAL[:M] if M == 3 else ("image", "text")
 
@@ -1466,13 +1476,8 @@ class DiffusionEngine:
 
     def _chain_parts(self, B: int, n_mods: int) -> List[int]:
         """Launches of the persistent chain over n_mods modalities of B rows -> for every launch, how many modalities are COMPLETE once it has run
-        (modality-major groups of 256 rows, ops.latent_chain_groups_per_launch groups per launch).  [] when the chain is not launched in parts."""
-        per = ops.latent_chain_groups_per_launch(self.H) if self._latent_fused() else 0
-        rbs = -(-B // 256)
-        total = n_mods * rbs
-        if per <= 0 or total <= per:
-            return []
-        return [min(n_mods, ((p + 1) * per) // rbs) if (p + 1) * per < total else n_mods for p in range(-(-total // per))]
+        (chain_parts below).  [] when the chain is not launched in parts."""
+        return chain_parts(ops.latent_chain_groups_per_launch(self.H) if self._latent_fused() else 0, B, n_mods)
 
     def _latent_h0(self, rows: Optional[CsrRows] = None, xT=None, B: Optional[int] = None, mods: Optional[Sequence[int]] = None, parts: bool = False):
         """The latent chain down to h_0 (bf16 [B, H] per modality; see generate_views_latent).  Returns ({m: h_0}, B).

@@ -333,3 +333,17 @@ def test_graft_entry_build_runs():
         sys.path.insert(0, REPO)
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_chain_parts_says_which_modalities_a_launch_completes():
+    """engine.chain_parts (what DiffusionEngine.rebuild_edges uses to put a finished modality's tail under the next launch of the persistent chain)."""
+    from diffmm_amd.engine import chain_parts
+    assert chain_parts(64, 9308, 3) == [1, 3]          # the bench shape: 37 groups per modality, 64 + 47
+    assert chain_parts(64, 9308, 1) == []              # one launch
+    assert chain_parts(0, 9308, 3) == []               # the persistent form cannot run
+    assert chain_parts(64, 19445, 2) == [0, 1, 2]      # Baby shape: 76 groups per modality -- nothing complete after the first launch
+    assert chain_parts(64, 256 * 64, 2) == [1, 2]      # a boundary: the first launch ends exactly with modality 0
+    assert chain_parts(32, 256 * 16, 4) == [2, 4]
+    for per, rows, m in ((64, 9308, 3), (40, 5000, 4), (8, 300, 3)):
+        cp = chain_parts(per, rows, m)
+        assert cp == sorted(cp) and (not cp or cp[-1] == m)
