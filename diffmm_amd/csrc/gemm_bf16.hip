@@ -427,7 +427,8 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   // tiles -- one round of the LDS-DMA tile is still twice as fast as the register-staged tiles at that size)
   static const int use_8ph = [] { const char* e = getenv("DMM_GEMM_8PH"); return e ? atoi(e) : 1; }();  // 0: register-staged tiles only
   const long long t8 = (long long)cdiv(M, 256) * cdiv(N, 256) * n_batch;
-  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= 64))) {
+  static const int min_t8 = [] { const char* e = getenv("DMM_GEMM_8PH_MIN_TILES"); return e ? atoi(e) : 64; }();  // (tuning knob)
+  if (a0->K % 64 == 0 && (force_tile == 512 || (force_tile == 0 && use_8ph && t8 >= min_t8))) {
     for (int i = 0; i < n_batch; ++i) {
       b.p[i].mt = cdiv(M, 256); b.p[i].nt = cdiv(N, 256); b.p[i].part = force_part >= 0 ? force_part : 2;
     }
