@@ -438,6 +438,8 @@ extern "C" int dmm_gemm_bf16_nt_batched(const dmm_gemm_bf16_args* args, int n_ba
   }
   const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 128) * n_batch, t128 = (long long)cdiv(M, 128) * cdiv(N, 128) * n_batch;
   int tile = t256 >= 768 ? 256 : (t128 >= 512 ? 128 : 64);  // big tiles only when they still fill the 256 CUs several times over
+  // (round 4: taking 128 x 128 for the long-K launches the rule below gives 128 x 64 -- the third diffusion batch's layer-1 / dh products, 216 tiles; the
+  // G refresh, 192 -- measured slower or neutral)
   if (force_tile) tile = force_tile;
   const int bm = tile == 256 ? 256 : 128, bn = tile == 64 ? 64 : 128;
   const int mt = cdiv(M, bm), nt = cdiv(N, bn);
