@@ -1031,10 +1031,6 @@ static void walk_launch(int n_terms, hipStream_t s, Bf16Pack pk, const float* zh
                        row_loss, dzhat);
   }
 }
-template <int D, int PREC>
-static void inf_launch(int n_terms, hipStream_t s, Bf16Pack pk, const float* zhat, const TermTable& T, int B, float* lse, float* row_loss, float* dzhat) {
-  walk_launch<D, PREC, true>(n_terms, s, pk, zhat, T, B, lse, row_loss, dzhat);
-}
 static bool walk_ok(int D, int precision, bool product) {  // WalkShape<>::OK of the instantiations the dispatch below can reach
   if (product) return !(D == 256 && precision == 3);
   return D >= 64;
