@@ -1504,3 +1504,41 @@ def test_csr_gather_sum_latent_batched_equals_single(dev):
     ops.csr_gather_sum_latent_batched(ptr, col, rows, [dict(Wt=Wt[m], bias=bias[m], z=z2[m], out16=h2[m]) for m in range(3)])
     for m in range(3):
         assert torch.equal(z1[m], z2[m]) and torch.equal(h1[m], h2[m]), m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,prec", [(1000, 64, 1), (4160, 64, 1), (257, 128, 1), (300, 256, 1), (300, 256, 3), (97, 64, 1)])
+def test_infonce_mfma_every_walk_form_against_the_fp32_kernels(dev, B, D, prec):
+    """The round-4 forms of the backward walk against the fp32 VALU kernels: two own tiles per wave (d = 64, precision 1 -- with B = 1000 / 97 the wave's
+    second tile is partly or wholly past the view, with B = 4160 the walk is cut into splits of unequal length), one tile pipelined (d = 128, 256) and
+    the two-stage ring without the pipeline (d = 256, precision 3).  Precision 1 rounds the operands to bf16: lse within 2e-2, gradients within 3 % of
+    their scale; precision 3 as tight as test_infonce_mfma_matches_valu_kernels."""
+    from diffmm_amd import ops
+    rng = np.random.default_rng(B + D)
+    n = 3000
+    views = [T(rng.standard_normal((n, D)).astype(np.float32)).to(dev) for _ in range(3)]
+    idx = T(rng.integers(0, n, size=B).astype(np.int32)).to(dev)
+    terms_l = [(0, 1, 0.2, 0.5), (0, 2, 0.5, 0.01), (1, 2, 0.5, 1.0)]
+    res = {}
+    for p in (0, prec):
+        grads = [torch.zeros_like(v) for v in views]
+        slots = ops.Slots([(v, idx, g) for v, g in zip(views, grads)])
+        terms = ops.make_terms(terms_l)
+        zhat, nrm, dz = torch.empty(3, B, D, device=dev), torch.empty(3, B, device=dev), torch.zeros(3, B, D, device=dev)
+        lse, rl = torch.empty(3, B, device=dev), torch.empty(3, B, device=dev)
+        pack = ops.infonce_pack(3, B, D, dev) if p else None
+        kw = dict(pack=pack, n_slots=3, precision=p) if p else {}
+        ops.gather_normalize(slots, B, D, zhat, nrm, pack, hi_only=(p == 1))
+        if p:
+            ops.infonce_fwd_bwd(zhat, terms, 3, B, D, lse, rl, dz, **kw)
+        else:
+            ops.infonce_fwd(zhat, terms, 3, B, D, lse, rl)
+            ops.infonce_bwd(zhat, lse, terms, 3, B, D, dz)
+        ops.scatter_normalize_bwd(slots, B, D, zhat, nrm, dz)
+        res[p] = (lse.clone(), rl.clone(), [g.clone() for g in grads])
+    tl, tg = (2e-2, 3e-2) if prec == 1 else (2e-5, 1e-3)
+    close(res[prec][0], res[0][0], rtol=tl, atol=tl, what="lse")
+    close(res[prec][1].sum(1), res[0][1].sum(1), rtol=max(tl, 5e-5), what="term losses")
+    for a, b in zip(res[prec][2], res[0][2]):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= tg * sc, f"gradients: {float((a - b).abs().max()) / sc:.3e} of scale"
