@@ -353,7 +353,7 @@ class Coach:
 
         # ---- phase 3: joint training (Main.py:292-377) ----
         acc = torch.zeros(J.loss_parts.numel(), dtype=torch.float64, device=dev)
-        in_kernel_acc = isinstance(getattr(J, "loss_acc", None), torch.Tensor)  # (the single-GPU engine: its loss reduction adds to fp64 sums itself)
+        in_kernel_acc = isinstance(getattr(J, "loss_acc", None), torch.Tensor) and os.environ.get("DMM_LOSS_ACC", "1") != "0"  # (the single-GPU engine: its loss reduction adds to fp64 sums itself)
         if in_kernel_acc:
             J.loss_acc.zero_()
         if prefetched is not None:

@@ -106,7 +106,10 @@ def test_tiktok_shape_epochs_with_bf16_gather_operands():
     N = ref["users"] + ref["items"]
     for i, (a, b) in enumerate(zip(ref["epochs"], got["epochs"])):
         assert b["modal_nnz"] == [2 * ref["E"] + N] * 3
-        tols = {"Loss": 0.01, "BPR Loss": 0.01, "CL loss": 0.01, "reg loss": 0.01} if i == 0 else {"Loss": 0.02, "BPR Loss": 0.10, "CL loss": 0.03, "reg loss": 0.08}
+        # (first epoch: two RUNS of this configuration differ by more than the arithmetic modes do -- 30 single-GPU runs in round 4, fp32 operands: BPR 0.6595 .. 0.6635
+        # in most, 0.650 .. 0.655 in one run of five (the rebuilt graphs after ten Denoise steps rank near-uniform scores: ties flip with the order of the float
+        # atomics), reg 0.0333 .. 0.0338, CL 3.478 .. 3.493, total 4.173 .. 4.181 -- so BPR and reg are held to 2.5 % / 3 %, the others to 1 %)
+        tols = {"Loss": 0.01, "BPR Loss": 0.025, "CL loss": 0.01, "reg loss": 0.03} if i == 0 else {"Loss": 0.02, "BPR Loss": 0.10, "CL loss": 0.03, "reg loss": 0.08}
         for k, tol in tols.items():
             assert abs(a["train"][k] - b["train"][k]) <= tol * abs(a["train"][k]), f"epoch {i} {k}: fp32 operands {a['train'][k]:.5f} vs bf16 {b['train'][k]:.5f}"
         assert abs(a["test"]["Recall"] - b["test"]["Recall"]) <= 0.03
@@ -163,6 +166,8 @@ def test_tiktok_shape_epochs_with_users_and_items_sharded(denoise_shard):
     N = single["users"] + single["items"]
     assert shard["modal_nnz_sum_over_replicas"] == [2 * single["E"] + N] * 3
     s, d = single["epochs"][0], shard["epochs"][0]
-    for k, tol in (("Loss", 0.02), ("BPR Loss", 0.01), ("CL loss", 0.02), ("reg loss", 0.08)):
+    # (BPR: 2.5 % -- the run-to-run spread of this configuration's first epoch, see test_tiktok_shape_epochs_with_bf16_gather_operands; at 1 % this test failed
+    # in one run of three with a single-GPU value of 0.650 .. 0.652 against 0.660 on the replicas, and so did two single-GPU runs against each other)
+    for k, tol in (("Loss", 0.02), ("BPR Loss", 0.025), ("CL loss", 0.02), ("reg loss", 0.08)):
         assert abs(s["train"][k] - d["train"][k]) <= tol * abs(s["train"][k]), f"{k}: single {s['train'][k]:.5f} vs 2D-sharded {d['train'][k]:.5f}"
     assert abs(single["epochs"][1]["test"]["Recall"] - shard["epochs"][1]["test"]["Recall"]) <= 0.03
